@@ -1,0 +1,30 @@
+"""Shared test helpers: fixture loading and oracle state plumbing."""
+import json
+import os
+
+import numpy as np
+
+from oracle import nav_oracle as no
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def cfg_of(fx):
+    args = json.loads(str(fx['args']))
+    return no.Config(**{k: v for k, v in args.items() if k in no.Config.__dataclass_fields__})
+
+
+def state_from(fx, cfg, prefix='init_'):
+    n = fx[prefix + 'agent_pos'].shape[0]
+    st = no.State(cfg, n)
+    for k in no.State.FIELDS:
+        getattr(st, k)[...] = fx[prefix + k]
+    return st
+
+
+TRAJ = ['traj_n3.npz', 'traj_n3w2.npz', 'traj_n1.npz', 'traj_n2o1w1.npz', 'traj_n10.npz', 'traj_n32.npz',
+        'traj_n3_ep5.npz', 'traj_n3_float.npz', 'traj_n4_knobs.npz', 'traj_crafted.npz']

@@ -1,0 +1,40 @@
+"""Oracle lexifair: polynomial solver vs brute force, KAT-7, reference call-site shapes.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle.lexifair import lexifair, lexifair_bruteforce, solve_fair_assignment
+from oracle.nav_oracle import cost_matrix
+
+
+def test_kat7_reference_main_example():
+    """marl_fair_assign.py:62-63 example (the only concrete input in the reference)."""
+    goals = np.array([[0., -0.5], [0.45, -0.5], [0.9, -0.5]])
+    agents = np.array([[-0.9, -0.9], [-0.9, 0.], [-0.9, 0.9]])
+    costs = cost_matrix(agents, goals)
+    assert np.allclose(costs[0], [0.98488578, 1.40801278, 1.84390889])
+    x, objs = solve_fair_assignment(costs)
+    assert np.array_equal(np.where(x == 1)[1], [2, 1, 0])  # navigation_graph.py:559
+    assert np.allclose(objs, [1.8439088915, 1.6643316977, 1.4396180049])
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 6, 7])
+def test_polynomial_vs_bruteforce(n):
+    rs = np.random.RandomState(n)
+    for _ in range(40 if n < 7 else 8):
+        a, g = rs.uniform(-1, 1, (n, 2)), rs.uniform(-0.8, 0.8, (n, 2))
+        c = cost_matrix(a, g)
+        assert np.array_equal(lexifair(c), lexifair_bruteforce(c))
+
+
+def test_lexicographic_property_n32():
+    """No single swap of two agents' goals may improve the sorted-descending cost vector."""
+    rs = np.random.RandomState(0)
+    c = cost_matrix(rs.uniform(-1, 1, (32, 2)), rs.uniform(-0.8, 0.8, (32, 2)))
+    p = lexifair(c)
+    assert sorted(p) == list(range(32))
+    base = np.sort(c[np.arange(32), p])[::-1]
+    for i in range(32):
+        for j in range(i + 1, 32):
+            q = p.copy(); q[i], q[j] = p[j], p[i]
+            alt = np.sort(c[np.arange(32), q])[::-1]
+            assert tuple(base) <= tuple(alt)
