@@ -1,0 +1,76 @@
+"""ctypes binding of ``libfmarl.so`` (declarations: ``include/fmarl.h``).  Fails loudly if the
+HIP library has not been built -- there is deliberately no fallback implementation."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libfmarl.so')
+
+INFO_WIDTH = 14
+(F_AGENT_POS, F_AGENT_VEL, F_P_DIST, F_LANDMARK_POS, F_OBSTACLE_POS, F_WALL_AXIS, F_WALL_E0, F_WALL_E1,
+ F_WALL_ORIENT, F_WALL_LENGTH, F_GOAL_MATCH, F_DISTS_TO_GOAL, F_TIMES_REQUIRED, F_DIST_LEFT,
+ F_NUM_OBST_COLL, F_NUM_AGENT_COLL, F_MIN_TIME, F_CUR_STEP, F_EPISODE, F_SLOT_POS, F_SLOT_OCC,
+ F_SLOT_DELTA, F_FORMATION_DONE, F_RESET_FLAG, NUM_FIELDS) = range(25)
+FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_e0',
+               'wall_e1', 'wall_orient', 'wall_length', 'goal_match', 'dists_to_goal', 'times_required',
+               'dist_left', 'num_obst_coll', 'num_agent_coll', 'min_time', 'cur_step', 'episode',
+               'slot_pos', 'slot_occ', 'slot_delta', 'formation_done', 'reset_flag')
+DTYPE_F64, DTYPE_I32 = 0, 1
+SCENARIOS = {'navigation_graph': 0, 'fair_graph_formation': 1}
+
+
+class FmarlConfig(C.Structure):
+    _fields_ = [('scenario', C.c_int32), ('n_envs', C.c_int32), ('num_agents', C.c_int32),
+                ('num_landmarks', C.c_int32), ('num_obstacles', C.c_int32), ('num_walls', C.c_int32),
+                ('episode_length', C.c_int32), ('has_max_speed', C.c_int32), ('env_offset', C.c_int32),
+                ('reserved0', C.c_int32), ('world_size', C.c_double), ('max_speed', C.c_double),
+                ('collision_rew', C.c_double), ('goal_rew', C.c_double), ('min_dist_thresh', C.c_double),
+                ('fair_rew', C.c_double), ('zeroshift', C.c_double), ('max_edge_dist', C.c_double),
+                ('seed', C.c_uint64)]
+
+
+class FmarlOutputs(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('node_obs', C.c_void_p), ('adj', C.c_void_p), ('reward', C.c_void_p),
+                ('done', C.c_void_p), ('info', C.c_void_p)]
+
+
+_SIGS = {
+    'fmarl_create': (C.c_int, [C.POINTER(FmarlConfig), C.POINTER(C.c_void_p)]),
+    'fmarl_destroy': (C.c_int, [C.c_void_p]),
+    'fmarl_last_error': (C.c_char_p, []),
+    'fmarl_state_bytes': (C.c_size_t, [C.POINTER(FmarlConfig)]),
+    'fmarl_state_field': (C.c_int, [C.POINTER(FmarlConfig), C.c_int, C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    'fmarl_init_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fmarl_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs), C.c_void_p]),
+    'fmarl_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs),
+                             C.c_int, C.c_void_p]),
+    'fmarl_state_changed': (C.c_int, [C.c_void_p]),
+    'fmarl_cost_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'fmarl_lexifair': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'fmarl_update_graph': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_double, C.c_void_p]),
+}
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def load():
+    """Load libfmarl.so and attach the prototypes of include/fmarl.h."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'fair_marl_amd: %s is missing -- build it first (python -c "import __graft_entry__ as g; '
+                'g.build()").  There is no CPU fallback for the rollout path.' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, load().fmarl_last_error().decode()))

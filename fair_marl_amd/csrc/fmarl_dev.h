@@ -1,0 +1,99 @@
+// Device-side definitions shared by the gfx950 kernels of libfmarl (CDNA4 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fmarl.h"
+
+namespace fmarl {
+
+// World constants: reference multiagent/core.py:153-161, :68, :38; environment.py:307.
+constexpr double kDt = 0.1;
+constexpr double kDamping = 0.25;
+constexpr double kContactForce = 3e2;
+constexpr double kContactMargin = 2e-2;
+constexpr double kWallContactForce = 2.2e2;
+constexpr double kWallContactMargin = 2.4e-2;
+constexpr double kEntitySize = 0.05;
+constexpr double kWallWidth = 0.1;
+constexpr double kSensitivity = 5.0;
+constexpr int kThreads = 256;       // workgroup size of the step / emit kernels (4 waves)
+constexpr int kMaxTries = 10000;    // bound on the reference's unbounded rejection loops
+constexpr int kBWidth = 5;          // ego table width: vx, vy, x, y, 0
+
+// floor(q / d) for q * d < 2^40, q < 2^24 (block-local flat indices): one 64-bit multiply.
+struct FastDiv {
+    uint64_t m;
+    uint32_t d;
+    __host__ void set(uint32_t div) { d = div; m = ((1ull << 40) + div - 1) / div; }
+    __device__ __forceinline__ uint32_t div(uint32_t q) const { return (uint32_t)(((uint64_t)q * m) >> 40); }
+};
+
+// Kernel parameter block (passed by value).  State pointers follow include/fmarl.h FMARL_F_*.
+struct Params {
+    int n_envs, N, L, O, W, E, D, F;
+    int episode_length, has_max_speed, env_offset, scenario;
+    int epb;                 // environments per workgroup = kThreads / N
+    int lds_pos, lds_stat, lds_a, lds_b, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
+    double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
+    uint64_t seed;
+    FastDiv dNEF, dEF, dF, dEE, dE, dLO;
+    uint64_t bsel;           // nibble f = ego-table column subtracted from feature column f (4 = constant 0)
+    // state
+    double2 *agent_pos, *agent_vel, *landmark_pos, *obstacle_pos;
+    double *p_dist, *wall_axis, *wall_e0, *wall_e1, *wall_length;
+    double *dists_to_goal, *times_required, *dist_left, *min_time;
+    int *wall_orient, *goal_match, *num_obst_coll, *num_agent_coll, *cur_step, *episode, *reset_flag;
+};
+
+// ---------------------------------------------------------------- Philox4x32-10 (oracle/philox.py)
+constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u;
+constexpr uint32_t kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
+constexpr uint32_t kPhiloxTag = 0x464D4152u;
+
+struct PhiloxStream {
+    uint32_t k0, k1, env, episode, idx;
+    __device__ PhiloxStream(uint64_t seed, uint32_t env_, uint32_t episode_, uint32_t first = 0)
+        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), env(env_), episode(episode_), idx(first) {}
+    // one 128-bit block -> two doubles in [0, 1) built like NumPy's random_double
+    __device__ void next(double &u0, double &u1) {
+        uint32_t c0 = idx++, c1 = env, c2 = episode, c3 = kPhiloxTag, a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            if (r) { a += kPhiloxW0; b += kPhiloxW1; }
+            uint64_t p0 = (uint64_t)kPhiloxM0 * c0, p1 = (uint64_t)kPhiloxM1 * c2;
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b;
+            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        }
+        const double s = 1.0 / 9007199254740992.0;
+        u0 = (double)((((uint64_t)c1 << 32) | c0) >> 11) * s;
+        u1 = (double)((((uint64_t)c3 << 32) | c2) >> 11) * s;
+    }
+    __device__ double2 uniform_pair(double lo, double hi) {
+        double a, b; next(a, b);
+        return make_double2(lo + (hi - lo) * a, lo + (hi - lo) * b);
+    }
+    __device__ double uniform(double lo, double hi) { double a, b; next(a, b); return lo + (hi - lo) * a; }
+    __device__ int choice_hv() { double a, b; next(a, b); return a < 0.5 ? 0 : 1; }  // 0 = 'H'
+};
+
+// np.logaddexp(0, z) * k -- reference core.py:391 / :439 (softplus penetration)
+__device__ __forceinline__ double softplus_pen(double z, double k) {
+    double la = (z > 0.0) ? z + log1p(exp(-z)) : log1p(exp(z));
+    return la * k;
+}
+
+__device__ __forceinline__ double dist2(double2 a, double2 b) {
+    double dx = a.x - b.x, dy = a.y - b.y;
+    return sqrt(dx * dx + dy * dy);
+}
+
+// navigation_graph.py:671-683: wall box test with the 1.05 factors
+__device__ __forceinline__ bool wall_box_hit(double2 p, double axis, double e0, double e1, int orient) {
+    const double s = kEntitySize;
+    double pperp = orient == 0 ? p.y : p.x, ppar = orient == 0 ? p.x : p.y;
+    return (1.05 * (axis - s / 2) <= pperp) && (pperp <= 1.05 * (axis + s / 2)) &&
+           (1.05 * (e0 - s / 2) <= ppar) && (ppar <= 1.05 * (e1 + s / 2));
+}
+
+}  // namespace fmarl

@@ -1,0 +1,29 @@
+// Kernel entry points of libfmarl (gfx950).  Launch geometry is chosen in fmarl_capi.hip.
+#pragma once
+#include "fmarl_dev.h"
+
+namespace fmarl {
+
+// fmarl_step.hip
+__global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
+                            int auto_reset);
+__device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv);
+__device__ void fill_static_rows(const Params &p, char *lds, int nenv);
+__device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
+
+// fmarl_reset.hip
+enum ResetMode { kResetAll = 0, kResetMask = 1, kResetAuto = 2, kResetInit = 3 };
+__global__ void reset_place_kernel(Params p, int mode, const uint8_t *mask);
+__global__ void reset_emit_kernel(Params p, FmarlOutputs o);
+__global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal_pos, double *costs,
+                                   int n_envs, int N, int L);
+
+// fmarl_lexifair.hip
+void launch_lexifair_costs(const double *costs, int32_t *perm, int n_envs, int N, hipStream_t stream);
+void launch_lexifair_state(const Params &p, hipStream_t stream);
+
+// fmarl_graph.hip
+__global__ void update_graph_kernel(const float *adj, int32_t *edge_index, float *edge_weight, int32_t *nnz,
+                                    int n_envs, int E, float max_edge_dist);
+
+}  // namespace fmarl

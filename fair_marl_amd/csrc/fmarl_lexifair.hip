@@ -1,0 +1,141 @@
+// Lexicographic-bottleneck ("lexifair") goal assignment on gfx950, one lane group per environment.
+//
+// Restates solve_fair_assignment (reference marl_fair_assign.py:16-55: N rounds of
+// "minimise the largest assigned cost, fix the row that attains it"), which the reference solves
+// with pyomo + Gurobi MILPs.  For distinct costs the result is the unique assignment whose
+// descending-sorted cost vector is lexicographically minimal; ties are broken here by the total
+// order (cost, row * G + col).
+//
+// Algorithm (all state in registers, cross-lane traffic by DPP / ds_bpermute shuffles only):
+//   lane r of a G-lane group owns row r of the N x N cost matrix (N <= G, G in {4, 8, 16, 32, 64}).
+//   Keep a perfect matching of the still-free rows/cols (start: identity).  Repeat: take the
+//   matched edge (r*, c*) with the largest key; drop it and look for an augmenting path from r* to
+//   c* through edges with a strictly smaller key (alternating BFS on 64-bit row masks).  Found ->
+//   the matching's largest key strictly decreased.  Not found -> by Berge's theorem no perfect
+//   matching avoids (r*, c*) below that key, so it is the bottleneck edge: fix it, retire r*, c*.
+#pragma once
+#include "fmarl_dev.h"
+#include "fmarl_kernels.h"
+
+namespace fmarl {
+
+template <int G>
+__device__ __forceinline__ uint64_t group_or(uint64_t v) {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v |= __shfl_xor(v, off, G);
+    return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void lexifair_kernel(const double *costs, const double2 *agent_pos,
+                                                       const double2 *goal_pos, int32_t *perm,
+                                                       const int *flag, int n_envs, int N) {
+    const int lane = threadIdx.x % G;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int env = min(grp, n_envs - 1);          // every lane stays in the shuffles
+    const bool valid = grp < n_envs && (flag == nullptr || flag[env] != 0);
+    const bool is_row = lane < N;
+
+    double c[G];   // row `lane` of the cost matrix (navigation_graph.py:555 cdist when built from positions)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        double v = 0.0;
+        if (is_row && j < N)
+            v = costs ? costs[((size_t)env * N + lane) * N + j]
+                      : dist2(agent_pos[(size_t)env * N + lane], goal_pos[(size_t)env * N + j]);
+        c[j] = v;
+    }
+    int mc = lane, mr = lane;       // col matched to row `lane`; row matched to col `lane`
+    double mycost = 0.0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) if (j == lane) mycost = c[j];
+    const uint64_t full = N >= 64 ? ~0ull : ((1ull << N) - 1);
+    uint64_t R = full, C = full;    // free rows / cols (uniform over the group)
+
+    for (int iter = 0; R != 0 && iter < N * N + N + 8; ++iter) {
+        // 1. matched edge with the largest key (cost, row * G + col) among the free rows
+        const bool arow = (R >> lane) & 1;
+        double kc = arow ? mycost : -__builtin_huge_val();
+        int kidx = arow ? lane * G + mc : -1;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1) {
+            double oc = __shfl_xor(kc, off, G);
+            int oi = __shfl_xor(kidx, off, G);
+            if (oc > kc || (oc == kc && oi > kidx)) { kc = oc; kidx = oi; }
+        }
+        const int rstar = kidx / G, cstar = kidx - rstar * G;
+        // 2. edges of this row with a strictly smaller key, restricted to the free columns
+        uint64_t adj = 0;
+        if (arow) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                bool lt = c[j] < kc || (c[j] == kc && lane * G + j < kidx);
+                if (lt && ((C >> j) & 1)) adj |= 1ull << j;
+            }
+        }
+        // 3. alternating BFS from the freed row r* to the freed column c*
+        uint64_t F = 1ull << rstar, VC = 0;
+        int parent = -1;
+        bool found = false;
+        for (int lvl = 0; lvl < N; ++lvl) {
+            const uint64_t nc = group_or<G>(((F >> lane) & 1) ? adj : 0ull) & ~VC;
+            if (nc == 0) break;
+            const bool newcol = (nc >> lane) & 1;
+            int pr = -1;
+            for (uint64_t Fi = F; Fi != 0; Fi &= Fi - 1) {
+                const int r = __builtin_ctzll(Fi);
+                const uint64_t ar = __shfl(adj, r, G);
+                if (newcol && pr < 0 && ((ar >> lane) & 1)) pr = r;
+            }
+            if (newcol) parent = pr;
+            VC |= nc;
+            if ((nc >> cstar) & 1) { found = true; break; }
+            F = group_or<G>(newcol ? (1ull << mr) : 0ull);
+        }
+        if (found) {   // flip the path: every matched key is now smaller than the old maximum
+            int ccur = cstar;
+            for (int hop = 0; hop < N; ++hop) {
+                const int r = __shfl(parent, ccur, G);
+                const int cprev = __shfl(mc, r, G);
+                if (lane == r) mc = ccur;
+                if (lane == ccur) mr = r;
+                if (r == rstar) break;
+                ccur = cprev;
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) if (j == mc) mycost = c[j];
+        } else {       // (r*, c*) is the bottleneck edge of the remaining problem: fix it
+            R &= ~(1ull << rstar);
+            C &= ~(1ull << cstar);
+        }
+    }
+    if (valid && is_row) perm[(size_t)env * N + lane] = mc;
+}
+
+template <int G>
+static void launch_lexifair_g(const double *costs, const double2 *ap, const double2 *gp, int32_t *perm,
+                              const int *flag, int n_envs, int N, hipStream_t stream) {
+    const int per_block = 256 / G;
+    const int blocks = (n_envs + per_block - 1) / per_block;
+    hipLaunchKernelGGL(lexifair_kernel<G>, dim3(blocks), dim3(256), 0, stream, costs, ap, gp, perm, flag, n_envs, N);
+}
+
+static void launch_lexifair_any(const double *costs, const double2 *ap, const double2 *gp, int32_t *perm,
+                                const int *flag, int n_envs, int N, hipStream_t stream) {
+    if (N <= 4) launch_lexifair_g<4>(costs, ap, gp, perm, flag, n_envs, N, stream);
+    else if (N <= 8) launch_lexifair_g<8>(costs, ap, gp, perm, flag, n_envs, N, stream);
+    else if (N <= 16) launch_lexifair_g<16>(costs, ap, gp, perm, flag, n_envs, N, stream);
+    else if (N <= 32) launch_lexifair_g<32>(costs, ap, gp, perm, flag, n_envs, N, stream);
+    else launch_lexifair_g<64>(costs, ap, gp, perm, flag, n_envs, N, stream);
+}
+
+void launch_lexifair_costs(const double *costs, int32_t *perm, int n_envs, int N, hipStream_t stream) {
+    launch_lexifair_any(costs, nullptr, nullptr, perm, nullptr, n_envs, N, stream);
+}
+
+// reset path: costs = cdist(agent_pos, landmark_pos) of the envs flagged by reset_place_kernel
+void launch_lexifair_state(const Params &p, hipStream_t stream) {
+    launch_lexifair_any(nullptr, p.agent_pos, p.landmark_pos, p.goal_match, p.reset_flag, p.n_envs, p.N, stream);
+}
+
+}  // namespace fmarl

@@ -1,0 +1,156 @@
+// Environment reset on the device (gfx950).
+//
+// Restates reference multiagent/custom_scenarios/navigation_graph.py:212-575 (reset_world +
+// random_scenario) and multiagent/environment.py:882-898 (reset observation):
+//   reset_place_kernel  one lane per env: Philox draws in the reference's draw order, rejection
+//                       sampling of agents / goals, min_time from the PREVIOUS assignment (:545-547)
+//   lexifair            fair goal assignment (fmarl_lexifair.hip; marl_fair_assign.py:16-55)
+//   reset_emit_kernel   obs / node_obs / adj of the freshly reset envs (same emission code as step)
+// The reference draws from NumPy's global MT19937; the device uses a counter-based Philox stream
+// keyed (seed; draw, env, episode) so results do not depend on the number of GPUs.  oracle/philox.py
+// is the bit-exact host twin used by the parity tests.
+#pragma once
+#include "fmarl_dev.h"
+#include "fmarl_kernels.h"
+#include "fmarl_step.hip"
+
+namespace fmarl {
+
+// navigation_graph.py:650-684 is_obstacle_collision(pos, size = 0.05)
+__device__ bool obstacle_hit_global(const Params &p, int env, double2 x) {
+    for (int k = 0; k < p.O; ++k)
+        if (dist2(p.obstacle_pos[(size_t)env * p.O + k], x) < 1.05 * (kEntitySize + kEntitySize)) return true;
+    for (int w = 0; w < p.W; ++w) {
+        size_t g = (size_t)env * p.W + w;
+        if (wall_box_hit(x, p.wall_axis[g], p.wall_e0[g], p.wall_e1[g], p.wall_orient[g])) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, const uint8_t *mask) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.n_envs) return;
+    bool doit = true;
+    if (mode == kResetMask) doit = mask[env] != 0;
+    else if (mode == kResetAuto) doit = p.cur_step[env] >= p.episode_length;   // all agents done
+    p.reset_flag[env] = doit ? 1 : 0;
+    if (!doit) return;
+
+    const int N = p.N, L = p.L;
+    const size_t a0 = (size_t)env * N;
+    int episode = 0;
+    if (mode == kResetInit) {
+        for (int i = 0; i < N; ++i) { p.goal_match[a0 + i] = i; p.min_time[a0 + i] = __builtin_huge_val(); }
+    } else {
+        episode = p.episode[env];
+    }
+    PhiloxStream rng(p.seed, (uint32_t)(p.env_offset + env), (uint32_t)episode);
+    if (mode == kResetInit)   // make_world: navigation_graph.py:183-185
+        p.wall_length[env] = rng.uniform(0.2, 0.8) * p.world_size / 4;
+    const double ws = p.world_size, wlen = p.wall_length[env];
+
+    for (int i = 0; i < N; ++i) {   // :215-225, :239-240
+        p.times_required[a0 + i] = -1.0; p.dists_to_goal[a0 + i] = -1.0; p.dist_left[a0 + i] = -1.0;
+        p.num_obst_coll[a0 + i] = 0; p.num_agent_coll[a0 + i] = 0; p.p_dist[a0 + i] = 0.0;
+    }
+    p.cur_step[env] = 0;
+    for (int k = 0; k < p.O; ++k) {   // :271-275
+        double2 u = rng.uniform_pair(-ws / 2, ws / 2);
+        p.obstacle_pos[(size_t)env * p.O + k] = make_double2(0.8 * u.x, 0.8 * u.y);
+    }
+    const double wall_position = rng.uniform(0.2, 0.9);   // :288, drawn even without walls
+    for (int w = 0; w < p.W; ++w) {   // :294-324
+        size_t g = (size_t)env * p.W + w;
+        p.wall_orient[g] = rng.choice_hv();
+        p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen;
+        p.wall_axis[g] = (w == 0 ? wall_position : -wall_position) * ws / 2;
+    }
+    const double thr = 1.05 * (kEntitySize + kEntitySize);
+    for (int k = 0, tries = 0; k < N;) {   // :389-457
+        double2 x = rng.uniform_pair(-ws / 2, ws / 2);
+        ++tries;
+        bool bad = obstacle_hit_global(p, env, x);
+        for (int j = 0; j < k && !bad; ++j) bad = dist2(p.agent_pos[a0 + j], x) < thr;   // :689-698
+        if (!bad || tries >= kMaxTries) {
+            p.agent_pos[a0 + k] = x; p.agent_vel[a0 + k] = make_double2(0.0, 0.0);
+            ++k; tries = 0;
+        }
+    }
+    const size_t l0 = (size_t)env * L;
+    for (int k = 0, tries = 0; k < L;) {   // :472-535
+        double2 u = rng.uniform_pair(-ws / 2, ws / 2);
+        double2 x = make_double2(0.8 * u.x, 0.8 * u.y);
+        ++tries;
+        bool bad = obstacle_hit_global(p, env, x);
+        for (int j = 0; j < k && !bad; ++j) bad = dist2(p.landmark_pos[l0 + j], x) < thr;   // :707-716
+        if (!bad || tries >= kMaxTries) { p.landmark_pos[l0 + k] = x; ++k; tries = 0; }
+    }
+    if (p.has_max_speed)   // :545-547, :719-728 -- previous episode's goal_match_index
+        for (int i = 0; i < N; ++i)
+            p.min_time[a0 + i] = dist2(p.agent_pos[a0 + i], p.landmark_pos[l0 + p.goal_match[a0 + i]]) / p.max_speed;
+    p.episode[env] = episode + 1;
+}
+
+// obs / node_obs / adj of freshly reset envs (environment.py:882-898).  Same workgroup shape as the
+// step kernel; envs whose reset_flag is 0 are skipped.
+__global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOutputs o) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x;
+    const int env0 = blockIdx.x * p.epb;
+    const int nenv = min(p.epb, p.n_envs - env0);
+    const int el = tid / p.N, i = tid - el * p.N;
+    const bool active = el < nenv;
+    const int env = env0 + el;
+    const size_t g = (size_t)env * p.N + i;
+    char *base = lds + (size_t)el * p.lds_env_bytes;
+    double2 *s_pos = (double2 *)(base + p.lds_pos);
+    double *s_stat = (double *)(base + p.lds_stat);
+    double2 x = make_double2(0, 0), v = make_double2(0, 0);
+    double Dg = 0;
+    bool flagged = false;
+    if (active) {
+        flagged = p.reset_flag[env] != 0;
+        x = p.agent_pos[g]; v = p.agent_vel[g]; Dg = p.dists_to_goal[g];
+        s_pos[i] = x;
+        s_stat[i] = p.p_dist[g];
+        s_stat[p.N + i] = Dg;
+        if (i == 0) *(int *)(base + p.lds_flag) = flagged ? 0 : 1;   // 1 = skip
+    }
+    load_statics(p, lds, env0, nenv);
+    __syncthreads();
+    if (active && flagged) {
+        const double2 goal = s_pos[p.N + p.goal_match[g]];
+        double m, sd;   // navigation_graph.py:849-854
+        if (Dg == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
+        else mixed_stats(s_stat + p.N, s_stat + p.N, p.N, p.N, m, sd);
+        const double fairness = m / (sd + 0.0001);
+        if (o.obs) {
+            float *ob = o.obs + g * p.D;
+            ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;
+            ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)fairness;
+        }
+        float *A = (float *)(base + p.lds_a) + i * p.F;
+        float *B = (float *)(base + p.lds_b) + i * kBWidth;
+        const float fx = (float)x.x, fy = (float)x.y, fvx = (float)v.x, fvy = (float)v.y;
+        A[0] = fvx; A[1] = fvy; A[2] = fx; A[3] = fy; A[4] = (float)goal.x; A[5] = (float)goal.y;
+        A[6] = fx; A[7] = fy; A[8] = fx; A[9] = fy; A[10] = 0.f;
+        B[0] = fvx; B[1] = fvy; B[2] = fx; B[3] = fy; B[4] = 0.f;
+    }
+    fill_static_rows(p, lds, nenv);
+    __syncthreads();
+    emit_graph(p, o, lds, env0, nenv);
+}
+
+// navigation_graph.py:555 dist.cdist(agent_pos, goal_pos)
+__global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal_pos, double *costs,
+                                   int n_envs, int N, int L) {
+    const size_t total = (size_t)n_envs * N * L;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+        size_t env = q / ((size_t)N * L);
+        int r = (int)(q - env * N * L);
+        int i = r / L, j = r - i * L;
+        costs[q] = dist2(agent_pos[env * N + i], goal_pos[env * L + j]);
+    }
+}
+
+}  // namespace fmarl

@@ -1,0 +1,277 @@
+// libfmarl.so -- C-ABI (include/fmarl.h) over the gfx950 kernels.  Single translation unit.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "fmarl_dev.h"
+#include "fmarl_kernels.h"
+#include "fmarl_step.hip"
+#include "fmarl_reset.hip"
+#include "fmarl_lexifair.hip"
+#include "fmarl_graph.hip"
+
+using namespace fmarl;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *a = "") {
+    snprintf(g_err, sizeof g_err, fmt, a);
+    return code;
+}
+#define HIP_OK(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return fail(FMARL_EHIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+struct Layout {
+    size_t off[FMARL_NUM_FIELDS], count[FMARL_NUM_FIELDS];
+    int dtype[FMARL_NUM_FIELDS];
+    size_t total;
+};
+
+bool config_ok(const FmarlConfig *c, const char **why) {
+    *why = "";
+    if (!c) { *why = "null config"; return false; }
+    if (c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH) { *why = "unsupported scenario"; return false; }
+    if (c->n_envs < 1) { *why = "n_envs < 1"; return false; }
+    if (c->num_agents < 1 || c->num_agents > 64) { *why = "num_agents must be in 1..64"; return false; }
+    if (c->num_landmarks != c->num_agents) { *why = "navigation_graph needs num_landmarks == num_agents"; return false; }
+    if (c->num_obstacles < 0 || c->num_obstacles > 4096) { *why = "bad num_obstacles"; return false; }
+    if (c->num_walls < 0 || c->num_walls > 2) { *why = "num_walls must be 0..2"; return false; }
+    if (c->episode_length < 1) { *why = "episode_length < 1"; return false; }
+    return true;
+}
+
+void make_layout(const FmarlConfig *c, Layout *l) {
+    const size_t n = c->n_envs, N = c->num_agents, L = c->num_landmarks, O = c->num_obstacles, W = c->num_walls;
+    auto set = [&](int f, size_t count, int dt) { l->count[f] = count; l->dtype[f] = dt; };
+    set(FMARL_F_AGENT_POS, n * N * 2, FMARL_DTYPE_F64);   set(FMARL_F_AGENT_VEL, n * N * 2, FMARL_DTYPE_F64);
+    set(FMARL_F_P_DIST, n * N, FMARL_DTYPE_F64);          set(FMARL_F_LANDMARK_POS, n * L * 2, FMARL_DTYPE_F64);
+    set(FMARL_F_OBSTACLE_POS, n * O * 2, FMARL_DTYPE_F64); set(FMARL_F_WALL_AXIS, n * W, FMARL_DTYPE_F64);
+    set(FMARL_F_WALL_E0, n * W, FMARL_DTYPE_F64);         set(FMARL_F_WALL_E1, n * W, FMARL_DTYPE_F64);
+    set(FMARL_F_WALL_ORIENT, n * W, FMARL_DTYPE_I32);     set(FMARL_F_WALL_LENGTH, n, FMARL_DTYPE_F64);
+    set(FMARL_F_GOAL_MATCH, n * N, FMARL_DTYPE_I32);      set(FMARL_F_DISTS_TO_GOAL, n * N, FMARL_DTYPE_F64);
+    set(FMARL_F_TIMES_REQUIRED, n * N, FMARL_DTYPE_F64);  set(FMARL_F_DIST_LEFT, n * N, FMARL_DTYPE_F64);
+    set(FMARL_F_NUM_OBST_COLL, n * N, FMARL_DTYPE_I32);   set(FMARL_F_NUM_AGENT_COLL, n * N, FMARL_DTYPE_I32);
+    set(FMARL_F_MIN_TIME, n * N, FMARL_DTYPE_F64);        set(FMARL_F_CUR_STEP, n, FMARL_DTYPE_I32);
+    set(FMARL_F_EPISODE, n, FMARL_DTYPE_I32);
+    const bool form = c->scenario == FMARL_SCENARIO_FORMATION;
+    set(FMARL_F_SLOT_POS, form ? n * N * 2 : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_SLOT_OCC, form ? n * N : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_SLOT_DELTA, form ? n * N : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_FORMATION_DONE, form ? n * N : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_RESET_FLAG, n, FMARL_DTYPE_I32);
+    size_t off = 0;
+    for (int f = 0; f < FMARL_NUM_FIELDS; ++f) {
+        l->off[f] = off;
+        size_t bytes = l->count[f] * (l->dtype[f] == FMARL_DTYPE_F64 ? 8 : 4);
+        off += (bytes + 255) / 256 * 256;
+    }
+    l->total = off;
+}
+
+struct Handle {
+    FmarlConfig cfg;
+    Layout layout;
+    Params base;        // everything but the state pointers
+    size_t lds_bytes;
+    int grid;
+    bool lockstep;      // all envs share one step counter, known on the host
+    int host_step;
+};
+
+int align16(int x) { return (x + 15) / 16 * 16; }
+
+Params bind(const Handle *h, void *state) {
+    Params p = h->base;
+    char *s = (char *)state;
+    const size_t *o = h->layout.off;
+    p.agent_pos = (double2 *)(s + o[FMARL_F_AGENT_POS]);       p.agent_vel = (double2 *)(s + o[FMARL_F_AGENT_VEL]);
+    p.landmark_pos = (double2 *)(s + o[FMARL_F_LANDMARK_POS]); p.obstacle_pos = (double2 *)(s + o[FMARL_F_OBSTACLE_POS]);
+    p.p_dist = (double *)(s + o[FMARL_F_P_DIST]);              p.wall_axis = (double *)(s + o[FMARL_F_WALL_AXIS]);
+    p.wall_e0 = (double *)(s + o[FMARL_F_WALL_E0]);            p.wall_e1 = (double *)(s + o[FMARL_F_WALL_E1]);
+    p.wall_length = (double *)(s + o[FMARL_F_WALL_LENGTH]);    p.dists_to_goal = (double *)(s + o[FMARL_F_DISTS_TO_GOAL]);
+    p.times_required = (double *)(s + o[FMARL_F_TIMES_REQUIRED]); p.dist_left = (double *)(s + o[FMARL_F_DIST_LEFT]);
+    p.min_time = (double *)(s + o[FMARL_F_MIN_TIME]);          p.wall_orient = (int *)(s + o[FMARL_F_WALL_ORIENT]);
+    p.goal_match = (int *)(s + o[FMARL_F_GOAL_MATCH]);         p.num_obst_coll = (int *)(s + o[FMARL_F_NUM_OBST_COLL]);
+    p.num_agent_coll = (int *)(s + o[FMARL_F_NUM_AGENT_COLL]); p.cur_step = (int *)(s + o[FMARL_F_CUR_STEP]);
+    p.episode = (int *)(s + o[FMARL_F_EPISODE]);               p.reset_flag = (int *)(s + o[FMARL_F_RESET_FLAG]);
+    return p;
+}
+
+int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const FmarlOutputs *outs, hipStream_t st) {
+    Params p = bind(h, state);
+    const int blocks = (p.n_envs + 63) / 64;
+    hipLaunchKernelGGL(reset_place_kernel, dim3(blocks), dim3(64), 0, st, p, mode, mask);
+    launch_lexifair_state(p, st);
+    if (outs && (outs->obs || outs->node_obs || outs->adj))
+        hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *fmarl_last_error(void) { return g_err; }
+
+size_t fmarl_state_bytes(const FmarlConfig *cfg) {
+    const char *why;
+    if (!config_ok(cfg, &why)) { fail(FMARL_EINVAL, "fmarl_state_bytes: %s", why); return 0; }
+    Layout l;
+    make_layout(cfg, &l);
+    return l.total;
+}
+
+int fmarl_state_field(const FmarlConfig *cfg, int field, size_t *offset_bytes, size_t *count, int *dtype) {
+    const char *why;
+    if (!config_ok(cfg, &why)) return fail(FMARL_EINVAL, "fmarl_state_field: %s", why);
+    if (field < 0 || field >= FMARL_NUM_FIELDS) return fail(FMARL_EINVAL, "fmarl_state_field: bad field id");
+    Layout l;
+    make_layout(cfg, &l);
+    if (offset_bytes) *offset_bytes = l.off[field];
+    if (count) *count = l.count[field];
+    if (dtype) *dtype = l.dtype[field];
+    return FMARL_OK;
+}
+
+int fmarl_create(const FmarlConfig *cfg, void **handle) {
+    const char *why;
+    if (!handle) return fail(FMARL_EINVAL, "fmarl_create: null handle pointer");
+    if (!config_ok(cfg, &why)) return fail(FMARL_EINVAL, "fmarl_create: %s", why);
+    Handle *h = new (std::nothrow) Handle();
+    if (!h) return fail(FMARL_EINVAL, "fmarl_create: out of host memory");
+    h->cfg = *cfg;
+    make_layout(cfg, &h->layout);
+    Params &p = h->base;
+    memset(&p, 0, sizeof p);
+    p.n_envs = cfg->n_envs; p.N = cfg->num_agents; p.L = cfg->num_landmarks; p.O = cfg->num_obstacles;
+    p.W = cfg->num_walls; p.E = p.N + p.L + p.O + p.W; p.D = 7; p.F = 11;
+    p.episode_length = cfg->episode_length; p.has_max_speed = cfg->has_max_speed; p.env_offset = cfg->env_offset;
+    p.scenario = cfg->scenario;
+    p.world_size = cfg->world_size; p.max_speed = cfg->max_speed; p.collision_rew = cfg->collision_rew;
+    p.goal_rew = cfg->goal_rew; p.thr = cfg->min_dist_thresh; p.fair_rew = cfg->fair_rew; p.zeroshift = cfg->zeroshift;
+    p.seed = cfg->seed;
+    // node feature column f -> ego column: [vx vy | x y | x y | x y | x y | 0]  (navigation_graph.py:1118-1124)
+    const int sel[11] = {0, 1, 2, 3, 2, 3, 2, 3, 2, 3, 4};
+    for (int f = 0; f < 11; ++f) p.bsel |= (uint64_t)sel[f] << (4 * f);
+    // per-env LDS layout
+    int off = 0;
+    p.lds_pos = off;  off = align16(off + p.E * 16);
+    p.lds_stat = off; off = align16(off + 5 * p.N * 8);
+    p.lds_a = off;    off = align16(off + p.E * p.F * 4);
+    p.lds_b = off;    off = align16(off + p.N * kBWidth * 4);
+    p.lds_wall = off; off = align16(off + p.W * 4 * 8);
+    p.lds_flag = off; off = align16(off + 4);
+    p.lds_env_bytes = off;
+    int epb = kThreads / p.N;
+    const int budget = 48 * 1024;
+    if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
+    if (epb < 1) epb = 1;
+    if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
+    p.epb = epb;
+    h->lds_bytes = (size_t)epb * p.lds_env_bytes;
+    h->grid = (p.n_envs + epb - 1) / epb;
+    const uint64_t NEF = (uint64_t)p.N * p.E * p.F, maxq = (uint64_t)epb * NEF;
+    if (maxq >= (1ull << 24) || maxq * NEF >= (1ull << 40)) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large"); }
+    p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
+    p.dLO.set(p.L + p.O > 0 ? p.L + p.O : 1);
+    if (h->lds_bytes > 64 * 1024) {
+        hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
+    }
+    h->lockstep = false; h->host_step = 0;
+    *handle = h;
+    return FMARL_OK;
+}
+
+int fmarl_destroy(void *handle) {
+    delete (Handle *)handle;
+    return FMARL_OK;
+}
+
+int fmarl_init_state(void *handle, void *state, void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h || !state) return fail(FMARL_EINVAL, "fmarl_init_state: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(state, 0, h->layout.total, st));
+    int rc = launch_reset(h, state, kResetInit, nullptr, nullptr, st);
+    h->lockstep = true; h->host_step = 0;
+    return rc;
+}
+
+int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlOutputs *outs, void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h || !state) return fail(FMARL_EINVAL, "fmarl_reset: null argument");
+    int rc = launch_reset(h, state, env_mask ? kResetMask : kResetAll, env_mask, outs, (hipStream_t)stream);
+    if (env_mask) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
+    return rc;
+}
+
+int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
+               const FmarlOutputs *outs, int auto_reset, void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h || !state || !outs) return fail(FMARL_EINVAL, "fmarl_step: null argument");
+    if ((action_idx == nullptr) == (action_vec == nullptr))
+        return fail(FMARL_EINVAL, "fmarl_step: pass exactly one of action_idx / action_vec");
+    hipStream_t st = (hipStream_t)stream;
+    Params p = bind(h, state);
+    hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
+                       auto_reset ? 1 : 0);
+    HIP_OK(hipGetLastError());
+    if (h->lockstep) ++h->host_step;
+    if (auto_reset) {
+        const bool may_reset = !h->lockstep || h->host_step >= h->cfg.episode_length;
+        if (may_reset) {
+            int rc = launch_reset(h, state, kResetAuto, nullptr, outs, st);
+            if (rc) return rc;
+            if (h->lockstep) h->host_step = 0;
+        }
+    }
+    return FMARL_OK;
+}
+
+int fmarl_state_changed(void *handle) {
+    Handle *h = (Handle *)handle;
+    if (!h) return fail(FMARL_EINVAL, "fmarl_state_changed: null handle");
+    h->lockstep = false;
+    return FMARL_OK;
+}
+
+int fmarl_cost_matrix(const double *agent_pos, const double *goal_pos, double *costs, int n_envs, int num_agents,
+                      int num_goals, void *stream) {
+    if (!agent_pos || !goal_pos || !costs || n_envs < 1 || num_agents < 1 || num_goals < 1)
+        return fail(FMARL_EINVAL, "fmarl_cost_matrix: bad argument");
+    const size_t total = (size_t)n_envs * num_agents * num_goals;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cost_matrix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double2 *)agent_pos,
+                       (const double2 *)goal_pos, costs, n_envs, num_agents, num_goals);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_lexifair(const double *costs, int32_t *perm, int n_envs, int num_agents, void *stream) {
+    if (!costs || !perm || n_envs < 1 || num_agents < 1 || num_agents > 64)
+        return fail(FMARL_EINVAL, "fmarl_lexifair: bad argument (1 <= N <= 64)");
+    launch_lexifair_costs(costs, perm, n_envs, num_agents, (hipStream_t)stream);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_update_graph(const float *adj, int32_t *edge_index, float *edge_weight, int32_t *nnz, int n_envs,
+                       int num_entities, double max_edge_dist, void *stream) {
+    if (!adj || !edge_index || !edge_weight || !nnz || n_envs < 1 || num_entities < 1)
+        return fail(FMARL_EINVAL, "fmarl_update_graph: bad argument");
+    const int blocks = (n_envs + 3) / 4;   // 4 waves per workgroup, one env per wave
+    hipLaunchKernelGGL(update_graph_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, adj, edge_index,
+                       edge_weight, nnz, n_envs, num_entities, (float)max_edge_dist);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+}  // extern "C"

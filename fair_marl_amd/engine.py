@@ -1,0 +1,176 @@
+"""RolloutEngine: device-resident batch of environments driven through the C-ABI of libfmarl.
+
+One engine = one GPU = ``n_envs`` independent worlds (the reference runs one Python ``World``
+per OS process: onpolicy/envs/env_wrappers.py:951-1026).  All buffers are PyTorch-ROCm tensors
+owned here and handed to the library as raw pointers; PyTorch is only the allocator / stream
+provider.  Outputs stay on the device (float32); ``adj`` is stored once per env and exposed per
+agent as a stride-0 ``expand`` (the reference returns N identical copies,
+multiagent/custom_scenarios/navigation_graph.py:1033).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import EnvConfig
+
+_TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32}
+
+
+class RolloutEngine:
+    def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True):
+        if not isinstance(cfg, EnvConfig):
+            cfg = EnvConfig.from_args(cfg)
+        cfg.validate()
+        self.cfg, self.n_envs = cfg, int(n_envs)
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('fair_marl_amd needs an AMD GPU (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback for the rollout path')
+        self.device = torch.device(device)
+        self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.fmarl_create(C.byref(self.c), C.byref(self.handle)), 'fmarl_create')
+        nbytes = self.lib.fmarl_state_bytes(C.byref(self.c))
+        n, N, E = self.n_envs, cfg.N, cfg.E
+        D, F = cfg.obs_dim, cfg.node_feat
+        with torch.cuda.device(self.device):
+            self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self.obs = torch.zeros(n, N, D, dtype=torch.float32, device=self.device)
+            self.node_obs = torch.zeros(n, N, E, F, dtype=torch.float32, device=self.device)
+            self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device)
+            self.reward = torch.zeros(n, N, dtype=torch.float32, device=self.device)
+            self.done = torch.zeros(n, N, dtype=torch.uint8, device=self.device)
+            self.info = torch.zeros(n, N, _lib.INFO_WIDTH, dtype=torch.float32, device=self.device) if emit_info else None
+            self.agent_id = torch.arange(N, device=self.device).view(1, N, 1).expand(n, N, 1)
+        self.outs = _lib.FmarlOutputs(self.obs.data_ptr(), self.node_obs.data_ptr(), self.adj_env.data_ptr(),
+                                      self.reward.data_ptr(), self.done.data_ptr(),
+                                      self.info.data_ptr() if emit_info else None)
+        self._fields = {}
+        shapes = self._field_shapes()
+        for fid, name in enumerate(_lib.FIELD_NAMES):
+            off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int()
+            _lib.check(self.lib.fmarl_state_field(C.byref(self.c), fid, C.byref(off), C.byref(cnt), C.byref(dt)),
+                       'fmarl_state_field')
+            if cnt.value == 0:
+                if 0 in shapes[name]:   # empty field of this config (e.g. no walls), not a foreign scenario's field
+                    self._fields[name] = torch.zeros(shapes[name], dtype=_TORCH_DT[dt.value], device=self.device)
+                continue
+            esz = 8 if dt.value == _lib.DTYPE_F64 else 4
+            view = self.state[off.value: off.value + cnt.value * esz].view(_TORCH_DT[dt.value])
+            self._fields[name] = view.view(shapes[name])
+        _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
+
+    def _field_shapes(self):
+        n, c = self.n_envs, self.cfg
+        N, L, O, W = c.num_agents, c.num_landmarks, c.num_obstacles, c.num_walls
+        return dict(agent_pos=(n, N, 2), agent_vel=(n, N, 2), p_dist=(n, N), landmark_pos=(n, L, 2),
+                    obstacle_pos=(n, O, 2), wall_axis=(n, W), wall_e0=(n, W), wall_e1=(n, W), wall_orient=(n, W),
+                    wall_length=(n,), goal_match=(n, N), dists_to_goal=(n, N), times_required=(n, N),
+                    dist_left=(n, N), num_obst_coll=(n, N), num_agent_coll=(n, N), min_time=(n, N),
+                    cur_step=(n,), episode=(n,), slot_pos=(n, N, 2), slot_occ=(n, N), slot_delta=(n, N),
+                    formation_done=(n, N), reset_flag=(n,))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ state access (parity harness)
+    def field(self, name):
+        """Device tensor view of one state field (see include/fmarl.h FMARL_F_*)."""
+        return self._fields[name]
+
+    def get_state(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self._fields.items() if k != 'reset_flag'}
+
+    def set_state(self, state):
+        for k, v in state.items():
+            if k in self._fields:
+                t = self._fields[k]
+                t.copy_(torch.as_tensor(np.asarray(v)).to(t.dtype).reshape(t.shape))
+        _lib.check(self.lib.fmarl_state_changed(self.handle), 'fmarl_state_changed')
+
+    # ------------------------------------------------------------------ hot path
+    @property
+    def adj(self):
+        """(n, N, E, E) stride-0 view of the per-env distance matrix."""
+        n, E = self.n_envs, self.cfg.E
+        return self.adj_env.view(n, 1, E, E).expand(n, self.cfg.N, E, E)
+
+    def reset(self, env_mask=None):
+        """MultiAgentGraphEnv.reset for all (or the masked) envs -> (obs, agent_id, node_obs, adj)."""
+        mask_ptr = None
+        if env_mask is not None:
+            env_mask = torch.as_tensor(env_mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            mask_ptr = env_mask.data_ptr()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_reset(self.handle, self.state.data_ptr(), mask_ptr, C.byref(self.outs),
+                                            self._stream()), 'fmarl_reset')
+        return self.obs, self.agent_id, self.node_obs, self.adj
+
+    def step(self, actions, auto_reset=True):
+        """One env step for every env.  ``actions``: int tensor (n, N) of indices 0..4 or float tensor
+        (n, N, 5) in the reference's one-hot / continuous form.  Returns device tensors
+        (obs, agent_id, node_obs, adj, reward, done, info)."""
+        a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
+        n, N = self.n_envs, self.cfg.N
+        idx_ptr = vec_ptr = None
+        if a.dim() == 2:
+            if tuple(a.shape) != (n, N):
+                raise ValueError('action index tensor must have shape (%d, %d), got %s' % (n, N, tuple(a.shape)))
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+            idx_ptr = a.data_ptr()
+        else:
+            if tuple(a.shape) != (n, N, 5):
+                raise ValueError('action tensor must have shape (%d, %d, 5), got %s' % (n, N, tuple(a.shape)))
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+            vec_ptr = a.data_ptr()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_step(self.handle, self.state.data_ptr(), idx_ptr, vec_ptr,
+                                           C.byref(self.outs), 1 if auto_reset else 0, self._stream()), 'fmarl_step')
+        self._last_actions = a  # keep alive until the stream has consumed it
+        return self.obs, self.agent_id, self.node_obs, self.adj, self.reward, self.done, self.info
+
+    # ------------------------------------------------------------------ exported pieces
+    def cost_matrix(self, agent_pos, goal_pos):
+        """cdist(agent_pos, goal_pos): f64 (n, N, 2), (n, L, 2) -> (n, N, L) on the device."""
+        ap = torch.as_tensor(agent_pos).to(device=self.device, dtype=torch.float64).contiguous()
+        gp = torch.as_tensor(goal_pos).to(device=self.device, dtype=torch.float64).contiguous()
+        n, N, L = ap.shape[0], ap.shape[1], gp.shape[1]
+        out = torch.empty(n, N, L, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_cost_matrix(ap.data_ptr(), gp.data_ptr(), out.data_ptr(), n, N, L,
+                                                  self._stream()), 'fmarl_cost_matrix')
+        return out
+
+    def lexifair(self, costs):
+        """solve_fair_assignment for a batch of cost matrices f64 (n, N, N) -> perm int32 (n, N)."""
+        c = torch.as_tensor(costs).to(device=self.device, dtype=torch.float64).contiguous()
+        n, N = c.shape[0], c.shape[1]
+        perm = torch.empty(n, N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_lexifair(c.data_ptr(), perm.data_ptr(), n, N, self._stream()), 'fmarl_lexifair')
+        return perm
+
+    def update_graph(self, adj_env=None):
+        """Scenario.update_graph: (edge_index (n, 2, E*E) padded with -1, edge_weight (n, E*E), nnz (n))."""
+        adj = self.adj_env if adj_env is None else torch.as_tensor(adj_env).to(self.device, torch.float32).contiguous()
+        n, E = adj.shape[0], adj.shape[1]
+        ei = torch.empty(n, 2, E * E, dtype=torch.int32, device=self.device)
+        ew = torch.empty(n, E * E, dtype=torch.float32, device=self.device)
+        nnz = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_update_graph(adj.data_ptr(), ei.data_ptr(), ew.data_ptr(), nnz.data_ptr(), n, E,
+                                                   float(self.cfg.max_edge_dist), self._stream()), 'fmarl_update_graph')
+        return ei, ew, nnz
+
+    def close(self):
+        if getattr(self, 'handle', None) is not None and self.handle.value:
+            self.lib.fmarl_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,179 @@
+/*
+ * fmarl.h -- C-ABI of the MI355X-native Fair-MARL rollout hot path (libfmarl.so).
+ *
+ * The reference has no FFI: its hot path sits behind a Python vectorised-env API
+ * (onpolicy/envs/env_wrappers.py:850-1026 GraphSubprocVecEnv / GraphDummyVecEnv over
+ * multiagent/environment.py:816-898 MultiAgentGraphEnv.step/reset).  This header is the
+ * boundary a maintainer binds instead (ctypes stub: INTEGRATION.md); every entry point
+ * cites the reference code it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory owned by the
+ *     caller (PyTorch-ROCm tensors passed as data_ptr()); the library allocates nothing
+ *     persistent on the device;
+ *   - every call that launches work takes the hipStream_t to launch on (as void*);
+ *     calls are asynchronous and never synchronise the device (graph-capture safe);
+ *   - return value 0 = ok, otherwise an FMARL_E* code; fmarl_last_error() gives the text;
+ *   - one host thread per handle; handles on different devices are independent.
+ */
+#ifndef FMARL_H
+#define FMARL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMARL_OK 0
+#define FMARL_EINVAL 1   /* bad argument / unsupported shape */
+#define FMARL_EHIP 2     /* a HIP call failed */
+
+#define FMARL_SCENARIO_NAVIGATION_GRAPH 0   /* multiagent/custom_scenarios/navigation_graph.py */
+#define FMARL_SCENARIO_FORMATION 1          /* multiagent/custom_scenarios/fair_graph_formation.py */
+
+/* Scenario arguments: multiagent/custom_scenarios/navigation_graph.py:94-129,208
+ * (defaults onpolicy/config.py:176-252, onpolicy/scripts/train_mpe.py:71-106). */
+typedef struct FmarlConfig {
+    int32_t scenario;        /* FMARL_SCENARIO_* */
+    int32_t n_envs;          /* environments in this handle (n_rollout_threads of this shard) */
+    int32_t num_agents;      /* N */
+    int32_t num_landmarks;   /* L (navigation_graph needs L == N for the assignment) */
+    int32_t num_obstacles;   /* O */
+    int32_t num_walls;       /* W (<= 2: navigation_graph.py:289 has two wall axes) */
+    int32_t episode_length;  /* done when current_step >= episode_length (environment.py:237-247) */
+    int32_t has_max_speed;   /* 0 = max_speed None */
+    int32_t env_offset;      /* global index of env 0 (RNG streams independent of the sharding) */
+    int32_t reserved0;
+    double world_size;
+    double max_speed;
+    double collision_rew;
+    double goal_rew;
+    double min_dist_thresh;
+    double fair_rew;
+    double zeroshift;
+    double max_edge_dist;
+    uint64_t seed;           /* Philox key; env e, episode k draw from counter (i, env_offset+e, k, TAG) */
+} FmarlConfig;
+
+/* Output buffers of one step / reset, all caller-owned device memory, float32 unless noted.
+ * Shapes follow onpolicy/envs/env_wrappers.py:988-1002 with two differences that the Python
+ * layer undoes in its NumPy-compat mode: adj is stored once per env (the reference returns
+ * the same E x E matrix N times, navigation_graph.py:1033) and infos are a dense record
+ * array instead of per-agent dicts (navigation_graph.py:625-647).  Any pointer may be NULL
+ * to skip that output. */
+typedef struct FmarlOutputs {
+    float *obs;          /* (n, N, D)        D = 7 navigation_graph / 6 formation            */
+    float *node_obs;     /* (n, N, E, F)     F = 11 / 12, E = N + L + O + W                   */
+    float *adj;          /* (n, E, E)        cached_dist_mag, multiagent/core.py:204-228      */
+    float *reward;       /* (n, N)                                                            */
+    uint8_t *done;       /* (n, N)           environment.py:237-247                           */
+    float *info;         /* (n, N, FMARL_INFO_WIDTH) in FMARL_INFO_* order                    */
+} FmarlOutputs;
+
+#define FMARL_INFO_WIDTH 14
+/* order of the info record (keys of navigation_graph.py:625-647 + environment.py:861) */
+enum {
+    FMARL_INFO_DIST_TO_GOAL = 0, FMARL_INFO_TIME_REQ_TO_GOAL, FMARL_INFO_NUM_AGENT_COLLISIONS,
+    FMARL_INFO_NUM_OBST_COLLISIONS, FMARL_INFO_DISTANCE_MEAN, FMARL_INFO_DISTANCE_VARIANCE,
+    FMARL_INFO_MEAN_BY_VARIANCE, FMARL_INFO_DISTS_TRAVELED, FMARL_INFO_TIME_TAKEN,
+    FMARL_INFO_TIME_MEAN, FMARL_INFO_TIME_STDDEV, FMARL_INFO_TIME_MEAN_BY_STDDEV,
+    FMARL_INFO_MIN_TIME_TO_GOAL, FMARL_INFO_INDIVIDUAL_REWARD
+};
+
+/* World state: ONE caller-owned device buffer of fmarl_state_bytes() bytes holding the fields
+ * below back to back (each 256-byte aligned, row-major, env-major), i.e. the SoA restatement of
+ * multiagent/core.py:12-19,60-128 EntityState/Entity/Agent/Wall objects and the per-world
+ * vectors of navigation_graph.py:212-225.  float64 where the reference is float64. */
+enum {
+    FMARL_F_AGENT_POS = 0,     /* f64 (n, N, 2)  agent.state.p_pos                         */
+    FMARL_F_AGENT_VEL,         /* f64 (n, N, 2)  agent.state.p_vel                         */
+    FMARL_F_P_DIST,            /* f64 (n, N)     agent.state.p_dist                        */
+    FMARL_F_LANDMARK_POS,      /* f64 (n, L, 2)                                            */
+    FMARL_F_OBSTACLE_POS,      /* f64 (n, O, 2)                                            */
+    FMARL_F_WALL_AXIS,         /* f64 (n, W)     wall.axis_pos                             */
+    FMARL_F_WALL_E0,           /* f64 (n, W)     wall.endpoints[0]                         */
+    FMARL_F_WALL_E1,           /* f64 (n, W)     wall.endpoints[1]                         */
+    FMARL_F_WALL_ORIENT,       /* i32 (n, W)     0 = 'H', 1 = 'V'                          */
+    FMARL_F_WALL_LENGTH,       /* f64 (n)        scenario.wall_length (drawn in make_world) */
+    FMARL_F_GOAL_MATCH,        /* i32 (n, N)     scenario.goal_match_index                 */
+    FMARL_F_DISTS_TO_GOAL,     /* f64 (n, N)     world.dists_to_goal                       */
+    FMARL_F_TIMES_REQUIRED,    /* f64 (n, N)     world.times_required                      */
+    FMARL_F_DIST_LEFT,         /* f64 (n, N)     world.dist_left_to_goal                   */
+    FMARL_F_NUM_OBST_COLL,     /* i32 (n, N)     world.num_obstacle_collisions             */
+    FMARL_F_NUM_AGENT_COLL,    /* i32 (n, N)     world.num_agent_collisions                */
+    FMARL_F_MIN_TIME,          /* f64 (n, N)     agent.goal_min_time                       */
+    FMARL_F_CUR_STEP,          /* i32 (n)        env.current_step == world.current_time_step */
+    FMARL_F_EPISODE,           /* i32 (n)        resets drawn so far (Philox counter word)  */
+    FMARL_F_SLOT_POS,          /* f64 (n, N, 2)  formation: scenario.expected_poses         */
+    FMARL_F_SLOT_OCC,          /* f64 (n, N)     formation: scenario.expected_poses_occupied */
+    FMARL_F_SLOT_DELTA,        /* f64 (n, N)     formation: scenario.delta_dists            */
+    FMARL_F_FORMATION_DONE,    /* f64 (n, N)     formation: world.formation_complete        */
+    FMARL_F_RESET_FLAG,        /* i32 (n)        internal: envs picked by the last reset launch */
+    FMARL_NUM_FIELDS
+};
+#define FMARL_DTYPE_F64 0
+#define FMARL_DTYPE_I32 1
+
+/* --- lifetime ---------------------------------------------------------------------------- */
+
+/* Replaces GraphMPEEnv(args) x n_envs (multiagent/MPE_env.py:55-77): validates the config and
+ * builds the host-side handle (launch geometry, constants).  No device memory is allocated. */
+int fmarl_create(const FmarlConfig *cfg, void **handle);
+int fmarl_destroy(void *handle);
+const char *fmarl_last_error(void);
+
+/* Size and layout of the state buffer for cfg (0 / FMARL_EINVAL on a bad config). */
+size_t fmarl_state_bytes(const FmarlConfig *cfg);
+int fmarl_state_field(const FmarlConfig *cfg, int field, size_t *offset_bytes,
+                      size_t *count, int *dtype);
+
+/* --- the hot path ------------------------------------------------------------------------ */
+
+/* make_world for every env (navigation_graph.py:48-210): default vectors, wall_length draw and
+ * the hidden first reset_world (:209).  Must be called once on a fresh state buffer. */
+int fmarl_init_state(void *handle, void *state, void *stream);
+
+/* MultiAgentGraphEnv.reset (environment.py:882-898) = scenario.reset_world + random_scenario
+ * (navigation_graph.py:212-575) incl. the fair goal assignment (marl_fair_assign.py:16-55), for the
+ * envs with env_mask[e] != 0 (NULL = all), then obs / node_obs / adj of those envs into outs. */
+int fmarl_reset(void *handle, void *state, const uint8_t *env_mask,
+                const FmarlOutputs *outs, void *stream);
+
+/* MultiAgentGraphEnv.step (environment.py:816-877): action decode (:265-311), World.step
+ * (multiagent/core.py:250-274: action force, O(E^2) entity + wall collision forces, integrate),
+ * calculate_distances (core.py:204-228), then per agent observation / reward / graph_observation
+ * / done / info_callback (navigation_graph.py:826-857, 760-824, 941-1035, 577-647).
+ * Exactly one of action_idx (int32 (n, N), value 0..4) and action_vec (float32 (n, N, 5), the
+ * reference's one-hot / continuous form) is non-NULL.
+ * auto_reset != 0 adds the vec-env worker's behaviour (env_wrappers.py:859-865): envs whose agents
+ * are all done are reset and their obs / node_obs / adj are the reset observation while
+ * reward / done / info stay those of the terminal step. */
+int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
+               const FmarlOutputs *outs, int auto_reset, void *stream);
+
+/* Tell the handle the caller wrote into the state buffer (parity harness set_state): drops the
+ * host-side "all envs share one step counter" shortcut used to skip the auto-reset launch. */
+int fmarl_state_changed(void *handle);
+
+/* --- pieces exported on their own -------------------------------------------------------- */
+
+/* cdist(agent_pos, goal_pos) of navigation_graph.py:555: f64 (n, N, 2) x (n, L, 2) -> (n, N, L). */
+int fmarl_cost_matrix(const double *agent_pos, const double *goal_pos, double *costs,
+                      int n_envs, int num_agents, int num_goals, void *stream);
+
+/* solve_fair_assignment (marl_fair_assign.py:16-55): lexicographic-bottleneck assignment of
+ * costs f64 (n, N, N) -> perm i32 (n, N), perm[e][i] = goal of agent i (N <= 64). */
+int fmarl_lexifair(const double *costs, int32_t *perm, int n_envs, int num_agents, void *stream);
+
+/* Scenario.update_graph (navigation_graph.py:1037-1056): COO edges with 0 < adj <= max_edge_dist in
+ * row-major order.  adj f32 (n, E, E) -> edge_index i32 (n, 2, E*E) (padded with -1),
+ * edge_weight f32 (n, E*E), nnz i32 (n). */
+int fmarl_update_graph(const float *adj, int32_t *edge_index, float *edge_weight, int32_t *nnz,
+                       int n_envs, int num_entities, double max_edge_dist, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMARL_H */

@@ -60,10 +60,20 @@ def _perfect_matching(allowed, rows, cols):
 
 
 def lexifair(costs):
-    """Polynomial lexicographic-bottleneck assignment.  Returns perm (int64, shape (N,))."""
+    """Polynomial lexicographic-bottleneck assignment.  Returns perm (int64, shape (N,)).
+
+    Ties are broken by the total order (cost, row, col): the costs are replaced by their ranks
+    in that order, which keeps every strict comparison and makes all entries distinct (so the
+    "bottleneck edge is in every optimal matching" step is exact); the device kernel uses the
+    same order.  The sorted cost vector of the result is lexicographically minimal either way.
+    """
     costs = np.asarray(costs, dtype=np.float64)
     n = costs.shape[0]
     assert costs.shape == (n, n)
+    order = np.lexsort((np.arange(n * n), costs.ravel()))
+    ranks = np.empty(n * n, dtype=np.float64)
+    ranks[order] = np.arange(n * n)
+    costs = ranks.reshape(n, n)
     rows = list(range(n))
     cols = list(range(n))
     perm = np.full(n, -1, dtype=np.int64)

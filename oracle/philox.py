@@ -39,6 +39,7 @@ class PhiloxStream:
     """Sequential draw stream of one (seed, env, episode)."""
 
     def __init__(self, seed, env, episode):
+        seed, env, episode = int(seed), int(env), int(episode)  # never NumPy ints: products must not wrap
         self.key = (seed & MASK, (seed >> 32) & MASK)
         self.env = env & MASK
         self.episode = episode & MASK

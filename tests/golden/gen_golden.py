@@ -100,7 +100,7 @@ def gen_traj():
     save('traj_n3_ep5.npz', run_traj(args, [5, 6], actions))
     # general (non one-hot) float actions: environment.py:303-304 adds a[1]-a[2], a[3]-a[4]
     args = rh.make_args(num_agents=3, num_landmarks=3, num_obstacles=2)
-    actions = rs.uniform(0, 1, size=(8, 2, 3, 5))
+    actions = rs.uniform(0, 1, size=(8, 2, 3, 5)).astype(np.float32).astype(np.float64)  # float32-representable
     save('traj_n3_float.npz', run_traj(args, [21, 22], actions))
     # non-default reward knobs
     args = rh.make_args(num_agents=4, num_landmarks=4, num_obstacles=2, num_walls=1, goal_rew=7.5,

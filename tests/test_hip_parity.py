@@ -1,0 +1,255 @@
+"""-m gpu: the HIP path (through the C-ABI) against the golden fixtures and the oracle.
+
+Tolerances: device STATE is float64 and must follow the float64 reference trajectory closely
+(rtol/atol 1e-9; the stiff soft-contact dynamics amplify last-bit differences of exp/log/sqrt
+implementations); OUTPUTS are float32 and must match within 1e-5 (north_star: "within 1e-5 fp32").
+"""
+import numpy as np
+import pytest
+import torch
+
+import fair_marl_amd as fm
+from oracle import nav_oracle as no
+from oracle.philox import PhiloxStream
+from helpers import TRAJ, cfg_of, load, state_from
+
+pytestmark = pytest.mark.gpu
+OUT = dict(rtol=1e-5, atol=1e-5)
+STATE = dict(rtol=1e-9, atol=1e-9)
+DEV = 'cuda:0'
+
+
+def env_cfg(ocfg):
+    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__})
+
+
+def oracle_state_dict(st):
+    d = {k: getattr(st, k) for k in no.State.FIELDS if k != 'time'}
+    return d
+
+
+def check_outputs(got, want, msg=''):
+    obs, ids, node, adj, rew, done, info = got
+    np.testing.assert_allclose(obs.cpu().numpy(), want['obs'], err_msg=msg + ' obs', **OUT)
+    np.testing.assert_allclose(node.cpu().numpy(), want['node_obs'], err_msg=msg + ' node_obs', **OUT)
+    a = adj.cpu().numpy()
+    np.testing.assert_allclose(a[:, 0], want['adj'], err_msg=msg + ' adj', **OUT)
+    assert np.array_equal(a, np.broadcast_to(a[:, :1], a.shape))
+    np.testing.assert_allclose(rew.cpu().numpy(), want['reward'], err_msg=msg + ' reward', **OUT)
+    assert np.array_equal(done.cpu().numpy().astype(bool), want['done']), msg + ' done'
+    np.testing.assert_allclose(info.cpu().numpy(), want['info'], err_msg=msg + ' info', **OUT)
+
+
+def check_state(eng, st, msg=''):
+    got = eng.get_state()
+    for k in no.State.FIELDS:
+        if k == 'time':
+            continue
+        np.testing.assert_allclose(got[k], getattr(st, k), err_msg=msg + ' state ' + k, **STATE)
+
+
+@pytest.mark.parametrize('name', TRAJ)
+def test_golden_trajectory(name):
+    """Reference outputs (fixtures) vs HIP on the same initial state + action tape."""
+    fx = load(name)
+    ocfg = cfg_of(fx)
+    st = state_from(fx, ocfg)
+    n = st.agent_pos.shape[0]
+    eng = fm.RolloutEngine(env_cfg(ocfg), n, device=DEV)
+    eng.set_state(oracle_state_dict(st))
+    for t in range(fx['actions'].shape[0]):
+        got = eng.step(fx['actions'][t], auto_reset=False)
+        want = {k: fx[k][t] for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
+        check_outputs(got, want, '%s step %d' % (name, t))
+    final = eng.get_state()
+    for k in no.State.FIELDS:
+        if k != 'time':
+            np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
+
+
+@pytest.mark.parametrize('N,O,W,n', [(3, 3, 0, 300), (32, 8, 0, 64), (10, 3, 2, 100), (7, 0, 1, 37), (64, 4, 0, 5)])
+def test_reset_and_rollout_vs_philox_oracle(N, O, W, n):
+    """Device reset (Philox stream, rejection sampling, lexifair) is bit-comparable with the oracle
+    drawing from the same stream; then 30 steps incl. an auto-reset stay within tolerance."""
+    seed = 1234 + N
+    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    check_state(eng, orc.st, 'after make_world')
+    obs, ids, node, adj = eng.reset()
+    o = orc.reset()
+    got = eng.get_state()
+    for k in ('agent_pos', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_orient', 'goal_match', 'min_time'):
+        assert np.array_equal(got[k], getattr(orc.st, k)), k   # bit-exact placement + assignment
+    np.testing.assert_allclose(obs.cpu().numpy(), o[0], **OUT)
+    assert np.array_equal(ids.cpu().numpy(), o[1])
+    np.testing.assert_allclose(node.cpu().numpy(), o[2], **OUT)
+    np.testing.assert_allclose(adj.cpu().numpy(), o[3], **OUT)
+    rs = np.random.RandomState(N)
+    T = 30 if N < 64 else 27
+    for t in range(T):
+        a = rs.randint(0, 5, size=(n, N))
+        res = eng.step(torch.as_tensor(a, device=DEV))
+        ref = orc.step(a)
+        want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
+        check_outputs(res, want, 'N=%d step %d' % (N, t))
+    check_state(eng, orc.st, 'end')
+
+
+def test_masked_reset_and_float_actions():
+    cfg = fm.EnvConfig(num_agents=5, num_landmarks=5, num_obstacles=2, num_walls=2)
+    n, seed = 40, 5
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(3)
+    for t in range(4):
+        a = rs.uniform(0, 1, size=(n, 5, 5)).astype(np.float32)
+        res = eng.step(a, auto_reset=False)
+        out = no.env_step(ocfg, orc.st, a.astype(np.float64))
+        check_outputs(res, out, 'float step %d' % t)
+    mask = rs.randint(0, 2, size=n).astype(np.uint8)
+    before = eng.obs.clone()
+    obs, ids, node, adj = eng.reset(mask)
+    for e in np.nonzero(mask)[0]:
+        orc._reset_one(e)
+    o = no.observe_reset(ocfg, orc.st)
+    m = mask.astype(bool)
+    np.testing.assert_allclose(obs.cpu().numpy()[m], o['obs'][m], **OUT)
+    np.testing.assert_allclose(node.cpu().numpy()[m], o['node_obs'][m], **OUT)
+    assert torch.equal(obs[~torch.as_tensor(m)], before[~torch.as_tensor(m)])   # untouched envs keep their buffers
+    check_state(eng, orc.st, 'masked reset')
+
+
+def test_lexifair_cost_matrix_update_graph():
+    from oracle.lexifair import lexifair
+    eng = fm.RolloutEngine(fm.EnvConfig(num_agents=3, num_landmarks=3), 4, device=DEV)
+    rs = np.random.RandomState(0)
+    for N in (1, 2, 3, 5, 8, 13, 16, 32, 33, 64):
+        n = 24 if N <= 32 else 6
+        ap, gp = rs.uniform(-1, 1, (n, N, 2)), rs.uniform(-0.8, 0.8, (n, N, 2))
+        costs = eng.cost_matrix(ap, gp).cpu().numpy()
+        want = np.stack([no.cost_matrix(ap[e], gp[e]) for e in range(n)])
+        np.testing.assert_allclose(costs, want, rtol=1e-15, atol=1e-16)
+        perm = eng.lexifair(want).cpu().numpy()
+        for e in range(n):
+            assert np.array_equal(perm[e], lexifair(want[e])), (N, e)
+    # ties: integer costs; the device uses the same total order (cost, row, col) as the oracle
+    for N in (4, 7, 20):
+        c = rs.randint(0, 4, size=(10, N, N)).astype(np.float64)
+        perm = eng.lexifair(c).cpu().numpy()
+        for e in range(10):
+            assert np.array_equal(perm[e], lexifair(c[e]))
+    # update_graph on the engine's own adj
+    cfg = fm.EnvConfig(num_agents=6, num_landmarks=6, num_obstacles=3, num_walls=1)
+    eng = fm.RolloutEngine(cfg, 9, device=DEV, seed=3)
+    eng.reset()
+    ei, ew, nnz = eng.update_graph()
+    adj = eng.adj_env.cpu().numpy()
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    for e in range(9):
+        el, w = no.edge_list(ocfg, adj[e])
+        k = int(nnz[e])
+        assert k == el.shape[1]
+        assert np.array_equal(ei[e, :, :k].cpu().numpy(), el)
+        assert np.array_equal(ew[e, :k].cpu().numpy(), w)
+        assert (ei[e, :, k:] == -1).all()
+
+
+def test_vec_env_wrappers_api():
+    """Names / arities / dtypes of the reference wrappers (env_wrappers.py:895-1026) on the HIP engine."""
+    import argparse
+    args = argparse.Namespace(scenario_name='navigation_graph', num_agents=3, num_landmarks=3, num_obstacles=3,
+                              num_walls=0, world_size=2, max_speed=2, collision_rew=5, goal_rew=5,
+                              min_dist_thresh=0.05, fair_wt=1, fair_rew=1, zeroshift=5, max_edge_dist=1,
+                              episode_length=25, collaborative=False, use_dones=False, graph_feat_type='relative',
+                              num_scripted_agents=0)
+
+    def get_env_fn(rank):   # onpolicy/scripts/train_mpe.py:22-32
+        def init_env():
+            env = fm.GraphMPEEnv(args)
+            env.seed(1 + rank * 1000)
+            return env
+        return init_env
+    n = 8
+    venv = fm.GraphSubprocVecEnv([get_env_fn(i) for i in range(n)], device=DEV)
+    assert venv.num_envs == n and len(venv.observation_space) == 3
+    assert venv.observation_space[0].shape == (7,) and venv.share_observation_space[0].shape == (21,)
+    assert venv.action_space[0].__class__.__name__ == 'Discrete' and venv.action_space[0].n == 5
+    assert venv.node_observation_space[0].shape == (9, 11) and venv.adj_observation_space[0].shape == (9, 9)
+    assert venv.edge_observation_space[0].shape == (1,) and venv.share_agent_id_observation_space[0].shape == (3,)
+    obs, ids, node, adj = venv.reset()
+    assert obs.shape == (n, 3, 7) and obs.dtype == np.float64
+    assert ids.shape == (n, 3, 1) and ids.dtype == np.int64
+    assert node.shape == (n, 3, 9, 11) and adj.shape == (n, 3, 9, 9) and adj.dtype == np.float64
+    orc = no.OracleGraphVecEnv(no.Config.from_args(args), n, mode='subproc', streams=lambda e, ep: PhiloxStream(1, e, ep))
+    o = orc.reset()
+    np.testing.assert_allclose(obs, o[0], **OUT)
+    rs = np.random.RandomState(0)
+    for t in range(26):
+        a = np.eye(5)[rs.randint(0, 5, size=(n, 3))]
+        res = venv.step(a)
+        ref = orc.step(a)
+        assert len(res) == 7
+        obs, ids, node, adj, rew, done, infos = res
+        assert rew.shape == (n, 3) and rew.dtype == np.float64 and done.dtype == bool
+        np.testing.assert_allclose(obs, ref[0], **OUT)
+        np.testing.assert_allclose(rew, ref[4], **OUT)
+        assert np.array_equal(done, ref[5])
+        assert len(infos) == n and len(infos[0]) == 3
+        d = infos[2][1]
+        assert list(d.keys())[0] == 'individual_reward' and len(d) == 14
+        assert abs(d['Dists_traveled'] - ref[6][2, 1, 7]) < 1e-5
+        assert done.all() == (t == 24)   # step 25 is terminal; its obs are already those of the reset
+    venv.close()
+    dv = fm.GraphDummyVecEnv([get_env_fn(0)], device=DEV)
+    dv.reset()
+    res = dv.step(np.eye(5)[np.zeros((1, 3), dtype=int)])
+    assert len(res) == 8 and res[7] == 0
+    args.scenario_name = 'navigation_graph'
+    sv = fm.SubprocVecEnv([lambda: fm.MPEEnv(args) for _ in range(4)], device=DEV)
+    assert sv.reset().shape == (4, 3, 7)
+    r = sv.step(np.eye(5)[np.zeros((4, 3), dtype=int)])
+    assert len(r) == 4 and r[1].shape == (4, 3)
+    with pytest.raises(NotImplementedError):
+        args.scenario_name = 'simple_spread'
+        fm.MPEEnv(args)
+
+
+def test_full_size_properties_cfg3():
+    """BASELINE config 3 shapes (32 agents + 8 obstacles, 65 536 envs): size-independent properties plus
+    oracle parity on a sample of envs."""
+    cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
+    n = 65536
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=11)
+    eng.reset()
+    gm = eng.field('goal_match')
+    assert torch.equal(torch.sort(gm, dim=1).values, torch.arange(32, device=DEV, dtype=torch.int32).expand(n, 32))
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    sample = torch.arange(0, n, 1021, device=DEV)
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    for t in range(3):
+        a = torch.randint(0, 5, (n, 32), device=DEV, generator=g, dtype=torch.int32)
+        if t == 2:   # oracle on the sampled envs from the pre-step state
+            st = no.State(ocfg, len(sample))
+            pre = eng.get_state()
+            for k in no.State.FIELDS:
+                if k != 'time':
+                    getattr(st, k)[...] = pre[k][sample.cpu().numpy()]
+            st.time[...] = (st.cur_step * no.DT)[:, None]
+        obs, ids, node, adj, rew, done, info = eng.step(a, auto_reset=False)
+    adj_env = eng.adj_env
+    assert torch.equal(adj_env, adj_env.transpose(1, 2))                       # symmetric
+    assert (torch.diagonal(adj_env, dim1=1, dim2=2) == 0).all()                # zero diagonal
+    assert torch.isfinite(node).all() and torch.isfinite(obs).all()
+    # relative position block is antisymmetric between agents, and norms agree with adj
+    rel = node[:, :, :32, 2:4]
+    assert torch.allclose(rel, -rel.transpose(1, 2), atol=1e-6)
+    assert torch.allclose(rel.norm(dim=-1), adj_env[:, :32, :32], atol=1e-6)
+    assert (node[..., 10] == torch.tensor([0.] * 32 + [1.] * 32 + [2.] * 8, device=DEV)).all()
+    assert (rew <= cfg.goal_rew + cfg.fair_rew).all() and (rew >= -2 * cfg.collision_rew).all()
+    out = no.env_step(ocfg, st, a[sample].cpu().numpy())
+    s = sample
+    check_outputs((obs[s], ids[s], node[s], adj[s], rew[s], done[s], info[s]), out, 'cfg3 sample')

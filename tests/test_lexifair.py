@@ -38,3 +38,18 @@ def test_lexicographic_property_n32():
             q = p.copy(); q[i], q[j] = p[j], p[i]
             alt = np.sort(c[np.arange(32), q])[::-1]
             assert tuple(base) <= tuple(alt)
+
+
+def test_ties_total_order():
+    """With tied costs the reference's result is solver-dependent (Gurobi picks any optimum of each
+    round, marl_fair_assign.py:33-39); the oracle and the device define ties by the total order
+    (cost, row, col).  The bottleneck (largest assigned cost) is still the brute-force minimum."""
+    rs = np.random.RandomState(5)
+    for n in (3, 4, 5, 6):
+        for _ in range(30):
+            c = rs.randint(0, 4, size=(n, n)).astype(np.float64)
+            p = lexifair(c)
+            assert sorted(p) == list(range(n))
+            assert c[np.arange(n), p].max() == c[np.arange(n), lexifair_bruteforce(c)].max()
+            eps = c + 1e-9 * np.arange(n * n).reshape(n, n)   # the same order made explicit
+            assert np.array_equal(p, lexifair_bruteforce(eps))
