@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Throughput of the rollout hot path: random-action rollouts of navigation_graph on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3|cfg2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one env step of EVERY env of every rank (one pass of the hot path over one batch):
+action decode -> World.step physics -> obs / reward / info / node_obs / adj emission, plus the
+auto-reset (placement + fair assignment + reset observation) whenever an episode ends (every
+25th step).  Inputs (the random action tape) and all outputs stay resident in HBM.
+
+Metric (BASELINE.json): agent-steps/s = total envs x agents x K / wall seconds, where wall is
+the max over ranks of the time of exactly K steps bracketed by barrier + device sync.
+With N > 1 each rank owns 65 536 envs (weak scaling) and every step's trajectory record
+(obs, reward, done) is gathered to rank 0 over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how roofline / cpu_baseline are built.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import fair_marl_amd as fm  # noqa: E402
+from fair_marl_amd.sharding import StepRecord, TrajectoryGather  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # BASELINE.json configs[2] (and configs[4] per GPU): the configuration the target is quoted on
+    'cfg3': dict(workload='navigation_graph, 32 agents + 8 obstacles (E=72), 65536 envs per GPU',
+                 env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=64, cpu_episodes=5),
+    # BASELINE.json configs[1]
+    'cfg2': dict(workload='navigation_graph, 3 agents + 3 obstacles (E=9), 4096 envs per GPU',
+                 env=dict(num_agents=3, num_landmarks=3, num_obstacles=3), n_envs=4096, cpu_envs=512, cpu_episodes=20),
+}
+
+
+def algorithmic_bytes(cfg, emit=True):
+    """bytes per agent-step, B = 4 [A + S + D + R + F E + E^2/N + C/N]."""
+    N, E = cfg.N, cfg.E
+    C = 2 * (cfg.num_landmarks + cfg.num_obstacles) + 6 * cfg.num_walls
+    A, S, R = 1, 2 * 12, 3
+    words = A + S + R
+    if emit:
+        words += cfg.obs_dim + cfg.node_feat * E + E * E / N + C / N
+    return 4.0 * words
+
+
+def cpu_baseline(cfg, n_envs, episodes):
+    """The oracle (NumPy float64 restatement, single core) on a bounded sample of the same workload."""
+    from oracle import nav_oracle as no
+    from oracle.philox import PhiloxStream
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    env = no.OracleGraphVecEnv(ocfg, n_envs, mode='subproc', streams=lambda e, ep: PhiloxStream(1, e, ep))
+    env.reset()
+    rs = np.random.RandomState(0)
+    steps = episodes * cfg.episode_length
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.step(rs.randint(0, 5, size=(n_envs, cfg.N)))
+    dt = time.perf_counter() - t0
+    return dict(value=n_envs * cfg.N * steps / dt, unit='agent-steps/s', cores=1, kind='port',
+                sample='%d envs x %d agents x %d steps (%d episodes incl. auto-resets), NumPy f64 oracle, %.1f s'
+                       % (n_envs, cfg.N, steps, episodes, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
+    ap.add_argument('--n-envs', type=int, default=0, help='envs per GPU (default: the config\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gather', action='store_true', help='multi-GPU: skip the RCCL trajectory gather')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)'
+                         % (args.gpus, world))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    spec = CONFIGS[args.config]
+    cfg = fm.EnvConfig(**spec['env'])
+    n_envs = args.n_envs or spec['n_envs']
+    K, W = args.steps, args.warmup
+    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs)
+    gather = world > 1 and not args.no_gather
+    depth = 2
+    tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth) if gather else None
+    if gather:
+        sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done) for r in tg.records]
+    else:
+        sets = [eng.outs]
+
+    # synthetic action tape: int32 U{0..4} per (step, env, agent), resident in HBM before timing
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + rank)
+    tape_len = 32
+    tape = torch.randint(0, 5, (tape_len, n_envs, cfg.N), device=device, generator=g, dtype=torch.int32)
+
+    def run(first, count):
+        for t in range(first, first + count):
+            if gather:
+                tg.record(t)
+                eng.use_outputs(sets[t % depth])
+            eng.step(tape[t % tape_len], auto_reset=True)
+            if gather:
+                tg.submit(t)
+        if gather:
+            tg.finish()
+
+    eng.reset()
+    run(0, W)
+    torch.cuda.synchronize(device)
+    eng.profile_enable(K)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run(W, K)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = eng.profile_read()
+
+    if rank == 0:
+        agents = n_envs * cfg.N
+        # dominant kernel = step_kernel.  Launches on episode-end steps do not emit obs/node_obs/adj
+        # (the reset path does), so their algorithmic bytes are the state + reward part only.
+        ep = cfg.episode_length
+        resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)
+        bytes_per_launch = agents * (algorithmic_bytes(cfg) * (K - resets) + algorithmic_bytes(cfg, emit=False) * resets) / K
+        k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
+        achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.config, {}).get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), navigation_graph random-action rollout',
+            'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64 state and contact math, f32 outputs', 'data': 'synthetic',
+            'config': {'workload': spec['workload'], 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
+                       'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
+                       'exchange': ('RCCL gather of obs/reward/done to rank 0 every step, %d B per agent-step'
+                                    % StepRecord.bytes_per_agent_step(cfg.obs_dim)) if gather else 'none'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'step_kernel',
+                         'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),
+                         'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg, spec['cpu_envs'], spec['cpu_episodes'])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

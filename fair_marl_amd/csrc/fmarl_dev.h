@@ -19,7 +19,8 @@ constexpr double kWallWidth = 0.1;
 constexpr double kSensitivity = 5.0;
 constexpr int kThreads = 256;       // workgroup size of the step / emit kernels (4 waves)
 constexpr int kMaxTries = 10000;    // bound on the reference's unbounded rejection loops
-constexpr int kBWidth = 5;          // ego table width: vx, vy, x, y, 0
+constexpr int kEgoWidth = 5;         // LDS ego row: vx, vy, x, y, 0
+constexpr int kStepWavesPerSimd = 5; // register budget of step_kernel: 5 waves/SIMD = 5 workgroups of 256 per CU
 
 // floor(q / d) for q * d < 2^40, q < 2^24 (block-local flat indices): one 64-bit multiply.
 struct FastDiv {
@@ -34,11 +35,12 @@ struct Params {
     int n_envs, N, L, O, W, E, D, F;
     int episode_length, has_max_speed, env_offset, scenario;
     int epb;                 // environments per workgroup = kThreads / N
-    int lds_pos, lds_stat, lds_a, lds_b, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
+    int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
     uint64_t seed;
-    FastDiv dNEF, dEF, dF, dEE, dE, dLO;
-    uint64_t bsel;           // nibble f = ego-table column subtracted from feature column f (4 = constant 0)
+    FastDiv dNEF, dEF, dF, dEE, dE, dLO, dC4, dNC4, dEE4, dE4;
+    int ablate;              // measurement aid (env FMARL_ABLATE, bench only): bit mask of phases to skip
+    int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
     // state
     double2 *agent_pos, *agent_vel, *landmark_pos, *obstacle_pos;
     double *p_dist, *wall_axis, *wall_e0, *wall_e1, *wall_length;
@@ -77,15 +79,41 @@ struct PhiloxStream {
     __device__ int choice_hv() { double a, b; next(a, b); return a < 0.5 ? 0 : 1; }  // 0 = 'H'
 };
 
-// np.logaddexp(0, z) * k -- reference core.py:391 / :439 (softplus penetration)
+// log(u) for u in [1, 2], absolute error < 1e-16: u -> m in [1/sqrt2, sqrt2], s = (m-1)/(m+1),
+// log m = 2 s (1 + s^2/3 + ... + s^20/21) (|s| <= 0.172, truncation 6e-19).  ~27 f64 ops where the
+// library log1p spends 113; absolute (not relative) accuracy is what the force sum needs.
+__device__ __forceinline__ double log_1to2(double u) {
+    const bool big = u > 1.4142135623730951;
+    const double m = big ? u * 0.5 : u;
+    const double s = (m - 1.0) / (m + 1.0), w = s * s;
+    double q = 1.0 / 21.0;
+    q = fma(q, w, 1.0 / 19.0); q = fma(q, w, 1.0 / 17.0); q = fma(q, w, 1.0 / 15.0);
+    q = fma(q, w, 1.0 / 13.0); q = fma(q, w, 1.0 / 11.0); q = fma(q, w, 1.0 / 9.0);
+    q = fma(q, w, 1.0 / 7.0);  q = fma(q, w, 1.0 / 5.0);  q = fma(q, w, 1.0 / 3.0);
+    q = fma(q, w, 1.0);
+    const double r = 2.0 * s * q;
+    return big ? r + 0.6931471805599453 : r;
+}
+
+// np.logaddexp(0, z) * k -- reference core.py:391 / :439 (softplus penetration).
+// logaddexp(0, z) = max(z, 0) + log(1 + exp(-|z|)); 1 + t is rounded once (abs error 1.1e-16).
 __device__ __forceinline__ double softplus_pen(double z, double k) {
-    double la = (z > 0.0) ? z + log1p(exp(-z)) : log1p(exp(z));
-    return la * k;
+    const double t = exp(-fabs(z));
+    return (fmax(z, 0.0) + log_1to2(1.0 + t)) * k;
 }
 
 __device__ __forceinline__ double dist2(double2 a, double2 b) {
     double dx = a.x - b.x, dy = a.y - b.y;
     return sqrt(dx * dx + dy * dy);
+}
+
+// sqrt(|a-b|^2) < c, decided on the squared distance unless it is within a few ulp of c^2
+// (navigation_graph.py:659, :695, :705 compare np.linalg.norm(delta) < dist_min)
+__device__ __forceinline__ bool closer_than(double2 a, double2 b, double c) {
+    const double dx = a.x - b.x, dy = a.y - b.y, s = dx * dx + dy * dy, c2 = c * c;
+    if (s < c2 * (1.0 - 1e-15)) return true;
+    if (s > c2 * (1.0 + 1e-15)) return false;
+    return sqrt(s) < c;
 }
 
 // navigation_graph.py:671-683: wall box test with the 1.05 factors

@@ -129,14 +129,8 @@ __global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOut
             ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;
             ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)fairness;
         }
-        float *A = (float *)(base + p.lds_a) + i * p.F;
-        float *B = (float *)(base + p.lds_b) + i * kBWidth;
-        const float fx = (float)x.x, fy = (float)x.y, fvx = (float)v.x, fvy = (float)v.y;
-        A[0] = fvx; A[1] = fvy; A[2] = fx; A[3] = fy; A[4] = (float)goal.x; A[5] = (float)goal.y;
-        A[6] = fx; A[7] = fy; A[8] = fx; A[9] = fy; A[10] = 0.f;
-        B[0] = fvx; B[1] = fvy; B[2] = fx; B[3] = fy; B[4] = 0.f;
+        store_agent_rows(p, base, i, x, v, goal);
     }
-    fill_static_rows(p, lds, nenv);
     __syncthreads();
     emit_graph(p, o, lds, env0, nenv);
 }

@@ -9,81 +9,168 @@
 //                                       observation, reward, graph_observation, info_callback
 //
 // Data flow inside one workgroup (epb = 256 / N environments):
-//   HBM state (f64 SoA, 16 B per lane for pos / vel) -> registers + LDS entity table
+//   HBM state (f64 SoA, 16 B per lane for pos / vel) -> registers + LDS entity table (f64 positions)
 //   -> all-pairs soft-contact forces out of LDS -> integrate in registers
-//   -> LDS: new positions, per-env fairness vectors -> per-agent obs / reward / info (closed form of the
-//      reference's sequential agent loop) -> LDS row tables A (entity features) and B (ego features)
-//   -> streaming, lane-contiguous stores of node_obs = A - B and adj = |x_a - x_b| to HBM.
+//   -> LDS: new positions, per-env fairness vectors, per-agent (vel, goal) rows
+//   -> per-agent obs / reward / info (closed form of the reference's sequential agent loop)
+//   -> streaming 16-byte stores of node_obs[i][e][:] = feat(e) - ego(i) and adj = |x_a - x_b| to HBM.
+// The per-env LDS footprint is kept to the compact tables (about 3 KiB at E = 72) because occupancy
+// is what lets the store stream of one workgroup overlap the f64 contact math of the others.
 #pragma once
 #include "fmarl_dev.h"
 #include "fmarl_kernels.h"
 
 namespace fmarl {
 
-// ------------------------------------------------------------------------------------------------
-// Emission: node_obs[env][i][e][f] = A[env][e][f] - B[env][i][bsel[f]];  adj[env][a][b] = |x_a - x_b|.
-// Lanes walk the flat output index so that every wave store is 256 contiguous bytes.
-// `skip` (per env, in LDS) marks envs whose observation is produced by the reset path instead.
-__device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+// ---------------------------------------------------------------------------------------------
+// Per-env LDS tables (byte offsets in Params): pos[E] double2 | agentf[N] float4 (vx, vy, gx, gy) |
+// ego[N] 5 floats (vx, vy, x, y, 0) | stat[5 N] double | wall[W] 4 doubles (axis, e0, e1, orient) | flag int (1 = obs comes from a reset).
+struct EnvLds {
+    const char *base;
+    const Params &p;
+    __device__ EnvLds(const Params &p_, const char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
+    __device__ const double2 *pos() const { return (const double2 *)(base + p.lds_pos); }
+    __device__ const float4 *agentf() const { return (const float4 *)(base + p.lds_agentf); }
+    __device__ const double *wall() const { return (const double *)(base + p.lds_wall); }
+    __device__ bool skip() const { return *(const int *)(base + p.lds_flag) != 0; }
+
+    // Column f of the node-feature row of entity e before the ego part is subtracted
+    // (navigation_graph.py:1079-1124): [vel, pos, goal, pos, pos, type]; walls: corners in 6..9.
+    __device__ float entity_feature(uint32_t e, uint32_t f) const {
+        const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
+        if (f == 10) return e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
+        if (f < 2) {
+            if (e >= N) return 0.f;
+            const float4 a = agentf()[e];
+            return f == 0 ? a.x : a.y;
+        }
+        if (e < N && f < 6 && f >= 4) {   // goal of agent e
+            const float4 a = agentf()[e];
+            return f == 4 ? a.z : a.w;
+        }
+        if (e >= first_wall && f >= 6) {   // (e0, axis + w/2), (e1, axis - w/2): navigation_graph.py:1115-1116
+            const double *wl = wall() + (e - first_wall) * 4;
+            return (float)(f == 6 ? wl[1] : (f == 7 ? wl[0] + kWallWidth / 2 : (f == 8 ? wl[2] : wl[0] - kWallWidth / 2)));
+        }
+        const double2 x = pos()[e];
+        return (float)((f & 1) ? x.y : x.x);
+    }
+    // ego part of column f: [vx vy | x y | x y | x y | x y | 0]
+    __device__ float ego_feature(uint32_t i, uint32_t f) const {
+        if (f == 10) return 0.f;
+        if (f < 2) { const float4 a = agentf()[i]; return f == 0 ? a.x : a.y; }
+        const double2 x = pos()[i];
+        return (float)((f & 1) ? x.y : x.x);
+    }
+};
+
+// node_obs, 16-byte path (E*F % 4 == 0, at most 64 * CG <= 256 float4 chunks per ego row).  A wave owns whole
+// environments: each lane builds the entity part of its CG column chunks once per env, then the wave
+// streams the N ego rows front to back (1 KiB per store instruction, rows back to back in memory).
+template <int CG>
+__device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    const uint32_t EF = p.E * p.F, C4 = EF >> 2;
+    for (uint32_t el = wave; el < (uint32_t)nenv; el += nwaves) {
+        const EnvLds t(p, lds, el);
+        if (t.skip()) continue;
+        float4 a[CG];
+        uint32_t boff[CG][4];   // byte offset of each element's ego value inside an ego row [vx vy x y 0]
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+            const uint32_t c = g * 64 + lane;
+            a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            boff[g][0] = boff[g][1] = boff[g][2] = boff[g][3] = 0;
+            if (c < C4) {
+                uint32_t e = p.dF.div(c * 4), f = c * 4 - e * p.F;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = t.entity_feature(e, f);
+                    boff[g][k] = 4 * (f == 10 ? 4 : (f < 2 ? f : 2 + (f & 1)));
+                    if (++f == (uint32_t)p.F) { f = 0; ++e; }
+                }
+                a[g] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        float4 *dst = (float4 *)(o.node_obs + ((size_t)(env0 + el) * p.N) * EF);
+        const char *ego = t.base + p.lds_ego;
+        for (int i = 0; i < p.N; ++i, ego += kEgoWidth * 4, dst += C4) {
+#pragma unroll
+            for (int g = 0; g < CG; ++g) {
+                const uint32_t c = g * 64 + lane;
+                if (c < C4) {
+                    float b[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) b[k] = *(const float *)(ego + boff[g][k]);
+                    dst[c] = make_float4(a[g].x - b[0], a[g].y - b[1], a[g].z - b[2], a[g].w - b[3]);
+                }
+            }
+        }
+    }
+}
+
+// Emission of the graph outputs of the workgroup's envs.
+__device__ void emit_graph(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
     const int tid = threadIdx.x;
     const uint32_t NEF = p.N * p.E * p.F, EF = p.E * p.F, EE = p.E * p.E;
-    if (o.node_obs) {
+    if (o.node_obs && p.vec_node) {
+        const uint32_t groups = ((EF >> 2) + 63) >> 6;
+        if (groups <= 1) emit_node_rows<1>(p, o, lds, env0, nenv);
+        else if (groups <= 2) emit_node_rows<2>(p, o, lds, env0, nenv);
+        else emit_node_rows<4>(p, o, lds, env0, nenv);
+    } else if (o.node_obs) {   // any shape: one float per lane, 256 contiguous bytes per wave store
         float *dst = o.node_obs + (size_t)env0 * NEF;
         const uint32_t total = nenv * NEF;
         for (uint32_t q = tid; q < total; q += kThreads) {
-            uint32_t el = p.dNEF.div(q);
-            const char *base = lds + (size_t)el * p.lds_env_bytes;
-            if (*(const int *)(base + p.lds_flag)) continue;
-            uint32_t r = q - el * NEF;
-            uint32_t i = p.dEF.div(r);
-            uint32_t s = r - i * EF;
-            uint32_t f = s - p.dF.div(s) * p.F;
-            const float *A = (const float *)(base + p.lds_a);
-            const float *B = (const float *)(base + p.lds_b);
-            dst[q] = A[s] - B[i * kBWidth + (uint32_t)((p.bsel >> (4 * f)) & 0xF)];
+            const uint32_t el = p.dNEF.div(q);
+            const EnvLds t(p, lds, el);
+            if (t.skip()) continue;
+            const uint32_t r = q - el * NEF, i = p.dEF.div(r), s = r - i * EF;
+            const uint32_t e = p.dF.div(s), f = s - e * p.F;
+            dst[q] = t.entity_feature(e, f) - t.ego_feature(i, f);
         }
     }
-    if (o.adj) {
+    if (o.adj && p.vec_adj) {
+        // 16-byte path (E % 4 == 0): the workgroup streams its region front to back (chunk m = tid + 256 k:
+        // its four waves write one 4 KiB window at a time); a lane computes |x_a - x_b| for four b.
+        const uint32_t E4 = p.E >> 2, per_env = p.E * E4, chunks = nenv * per_env;
+        float4 *dst = (float4 *)(o.adj + (size_t)env0 * EE);
+        for (uint32_t m = tid; m < chunks; m += kThreads) {
+            const uint32_t el = p.dEE4.div(m), r = m - el * per_env;
+            const EnvLds t(p, lds, el);
+            if (t.skip()) continue;
+            const uint32_t a = p.dE4.div(r), b4 = r - a * E4;
+            const double2 pa = t.pos()[a];
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double2 pb = t.pos()[b4 * 4 + k];
+                const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
+                v[k] = sqrtf(dx * dx + dy * dy);
+            }
+            dst[m] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else if (o.adj) {
         float *dst = o.adj + (size_t)env0 * EE;
         const uint32_t total = nenv * EE;
         for (uint32_t q = tid; q < total; q += kThreads) {
-            uint32_t el = p.dEE.div(q);
-            const char *base = lds + (size_t)el * p.lds_env_bytes;
-            if (*(const int *)(base + p.lds_flag)) continue;
-            uint32_t r = q - el * EE;
-            uint32_t a = p.dE.div(r);
-            uint32_t b = r - a * p.E;
-            const double2 *pos = (const double2 *)(base + p.lds_pos);
-            double2 pa = pos[a], pb = pos[b];
-            float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
+            const uint32_t el = p.dEE.div(q);
+            const EnvLds t(p, lds, el);
+            if (t.skip()) continue;
+            const uint32_t r = q - el * EE, a = p.dE.div(r), b = r - a * p.E;
+            const double2 pa = t.pos()[a], pb = t.pos()[b];
+            const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
             dst[q] = sqrtf(dx * dx + dy * dy);
         }
     }
 }
 
-// Static rows of the A table (landmarks, obstacles, walls) and the wall records; cooperative.
-// navigation_graph.py:1100-1124: [rel_vel, rel_pos, rel_goal = rel_pos, rel_pos, rel_pos, type];
-// walls replace the last two pairs by corner points (:1115-1116).
-__device__ void fill_static_rows(const Params &p, char *lds, int nenv) {
-    const int S = p.L + p.O + p.W;
-    for (int t = threadIdx.x; t < nenv * S; t += kThreads) {
-        int el = t / S, k = t - el * S;
-        char *base = lds + (size_t)el * p.lds_env_bytes;
-        const double2 *pos = (const double2 *)(base + p.lds_pos);
-        float *A = (float *)(base + p.lds_a) + (p.N + k) * p.F;
-        double2 x = pos[p.N + k];
-        float fx = (float)x.x, fy = (float)x.y;
-        float type = k < p.L ? 1.f : (k < p.L + p.O ? 2.f : 3.f);
-        A[0] = 0.f; A[1] = 0.f; A[2] = fx; A[3] = fy; A[4] = fx; A[5] = fy;
-        if (k < p.L + p.O) {
-            A[6] = fx; A[7] = fy; A[8] = fx; A[9] = fy;
-        } else {
-            const double *wl = (const double *)(base + p.lds_wall) + (k - p.L - p.O) * 4;
-            A[6] = (float)wl[1]; A[7] = (float)(wl[0] + kWallWidth / 2);   // (e0, axis + w/2)
-            A[8] = (float)wl[2]; A[9] = (float)(wl[0] - kWallWidth / 2);   // (e1, axis - w/2)
-        }
-        A[10] = type;
-    }
+// f32 rows of agent i used by the emission: agentf = (vx, vy, gx, gy), ego = [vx vy x y 0].
+__device__ __forceinline__ void store_agent_rows(const Params &p, char *base, int i, double2 x, double2 v, double2 goal) {
+    ((float4 *)(base + p.lds_agentf))[i] = make_float4((float)v.x, (float)v.y, (float)goal.x, (float)goal.y);
+    float *ego = (float *)(base + p.lds_ego) + i * kEgoWidth;
+    ego[0] = (float)v.x; ego[1] = (float)v.y; ego[2] = (float)x.x; ego[3] = (float)x.y; ego[4] = 0.f;
 }
 
 // Loads landmarks / obstacles / walls of the workgroup's envs into the LDS entity table.
@@ -124,8 +211,8 @@ __device__ __forceinline__ void mixed_stats(const double *fresh, const double *s
     sd = sqrt(q / n);
 }
 
-__global__ __launch_bounds__(kThreads) void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
-                                                        const float *action_vec, int auto_reset) {
+__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
+    Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int env0 = blockIdx.x * p.epb;
@@ -140,9 +227,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params p, FmarlOutputs o
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0;
-    int step = 0;
+    int step = 0, match = 0;
     if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
+        match = p.goal_match[g];
         s_pos[i] = x;
         step = p.cur_step[env] + 1;   // environment.py:819, :823
     }
@@ -150,6 +238,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params p, FmarlOutputs o
     __syncthreads();
 
     // ---- World.step (core.py:250-274) ---------------------------------------------------------
+    double2 goal = make_double2(0, 0);
     if (active) {
         double ux, uy;
         if (action_idx) {
@@ -162,19 +251,35 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params p, FmarlOutputs o
             uy = ((double)a[3] - (double)a[4]) * kSensitivity;
         }
         double Fx = ux, Fy = uy;   // core.py:277-298, mass 1
+        goal = s_pos[p.N + match];
         // core.py:301-316 + :370-404: agent-agent, agent-obstacle, agent-wall-entity pairs
         const int first_obst = p.N + p.L, first_wall = first_obst + p.O;
-        for (int b = 0; b < p.E; ++b) {
+        for (int b = 0; b < ((p.ablate & 1) ? 0 : p.E); ++b) {
             if (b == i || (b >= p.N && b < first_obst)) continue;   // self; landmarks do not collide
-            double2 q = s_pos[b];
-            double dx = x.x - q.x, dy = x.y - q.y;
-            double d = sqrt(dx * dx + dy * dy);
-            double dmin = b < first_wall ? 2 * kEntitySize : kEntitySize + kWallWidth;
-            double z = -(d - dmin) / kContactMargin;
-            if (z < -37.0) continue;   // softplus tail < 1e-16 * margin: below f64 resolution of the sum
-            double pen = softplus_pen(z, kContactMargin);
-            Fx += kContactForce * dx / d * pen;
-            Fy += kContactForce * dy / d * pen;
+            const double2 q = s_pos[b];
+            const double dx = x.x - q.x, dy = x.y - q.y;
+            const double d2 = dx * dx + dy * dy;
+            const double dmin = b < first_wall ? 2 * kEntitySize : kEntitySize + kWallWidth;
+            // z = -(d - dmin) / margin.  Three regimes by distance (all exact to ~1e-16 in the force):
+            //   z < -37      : softplus tail < 1e-16 * margin, below f64 resolution of the sum -> skip
+            //   -37 <= z < -24: force < 2.3e-10, evaluated in f32 (relative 1e-6 -> absolute 2e-16)
+            //   otherwise    : f64
+            const double far = dmin + 37.0 * kContactMargin, mid = dmin + 24.0 * kContactMargin;
+            if (d2 > far * far) continue;
+            if (d2 > mid * mid) {
+                const float fdx = (float)dx, fdy = (float)dy;
+                const float r = rsqrtf(fdx * fdx + fdy * fdy), d = 1.0f / r;
+                const float e = __expf(((float)dmin - d) * (float)(1.0 / kContactMargin));
+                const float c = (float)(kContactForce * kContactMargin) * e * r;
+                Fx += (double)(c * fdx);
+                Fy += (double)(c * fdy);
+                continue;
+            }
+            const double d = sqrt(d2);
+            const double z = -(d - dmin) / kContactMargin;
+            const double c = kContactForce * softplus_pen(z, kContactMargin) / d;
+            Fx += c * dx;
+            Fy += c * dy;
         }
         // core.py:317-326 + :407-462 walls proper
         const double *wl = (const double *)(base + p.lds_wall);
@@ -210,53 +315,51 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params p, FmarlOutputs o
     }
     __syncthreads();   // every lane has finished reading the old positions
 
-    double Dg_old = 0, Tr_old = 0, left_old = 0, left_new = 0, rew = 0;
-    int match = 0, noc = 0, nac = 0;
+    double Dg_old = 0, Tr_old = 0, left_old = 0, dg = 0, Tr_new = 0;
     bool will_reset = false;
     if (active) {
         s_pos[i] = x;
+        store_agent_rows(p, base, i, x, v, goal);
         Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left_old = p.dist_left[g];
-        match = p.goal_match[g];
         const bool open = Tr_old == -1.0;
+        dg = dist2(x, goal);                                          // navigation_graph.py:583, :774
+        Tr_new = (dg < p.thr && open) ? step * kDt : Tr_old;          // :587-589
         s_stat[i] = pd;
         s_stat[p.N + i] = Dg_old;
-        s_stat[2 * p.N + i] = open ? pd : Dg_old;                     // navigation_graph.py:590, :597
+        s_stat[2 * p.N + i] = open ? pd : Dg_old;                     // :590, :597
         s_stat[3 * p.N + i] = Tr_old;
+        s_stat[4 * p.N + i] = Tr_new;
         will_reset = auto_reset && step >= p.episode_length;          // env_wrappers.py:859-864
         if (i == 0) *(int *)(base + p.lds_flag) = will_reset ? 1 : 0;
     }
     __syncthreads();
 
     if (active) {
-        const double2 goal = s_pos[p.N + match];
-        const double dg = dist2(x, goal);                             // :583, :774
         const bool open = Tr_old == -1.0;
-        const bool arrive = dg < p.thr && open;                       // :587
-        const double Tr_new = arrive ? step * kDt : Tr_old;           // :589
         const double Dg_new = open ? pd : Dg_old;
-        left_new = open ? dg : left_old;                 // :591, :598
-        s_stat[4 * p.N + i] = Tr_new;
+        const double left_new = open ? dg : left_old;                 // :591, :598
 
         // fairness scalar of obs_i / reward_i (:764-769, :849-854): p_dist statistics while this
         // agent's dists_to_goal is still -1, otherwise the statistics info_{i-1} left behind.
         double fairness, m, sd;
-        if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
+        if (p.ablate & 2) { m = 1.0; sd = 1.0; }
+        else if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd);
         fairness = m / (sd + 0.0001);
 
         // collisions (:701-705, :650-684)
         int ag_hits = 0;
-        for (int j = 0; j < p.N; ++j)
-            if (j != i && dist2(x, s_pos[j]) < 1.05 * (kEntitySize + kEntitySize)) ++ag_hits;
+        for (int j = 0; j < ((p.ablate & 4) ? 0 : p.N); ++j)
+            if (j != i && closer_than(x, s_pos[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
         bool ob_hit = false;
         for (int k = 0; k < p.O; ++k)
-            ob_hit |= dist2(s_pos[p.N + p.L + k], x) < 1.05 * (kEntitySize + kEntitySize);
+            ob_hit |= closer_than(s_pos[p.N + p.L + k], x, 1.05 * (kEntitySize + kEntitySize));
         const double *wl = (const double *)(base + p.lds_wall);
         for (int w = 0; w < p.W; ++w)
             ob_hit |= wall_box_hit(x, wl[w * 4], wl[w * 4 + 1], wl[w * 4 + 2], (int)wl[w * 4 + 3]);
 
         // reward (:760-824)
-        rew = dg < p.thr ? p.goal_rew : -dg;
+        double rew = dg < p.thr ? p.goal_rew : -dg;
         rew -= p.collision_rew * ag_hits;
         if (ob_hit) rew -= p.collision_rew;
         double fr = p.fair_rew * tanh(fairness - p.zeroshift);
@@ -265,50 +368,44 @@ __global__ __launch_bounds__(kThreads) void step_kernel(Params p, FmarlOutputs o
         rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
         // state + small outputs
-        noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0); nac = p.num_agent_coll[g] + ag_hits;
+        const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
         p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
         p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left_new;
         p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
         if (i == 0) p.cur_step[env] = step;
-        if (o.reward) o.reward[g] = (float)rew;
+        if (o.reward && !(p.ablate & 16)) o.reward[g] = (float)rew;
         if (o.done) o.done[g] = step >= p.episode_length;            // environment.py:237-247
-        if (o.obs && !will_reset) {                                    // :845-857
+        if (o.obs && !will_reset && !(p.ablate & 16)) {               // :845-857
             float *ob = o.obs + g * p.D;
             ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;
             ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)fairness;
         }
-        // ego / entity rows of the graph tables (:1084-1099, :1124)
-        float *A = (float *)(base + p.lds_a) + i * p.F;
-        float *B = (float *)(base + p.lds_b) + i * kBWidth;
-        const float fx = (float)x.x, fy = (float)x.y, fvx = (float)v.x, fvy = (float)v.y;
-        A[0] = fvx; A[1] = fvy; A[2] = fx; A[3] = fy; A[4] = (float)goal.x; A[5] = (float)goal.y;
-        A[6] = fx; A[7] = fy; A[8] = fx; A[9] = fy; A[10] = 0.f;
-        B[0] = fvx; B[1] = fvy; B[2] = fx; B[3] = fy; B[4] = 0.f;
+        if (o.info && !(p.ablate & 8)) {
+            // info_callback (:577-647): statistics after this agent's own update (entries <= i fresh).
+            // Field-major records: info[k][env][agent], every store is lane-contiguous.
+            double dm, ds, tm, ts;
+            mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
+            mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
+            const size_t plane = (size_t)p.n_envs * p.N;
+            float *inf = o.info + g;
+            inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left_new;
+            inf[FMARL_INFO_TIME_REQ_TO_GOAL * plane] = (float)Tr_new;
+            inf[FMARL_INFO_NUM_AGENT_COLLISIONS * plane] = (float)nac;
+            inf[FMARL_INFO_NUM_OBST_COLLISIONS * plane] = (float)noc;
+            inf[FMARL_INFO_DISTANCE_MEAN * plane] = (float)dm;
+            inf[FMARL_INFO_DISTANCE_VARIANCE * plane] = (float)ds;
+            inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)(dm / (ds + 0.0001));
+            inf[FMARL_INFO_DISTS_TRAVELED * plane] = (float)Dg_new;
+            inf[FMARL_INFO_TIME_TAKEN * plane] = (float)(step * kDt);
+            inf[FMARL_INFO_TIME_MEAN * plane] = (float)tm;
+            inf[FMARL_INFO_TIME_STDDEV * plane] = (float)ts;
+            inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)(tm / (ts + 0.0001));
+            inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
+            inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
+        }
     }
-    __syncthreads();
-    if (active && o.info) {
-        double dm, ds, tm, ts;
-        mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
-        mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
-        float *inf = o.info + g * FMARL_INFO_WIDTH;
-        inf[FMARL_INFO_DIST_TO_GOAL] = (float)left_new;
-        inf[FMARL_INFO_TIME_REQ_TO_GOAL] = (float)s_stat[4 * p.N + i];
-        inf[FMARL_INFO_NUM_AGENT_COLLISIONS] = (float)nac;
-        inf[FMARL_INFO_NUM_OBST_COLLISIONS] = (float)noc;
-        inf[FMARL_INFO_DISTANCE_MEAN] = (float)dm;
-        inf[FMARL_INFO_DISTANCE_VARIANCE] = (float)ds;
-        inf[FMARL_INFO_MEAN_BY_VARIANCE] = (float)(dm / (ds + 0.0001));
-        inf[FMARL_INFO_DISTS_TRAVELED] = (float)s_stat[2 * p.N + i];
-        inf[FMARL_INFO_TIME_TAKEN] = (float)(step * kDt);
-        inf[FMARL_INFO_TIME_MEAN] = (float)tm;
-        inf[FMARL_INFO_TIME_STDDEV] = (float)ts;
-        inf[FMARL_INFO_TIME_MEAN_BY_STDDEV] = (float)(tm / (ts + 0.0001));
-        inf[FMARL_INFO_MIN_TIME_TO_GOAL] = (float)p.min_time[g];
-        inf[FMARL_INFO_INDIVIDUAL_REWARD] = (float)rew;
-    }
-    fill_static_rows(p, lds, nenv);
-    __syncthreads();
-    emit_graph(p, o, lds, env0, nenv);
+    // emission only reads pos / agentf / wall / flag, all final since the barrier above
+    if (!(p.ablate & 32)) emit_graph(p, o, lds, env0, nenv);
 }
 
 }  // namespace fmarl

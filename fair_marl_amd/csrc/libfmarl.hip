@@ -1,5 +1,6 @@
 // libfmarl.so -- C-ABI (include/fmarl.h) over the gfx950 kernels.  Single translation unit.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -81,6 +82,8 @@ struct Handle {
     int grid;
     bool lockstep;      // all envs share one step counter, known on the host
     int host_step;
+    hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
+    int ev_cap, ev_n;
 };
 
 int align16(int x) { return (x + 15) / 16 * 16; }
@@ -156,17 +159,14 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.world_size = cfg->world_size; p.max_speed = cfg->max_speed; p.collision_rew = cfg->collision_rew;
     p.goal_rew = cfg->goal_rew; p.thr = cfg->min_dist_thresh; p.fair_rew = cfg->fair_rew; p.zeroshift = cfg->zeroshift;
     p.seed = cfg->seed;
-    // node feature column f -> ego column: [vx vy | x y | x y | x y | x y | 0]  (navigation_graph.py:1118-1124)
-    const int sel[11] = {0, 1, 2, 3, 2, 3, 2, 3, 2, 3, 4};
-    for (int f = 0; f < 11; ++f) p.bsel |= (uint64_t)sel[f] << (4 * f);
-    // per-env LDS layout
+    // per-env LDS layout (fmarl_step.hip EnvLds)
     int off = 0;
-    p.lds_pos = off;  off = align16(off + p.E * 16);
-    p.lds_stat = off; off = align16(off + 5 * p.N * 8);
-    p.lds_a = off;    off = align16(off + p.E * p.F * 4);
-    p.lds_b = off;    off = align16(off + p.N * kBWidth * 4);
-    p.lds_wall = off; off = align16(off + p.W * 4 * 8);
-    p.lds_flag = off; off = align16(off + 4);
+    p.lds_pos = off;    off = align16(off + p.E * 16);
+    p.lds_agentf = off; off = align16(off + p.N * 16);
+    p.lds_ego = off;    off = align16(off + p.N * kEgoWidth * 4);
+    p.lds_stat = off;   off = align16(off + 5 * p.N * 8);
+    p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
+    p.lds_flag = off;   off = align16(off + 4);
     p.lds_env_bytes = off;
     int epb = kThreads / p.N;
     const int budget = 48 * 1024;
@@ -175,23 +175,62 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     h->lds_bytes = (size_t)epb * p.lds_env_bytes;
+    if (const char *pad = getenv("FMARL_LDS_PAD")) h->lds_bytes += atoi(pad);   // measurement aid: lower occupancy
     h->grid = (p.n_envs + epb - 1) / epb;
     const uint64_t NEF = (uint64_t)p.N * p.E * p.F, maxq = (uint64_t)epb * NEF;
     if (maxq >= (1ull << 24) || maxq * NEF >= (1ull << 40)) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large"); }
     p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
     p.dLO.set(p.L + p.O > 0 ? p.L + p.O : 1);
+    if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
+    p.vec_node = (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
+    p.vec_adj = p.E % 4 == 0;
+    p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
+    p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
+    p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
+    p.dE4.set(p.vec_adj ? p.E / 4 : 1);
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
     }
     h->lockstep = false; h->host_step = 0;
+    h->ev = nullptr; h->ev_cap = h->ev_n = 0;
     *handle = h;
     return FMARL_OK;
 }
 
+static void drop_events(Handle *h) {
+    for (int i = 0; h->ev && i < 2 * h->ev_cap; ++i) (void)hipEventDestroy(h->ev[i]);
+    delete[] h->ev;
+    h->ev = nullptr; h->ev_cap = h->ev_n = 0;
+}
+
 int fmarl_destroy(void *handle) {
-    delete (Handle *)handle;
+    Handle *h = (Handle *)handle;
+    if (h) drop_events(h);
+    delete h;
+    return FMARL_OK;
+}
+
+int fmarl_profile_enable(void *handle, int capacity) {
+    Handle *h = (Handle *)handle;
+    if (!h || capacity < 0) return fail(FMARL_EINVAL, "fmarl_profile_enable: bad argument");
+    drop_events(h);
+    if (capacity == 0) return FMARL_OK;
+    h->ev = new (std::nothrow) hipEvent_t[2 * (size_t)capacity];
+    if (!h->ev) return fail(FMARL_EINVAL, "fmarl_profile_enable: out of host memory");
+    for (int i = 0; i < 2 * capacity; ++i) HIP_OK(hipEventCreate(&h->ev[i]));
+    h->ev_cap = capacity;
+    return FMARL_OK;
+}
+
+int fmarl_profile_read(void *handle, float *ms, int max_count, int *count) {
+    Handle *h = (Handle *)handle;
+    if (!h || !ms || !count) return fail(FMARL_EINVAL, "fmarl_profile_read: bad argument");
+    int n = h->ev_n < max_count ? h->ev_n : max_count;
+    for (int i = 0; i < n; ++i) HIP_OK(hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    *count = n;
+    h->ev_n = 0;
     return FMARL_OK;
 }
 
@@ -221,8 +260,11 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
         return fail(FMARL_EINVAL, "fmarl_step: pass exactly one of action_idx / action_vec");
     hipStream_t st = (hipStream_t)stream;
     Params p = bind(h, state);
+    const bool prof = h->ev && h->ev_n < h->ev_cap;
+    if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
                        auto_reset ? 1 : 0);
+    if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
     HIP_OK(hipGetLastError());
     if (h->lockstep) ++h->host_step;
     if (auto_reset) {

@@ -18,6 +18,11 @@ from .config import EnvConfig
 _TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32}
 
 
+class OutputSet(object):
+    """obs / reward / done / info tensors of one step + the FmarlOutputs struct pointing at them."""
+    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'c')
+
+
 class RolloutEngine:
     def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True):
         if not isinstance(cfg, EnvConfig):
@@ -37,16 +42,12 @@ class RolloutEngine:
         D, F = cfg.obs_dim, cfg.node_feat
         with torch.cuda.device(self.device):
             self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-            self.obs = torch.zeros(n, N, D, dtype=torch.float32, device=self.device)
             self.node_obs = torch.zeros(n, N, E, F, dtype=torch.float32, device=self.device)
             self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device)
-            self.reward = torch.zeros(n, N, dtype=torch.float32, device=self.device)
-            self.done = torch.zeros(n, N, dtype=torch.uint8, device=self.device)
-            self.info = torch.zeros(n, N, _lib.INFO_WIDTH, dtype=torch.float32, device=self.device) if emit_info else None
             self.agent_id = torch.arange(N, device=self.device).view(1, N, 1).expand(n, N, 1)
-        self.outs = _lib.FmarlOutputs(self.obs.data_ptr(), self.node_obs.data_ptr(), self.adj_env.data_ptr(),
-                                      self.reward.data_ptr(), self.done.data_ptr(),
-                                      self.info.data_ptr() if emit_info else None)
+        self.emit_info = emit_info
+        self.outs = self.new_output_set()
+        self.use_outputs(self.outs)
         self._fields = {}
         shapes = self._field_shapes()
         for fid, name in enumerate(_lib.FIELD_NAMES):
@@ -61,6 +62,33 @@ class RolloutEngine:
             view = self.state[off.value: off.value + cnt.value * esz].view(_TORCH_DT[dt.value])
             self._fields[name] = view.view(shapes[name])
         _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
+
+    def new_output_set(self, obs=None, reward=None, done=None):
+        """A set of per-step output buffers.  node_obs / adj are shared by all sets (large, consumed
+        before the next step); obs / reward / done / info are per set so a set can still be read
+        (e.g. by an in-flight RCCL gather, see sharding.py) while the next step writes another."""
+        n, N, D = self.n_envs, self.cfg.N, self.cfg.obs_dim
+        with torch.cuda.device(self.device):
+            mk = lambda t, shape, dt: t if t is not None else torch.zeros(shape, dtype=dt, device=self.device)
+            o = OutputSet()
+            o.obs = mk(obs, (n, N, D), torch.float32)
+            o.reward = mk(reward, (n, N), torch.float32)
+            o.done = mk(done, (n, N), torch.uint8)
+            # field-major planes on the device (coalesced stores); exposed as an (n, N, K) view
+            o.info_planes = torch.zeros(_lib.INFO_WIDTH, n, N, dtype=torch.float32, device=self.device) if self.emit_info else None
+            o.info = o.info_planes.permute(1, 2, 0) if self.emit_info else None
+        for t, shape, dt in ((o.obs, (n, N, D), torch.float32), (o.reward, (n, N), torch.float32), (o.done, (n, N), torch.uint8)):
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError('output buffer must be a contiguous %s tensor of shape %s on %s' % (dt, shape, self.device))
+        o.c = _lib.FmarlOutputs(o.obs.data_ptr(), self.node_obs.data_ptr(), self.adj_env.data_ptr(),
+                                o.reward.data_ptr(), o.done.data_ptr(),
+                                o.info_planes.data_ptr() if o.info_planes is not None else None)
+        return o
+
+    def use_outputs(self, out_set):
+        """Select the output set the next reset / step calls write into."""
+        self.outs = out_set
+        self.obs, self.reward, self.done, self.info = out_set.obs, out_set.reward, out_set.done, out_set.info
 
     def _field_shapes(self):
         n, c = self.n_envs, self.cfg
@@ -104,7 +132,7 @@ class RolloutEngine:
             env_mask = torch.as_tensor(env_mask).to(device=self.device, dtype=torch.uint8).contiguous()
             mask_ptr = env_mask.data_ptr()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fmarl_reset(self.handle, self.state.data_ptr(), mask_ptr, C.byref(self.outs),
+            _lib.check(self.lib.fmarl_reset(self.handle, self.state.data_ptr(), mask_ptr, C.byref(self.outs.c),
                                             self._stream()), 'fmarl_reset')
         return self.obs, self.agent_id, self.node_obs, self.adj
 
@@ -127,7 +155,7 @@ class RolloutEngine:
             vec_ptr = a.data_ptr()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fmarl_step(self.handle, self.state.data_ptr(), idx_ptr, vec_ptr,
-                                           C.byref(self.outs), 1 if auto_reset else 0, self._stream()), 'fmarl_step')
+                                           C.byref(self.outs.c), 1 if auto_reset else 0, self._stream()), 'fmarl_step')
         self._last_actions = a  # keep alive until the stream has consumed it
         return self.obs, self.agent_id, self.node_obs, self.adj, self.reward, self.done, self.info
 
@@ -163,6 +191,19 @@ class RolloutEngine:
             _lib.check(self.lib.fmarl_update_graph(adj.data_ptr(), ei.data_ptr(), ew.data_ptr(), nnz.data_ptr(), n, E,
                                                    float(self.cfg.max_edge_dist), self._stream()), 'fmarl_update_graph')
         return ei, ew, nnz
+
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, capacity):
+        """Record a hipEvent pair around each of the next ``capacity`` step-kernel launches (0 = off)."""
+        _lib.check(self.lib.fmarl_profile_enable(self.handle, int(capacity)), 'fmarl_profile_enable')
+        self._prof_cap = int(capacity)
+
+    def profile_read(self):
+        """Per-launch step-kernel durations [ms] since profile_enable / the last read (stream must be idle)."""
+        buf = (C.c_float * max(self._prof_cap, 1))()
+        cnt = C.c_int()
+        _lib.check(self.lib.fmarl_profile_read(self.handle, buf, self._prof_cap, C.byref(cnt)), 'fmarl_profile_read')
+        return [buf[i] for i in range(cnt.value)]
 
     def close(self):
         if getattr(self, 'handle', None) is not None and self.handle.value:

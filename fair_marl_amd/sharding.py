@@ -1,0 +1,96 @@
+"""Sharding of the rollout over the GPUs of one node and the per-step trajectory exchange.
+
+The reference has exactly one kind of parallelism: ``n_rollout_threads`` independent env
+processes (reference onpolicy/envs/env_wrappers.py:951-1026).  Environments never interact, so
+here each rank (one process per GPU) owns a contiguous range of env indices and runs them with
+its own ``RolloutEngine``; the Philox streams are keyed by the GLOBAL env index
+(``FmarlConfig.env_offset``), so results do not depend on the number of GPUs.
+
+The only exchange step is the one the reference does through its worker pipes
+(env_wrappers.py:988-996): handing the per-step trajectory record to the learner.  Here that is
+one ``gather`` per step to the learner rank over RCCL (backend "nccl" on ROCm; xGMI links are
+point to point, so each peer's shard moves over its own link).  The record is the compact part
+of the step output -- obs (which already carries every agent's velocity, position and goal
+offset), reward and done: 33 bytes per agent-step.  node_obs / adj are recomputable from it and
+are not sent.  Records are double-buffered: the gather of step t runs on RCCL's stream while
+the kernels of step t+1 write the other buffer.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total, world_size, rank):
+    """Contiguous env range [lo, hi) of ``rank``; the first ``n_total % world_size`` ranks get one more."""
+    base, rem = divmod(int(n_total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class StepRecord(object):
+    """One flat byte buffer laid out as [obs f32 (n,N,D) | reward f32 (n,N) | done u8 (n,N) | pad]."""
+
+    def __init__(self, n_envs, num_agents, obs_dim, device):
+        self.shape = (int(n_envs), int(num_agents), int(obs_dim))
+        n, N, D = self.shape
+        self.obs_bytes, self.rew_bytes, self.done_bytes = n * N * D * 4, n * N * 4, n * N
+        total = (self.obs_bytes + self.rew_bytes + self.done_bytes + 15) // 16 * 16
+        self.flat = torch.zeros(total, dtype=torch.uint8, device=device)
+        self.obs, self.reward, self.done = self.views(self.flat)
+
+    def views(self, flat):
+        n, N, D = self.shape
+        a, b = self.obs_bytes, self.obs_bytes + self.rew_bytes
+        return (flat[:a].view(torch.float32).view(n, N, D), flat[a:b].view(torch.float32).view(n, N),
+                flat[b:b + self.done_bytes].view(n, N))
+
+    @staticmethod
+    def bytes_per_agent_step(obs_dim):
+        return obs_dim * 4 + 4 + 1
+
+
+class TrajectoryGather(object):
+    """Double-buffered asynchronous gather of StepRecords to the learner rank.
+
+    Usage per step t:  rec = tg.record(t)  ->  engine writes rec.obs / rec.reward / rec.done  ->
+    tg.submit(t).  ``record(t)`` first waits for the gather that last used the same buffer
+    (step t - depth).  ``finish()`` waits for everything in flight.
+    All ranks must use the same n_envs per rank (equal shards) -- gather needs equal sizes.
+    """
+
+    def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2):
+        self.group, self.dst, self.depth = group, dst, depth
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.records = [StepRecord(n_envs, num_agents, obs_dim, device) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.recv = None
+        if self.world > 1 and self.rank == dst:
+            self.recv = [[torch.zeros_like(r.flat) for _ in range(self.world)] for r in self.records]
+
+    def record(self, t):
+        k = t % self.depth
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        return self.records[k]
+
+    def submit(self, t):
+        if self.world == 1:
+            return
+        k = t % self.depth
+        self.pending[k] = dist.gather(self.records[k].flat, self.recv[k] if self.rank == self.dst else None,
+                                      dst=self.dst, group=self.group, async_op=True)
+
+    def finish(self):
+        for k in range(self.depth):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def gathered(self, t):
+        """On the learner rank: list over ranks of (obs, reward, done) views of step t (after wait)."""
+        k = t % self.depth
+        if self.world == 1:
+            r = self.records[k]
+            return [(r.obs, r.reward, r.done)]
+        return [self.records[k].views(f) for f in self.recv[k]]

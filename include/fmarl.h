@@ -60,8 +60,8 @@ typedef struct FmarlConfig {
 /* Output buffers of one step / reset, all caller-owned device memory, float32 unless noted.
  * Shapes follow onpolicy/envs/env_wrappers.py:988-1002 with two differences that the Python
  * layer undoes in its NumPy-compat mode: adj is stored once per env (the reference returns
- * the same E x E matrix N times, navigation_graph.py:1033) and infos are a dense record
- * array instead of per-agent dicts (navigation_graph.py:625-647).  Any pointer may be NULL
+  * the same E x E matrix N times, navigation_graph.py:1033) and infos are dense field-major
+ * record planes instead of per-agent dicts (navigation_graph.py:625-647).  Any pointer may be NULL
  * to skip that output. */
 typedef struct FmarlOutputs {
     float *obs;          /* (n, N, D)        D = 7 navigation_graph / 6 formation            */
@@ -69,7 +69,7 @@ typedef struct FmarlOutputs {
     float *adj;          /* (n, E, E)        cached_dist_mag, multiagent/core.py:204-228      */
     float *reward;       /* (n, N)                                                            */
     uint8_t *done;       /* (n, N)           environment.py:237-247                           */
-    float *info;         /* (n, N, FMARL_INFO_WIDTH) in FMARL_INFO_* order                    */
+    float *info;         /* (FMARL_INFO_WIDTH, n, N) field-major records, FMARL_INFO_* order   */
 } FmarlOutputs;
 
 #define FMARL_INFO_WIDTH 14
@@ -156,6 +156,13 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
 /* Tell the handle the caller wrote into the state buffer (parity harness set_state): drops the
  * host-side "all envs share one step counter" shortcut used to skip the auto-reset launch. */
 int fmarl_state_changed(void *handle);
+
+/* Measurement hook (bench.py): record a hipEvent pair around every step-kernel launch of this
+ * handle, on the launch stream.  enable(capacity) (re)starts recording into `capacity` pairs
+ * (0 = off); read() returns the per-launch durations [ms] recorded since then -- the caller
+ * must have synchronised the stream -- and restarts. */
+int fmarl_profile_enable(void *handle, int capacity);
+int fmarl_profile_read(void *handle, float *ms, int max_count, int *count);
 
 /* --- pieces exported on their own -------------------------------------------------------- */
 
