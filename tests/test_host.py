@@ -1,0 +1,158 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol declared in
+include/fmarl.h, state-layout queries (host code only), spaces / specs / lazy infos, sharding and the
+trajectory gather over gloo with world_size 2.  No kernel is launched."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as graft  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def lib():
+    graft.build()
+    from fair_marl_amd import _lib
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'fmarl.h')).read()
+    declared = set(re.findall(r'\b(fmarl_[a-z_]+)\s*\(', hdr))
+    from fair_marl_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+
+
+def test_state_layout_and_config_validation(lib):
+    import fair_marl_amd as fm
+    from fair_marl_amd import _lib
+    cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
+    c = cfg.to_c(65536, seed=3, env_offset=65536)
+    total = lib.fmarl_state_bytes(C.byref(c))
+    prev_end = 0
+    for fid, name in enumerate(_lib.FIELD_NAMES):
+        off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int()
+        assert lib.fmarl_state_field(C.byref(c), fid, C.byref(off), C.byref(cnt), C.byref(dt)) == 0
+        assert off.value % 256 == 0 and off.value >= prev_end
+        prev_end = off.value + cnt.value * (8 if dt.value == _lib.DTYPE_F64 else 4)
+    assert prev_end <= total
+    off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int()
+    lib.fmarl_state_field(C.byref(c), _lib.F_AGENT_POS, C.byref(off), C.byref(cnt), C.byref(dt))
+    assert cnt.value == 65536 * 32 * 2 and dt.value == _lib.DTYPE_F64
+    assert lib.fmarl_state_field(C.byref(c), 99, None, None, None) != 0
+    # invalid configs are refused with a message, not a crash
+    bad = fm.EnvConfig(num_agents=3, num_landmarks=4).to_c(8)
+    h = C.c_void_p()
+    assert lib.fmarl_create(C.byref(bad), C.byref(h)) != 0
+    assert b'num_landmarks' in lib.fmarl_last_error()
+    assert lib.fmarl_state_bytes(C.byref(bad)) == 0
+    ok = C.c_void_p()
+    assert lib.fmarl_create(C.byref(c), C.byref(ok)) == 0 and ok.value
+    assert lib.fmarl_destroy(ok) == 0
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import fair_marl_amd as fm
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        fm.RolloutEngine(fm.EnvConfig(num_agents=3, num_landmarks=3), 8)
+
+
+def test_specs_spaces_and_unsupported_scenarios():
+    import argparse
+    import fair_marl_amd as fm
+    args = argparse.Namespace(scenario_name='navigation_graph', num_agents=32, num_landmarks=32, num_obstacles=8,
+                              num_walls=0, episode_length=25)
+    spec = fm.GraphMPEEnv(args)
+    spec.seed(1 + 3 * 1000)
+    assert spec.seed_value == 3001 and spec.n == 32
+    assert spec.observation_space[0].shape == (7,) and spec.observation_space[0].__class__.__name__ == 'Box'
+    assert spec.share_observation_space[0].shape == (224,)
+    assert spec.node_observation_space[0].shape == (72, 11) and spec.adj_observation_space[0].shape == (72, 72)
+    assert spec.action_space[0].__class__.__name__ == 'Discrete' and spec.action_space[0].n == 5
+    args.scenario_name = 'simple_spread_graph'
+    with pytest.raises(NotImplementedError):
+        fm.GraphMPEEnv(args)
+    args.scenario_name = 'navigation_graph'
+    args.collaborative = True
+    with pytest.raises(NotImplementedError):
+        fm.GraphMPEEnv(args)
+
+
+def test_lazy_infos_match_reference_structure():
+    from fair_marl_amd.infos import INFO_KEYS, LazyInfos
+    rec = np.arange(2 * 3 * 14, dtype=np.float64).reshape(2, 3, 14)
+    infos = LazyInfos(rec)
+    assert len(infos) == 2 and len(infos[1]) == 3
+    d = infos[1][2]
+    assert list(d)[0] == 'individual_reward' and set(d) == set(INFO_KEYS)
+    assert d['Dist_to_goal'] == rec[1, 2, 0] and d['individual_reward'] == rec[1, 2, 13]
+    assert [len(e) for e in infos] == [3, 3]
+    assert [a['Time_taken'] for a in infos[0]] == list(rec[0, :, 8])
+
+
+def test_shard_range_partitions_exactly():
+    from fair_marl_amd.sharding import shard_range
+    for n, w in ((524288, 8), (10, 3), (7, 8), (65536, 1)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from fair_marl_amd.sharding import TrajectoryGather, shard_range
+    n_total, N, D, T = 12, 3, 7, 5
+    lo, hi = shard_range(n_total, world, rank)
+    tg = TrajectoryGather(hi - lo, N, D, 'cpu', dst=0, depth=2)
+    ok = True
+    for t in range(T):
+        rec = tg.record(t)                       # waits for the gather that used this buffer (t - 2)
+        env = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
+        rec.obs.copy_((env * 100 + t).expand(hi - lo, N, D))
+        rec.reward.copy_((env[:, :, 0] + 0.5 * t).expand(hi - lo, N))
+        rec.done.fill_(t % 2)
+        tg.submit(t)
+        if t >= 1:                               # consume step t-1 on the learner rank while t is in flight
+            tg.pending[(t - 1) % 2] and tg.pending[(t - 1) % 2].wait()
+            if rank == 0:
+                for r, (obs, rew, done) in enumerate(tg.gathered(t - 1)):
+                    l2, h2 = shard_range(n_total, world, r)
+                    e = torch.arange(l2, h2, dtype=torch.float32)
+                    ok &= bool((obs[:, 0, 0] == e * 100 + (t - 1)).all()) and bool((rew[:, 1] == e + 0.5 * (t - 1)).all())
+                    ok &= bool((done == (t - 1) % 2).all()) and obs.shape == (h2 - l2, N, D)
+    tg.finish()
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trajectory_gather_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok

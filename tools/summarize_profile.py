@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Summarise gpurun_out/<tag>/ (written by tools/profile.sh on the GPU box) into profiles/:
+  profiles/<tag>_<cfg>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_<cfg>_summary.md         bench line + per-kernel table + HBM traffic from the PMC passes
+  profiles/pmc_traffic.json               per-config HBM bytes per step_kernel launch (read by bench.py)
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
+are collected in separate --pmc passes, are in KiB, and FETCH_SIZE is doubled on gfx950 (it counts
+128-byte requests at 64 bytes)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, cfg = (sys.argv + ['r1', 'cfg3'])[1:3]
+src = os.path.join(ROOT, 'gpurun_out', tag)
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    return sorted(glob.glob(os.path.join(src, pattern)))[0]
+
+
+def counter_mean(path, kernel, counter):
+    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
+            if kernel in r['Kernel_Name'] and r['Counter_Name'] == counter]
+    return float(np.mean(vals)), float(np.max(vals)), len(vals)
+
+
+stats = one('trace/*/*kernel_stats.csv')
+shutil.copy(stats, os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, cfg)))
+bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), 'step_kernel', 'FETCH_SIZE')
+w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), 'step_kernel', 'WRITE_SIZE')
+traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
+traffic_full = (2.0 * f_max + w_max) * 1024.0
+tpath = os.path.join(dst, 'pmc_traffic.json')
+allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
+allt[cfg] = dict(hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
+                 write_kib_mean=w_mean, launches=nf, source='%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+                 '(separate passes), step_kernel rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % tag)
+json.dump(allt, open(tpath, 'w'), indent=1, sort_keys=True)
+
+rows = list(csv.DictReader(open(stats)))
+out = os.path.join(dst, '%s_%s_summary.md' % (tag, cfg))
+with open(out, 'w') as f:
+    f.write('# %s %s: bench line, kernel trace, HBM counters\n\n' % (tag, cfg))
+    f.write('Commands (tools/profile.sh, on the MI355X box): `python bench.py --config %s` (bench line); '
+            '`rocprofv3 --kernel-trace --stats -- python3 bench.py --config %s --steps 200 --warmup 50 --no-cpu-baseline` '
+            '(kernel table); `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` in separate passes over '
+            '`python3 bench.py --config %s --steps 30 --warmup 25 --no-cpu-baseline` (traffic).\n\n' % (cfg, cfg, cfg))
+    f.write('## bench.py JSON line\n\n```json\n%s\n```\n\n' % json.dumps(bench, indent=1))
+    f.write('## rocprofv3 kernel stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n')
+    for r in rows[:8]:
+        f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'].split('(')[0][:60], r['Calls'], float(r['AverageNs']) / 1e3,
+                                                       float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+    rl = bench['roofline']
+    f.write('\nstep_kernel average: rocprofv3 %.1f us over %s launches vs %.1f us measured live by bench.py with hipEvents '
+            '(%d launches).\n' % (float(rows[0]['AverageNs']) / 1e3, rows[0]['Calls'], rl['kernel_avg_ms'] * 1e3, rl['kernel_launches']))
+    f.write('\n## HBM traffic of step_kernel (PMC)\n\n')
+    f.write('| counter | mean KiB / launch | max KiB / launch | launches |\n|---|---|---|---|\n')
+    f.write('| FETCH_SIZE | %.0f | %.0f | %d |\n| WRITE_SIZE | %.0f | %.0f | %d |\n\n' % (f_mean, f_max, nf, w_mean, w_max, nw))
+    f.write('HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = **%.3f GB** mean (%.3f GB for a full, '
+            'non-episode-end launch) against %.3f GB algorithmic per launch -> ratio %.3f.\n'
+            % (traffic_mean / 1e9, traffic_full / 1e9, rl['algorithmic_bytes_per_launch'] / 1e9,
+               traffic_mean / rl['algorithmic_bytes_per_launch']))
+print(open(out).read())
