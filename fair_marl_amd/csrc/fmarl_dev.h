@@ -20,7 +20,7 @@ constexpr double kSensitivity = 5.0;
 constexpr int kThreads = 256;       // workgroup size of the step / emit kernels (4 waves)
 constexpr int kMaxTries = 10000;    // bound on the reference's unbounded rejection loops
 constexpr int kEgoWidth = 5;         // LDS ego row: vx, vy, x, y, 0
-constexpr int kStepWavesPerSimd = 5; // register budget of step_kernel: 5 waves/SIMD = 5 workgroups of 256 per CU
+constexpr int kStepWavesPerSimd = 4; // register budget of step_kernel (128 VGPRs); measured best of 3..6 on MI355X
 
 // floor(q / d) for q * d < 2^40, q < 2^24 (block-local flat indices): one 64-bit multiply.
 struct FastDiv {

@@ -12,7 +12,7 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
 
 // fmarl_reset.hip
 enum ResetMode { kResetAll = 0, kResetMask = 1, kResetAuto = 2, kResetInit = 3 };
-__global__ void reset_place_kernel(Params p, int mode, const uint8_t *mask);
+template <bool LDS> __global__ void reset_place_kernel(Params p, int mode, const uint8_t *mask);
 __global__ void reset_emit_kernel(Params p, FmarlOutputs o);
 __global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal_pos, double *costs,
                                    int n_envs, int N, int L);

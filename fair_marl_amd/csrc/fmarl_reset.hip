@@ -16,18 +16,62 @@
 
 namespace fmarl {
 
-// navigation_graph.py:650-684 is_obstacle_collision(pos, size = 0.05)
-__device__ bool obstacle_hit_global(const Params &p, int env, double2 x) {
-    for (int k = 0; k < p.O; ++k)
-        if (dist2(p.obstacle_pos[(size_t)env * p.O + k], x) < 1.05 * (kEntitySize + kEntitySize)) return true;
-    for (int w = 0; w < p.W; ++w) {
-        size_t g = (size_t)env * p.W + w;
-        if (wall_box_hit(x, p.wall_axis[g], p.wall_e0[g], p.wall_e1[g], p.wall_orient[g])) return true;
+// Positions placed so far by one lane (= one env).  The rejection tests walk them sequentially; from
+// global memory every test is a dependent ~1 us load, so an f32 copy is kept in LDS, slot-major
+// [slot][lane] (8 B per lane, conflict-free).  A test is decided on the f32 copy unless the distance is
+// within 1e-6 of the threshold, in which case the f64 value is re-read from global memory (exact result).
+template <bool LDS>
+struct Placed {
+    float2 *lds;      // [slots][64]
+    const Params &p;
+    int env, lane;
+    __device__ double2 g_obstacle(int k) const { return p.obstacle_pos[(size_t)env * p.O + k]; }
+    __device__ double2 g_agent(int k) const { return p.agent_pos[(size_t)env * p.N + k]; }
+    __device__ double2 g_landmark(int k) const { return p.landmark_pos[(size_t)env * p.L + k]; }
+    __device__ void put(int slot, double2 x) { if (LDS) lds[slot * 64 + lane] = make_float2((float)x.x, (float)x.y); }
+    __device__ void set_obstacle(int k, double2 x) { put(k, x); p.obstacle_pos[(size_t)env * p.O + k] = x; }
+    __device__ void set_agent(int k, double2 x) { put(p.O + k, x); p.agent_pos[(size_t)env * p.N + k] = x; }
+    __device__ void set_landmark(int k, double2 x) { put(p.O + p.N + k, x); p.landmark_pos[(size_t)env * p.L + k] = x; }
+    // 0 = farther than thr, 1 = closer, 2 = too close to call in f32
+    __device__ int coarse(int slot, float2 xf, float thr) const {
+        const float2 q = lds[slot * 64 + lane];
+        const float dx = q.x - xf.x, dy = q.y - xf.y, s = dx * dx + dy * dy;
+        const float lo = (thr - 1e-6f) * (thr - 1e-6f), hi = (thr + 1e-6f) * (thr + 1e-6f);
+        return s < lo ? 1 : (s > hi ? 0 : 2);
     }
-    return false;
+    // any of the first k slots starting at `first` closer than thr to x (kind: 0 obstacle, 1 agent, 2 landmark)
+    __device__ bool any_closer(int kind, int k, double2 x, double thr) const {
+        bool hit = false;
+        if (LDS) {
+            const int first = kind == 0 ? 0 : (kind == 1 ? p.O : p.O + p.N);
+            const float2 xf = make_float2((float)x.x, (float)x.y);
+            bool unsure = false;
+            for (int j = 0; j < k; ++j) {
+                const int c = coarse(first + j, xf, (float)thr);
+                hit |= c == 1;
+                unsure |= c == 2;
+            }
+            if (!unsure) return hit;
+            hit = false;
+        }
+        for (int j = 0; j < k; ++j)
+            hit |= closer_than(kind == 0 ? g_obstacle(j) : (kind == 1 ? g_agent(j) : g_landmark(j)), x, thr);
+        return hit;
+    }
+};
+
+// navigation_graph.py:650-684 is_obstacle_collision(pos, size = 0.05)
+template <bool LDS>
+__device__ bool obstacle_hit(const Params &p, const Placed<LDS> &pl, const double *wall, double2 x) {
+    bool hit = pl.any_closer(0, p.O, x, 1.05 * (kEntitySize + kEntitySize));
+    for (int w = 0; w < p.W; ++w)
+        hit |= wall_box_hit(x, wall[w * 4], wall[w * 4 + 1], wall[w * 4 + 2], (int)wall[w * 4 + 3]);
+    return hit;
 }
 
+template <bool LDS>
 __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, const uint8_t *mask) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.n_envs) return;
     bool doit = true;
@@ -38,6 +82,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
 
     const int N = p.N, L = p.L;
     const size_t a0 = (size_t)env * N;
+    Placed<LDS> pl{(float2 *)lds_raw, p, env, (int)threadIdx.x};
     int episode = 0;
     if (mode == kResetInit) {
         for (int i = 0; i < N; ++i) { p.goal_match[a0 + i] = i; p.min_time[a0 + i] = __builtin_huge_val(); }
@@ -56,38 +101,40 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     p.cur_step[env] = 0;
     for (int k = 0; k < p.O; ++k) {   // :271-275
         double2 u = rng.uniform_pair(-ws / 2, ws / 2);
-        p.obstacle_pos[(size_t)env * p.O + k] = make_double2(0.8 * u.x, 0.8 * u.y);
+        pl.set_obstacle(k, make_double2(0.8 * u.x, 0.8 * u.y));
     }
     const double wall_position = rng.uniform(0.2, 0.9);   // :288, drawn even without walls
+    double wall[2 * 4] = {0, 0, 0, 0, 0, 0, 0, 0};   // W <= 2 (axis, e0, e1, orient)
     for (int w = 0; w < p.W; ++w) {   // :294-324
         size_t g = (size_t)env * p.W + w;
-        p.wall_orient[g] = rng.choice_hv();
-        p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen;
-        p.wall_axis[g] = (w == 0 ? wall_position : -wall_position) * ws / 2;
+        const int orient = rng.choice_hv();
+        const double axis = (w == 0 ? wall_position : -wall_position) * ws / 2;
+        p.wall_orient[g] = orient; p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; p.wall_axis[g] = axis;
+        if (w == 0) { wall[0] = axis; wall[1] = -wlen; wall[2] = wlen; wall[3] = orient; }
+        else { wall[4] = axis; wall[5] = -wlen; wall[6] = wlen; wall[7] = orient; }
     }
     const double thr = 1.05 * (kEntitySize + kEntitySize);
     for (int k = 0, tries = 0; k < N;) {   // :389-457
         double2 x = rng.uniform_pair(-ws / 2, ws / 2);
         ++tries;
-        bool bad = obstacle_hit_global(p, env, x);
-        for (int j = 0; j < k && !bad; ++j) bad = dist2(p.agent_pos[a0 + j], x) < thr;   // :689-698
+        bool bad = obstacle_hit(p, pl, wall, x);
+        bad |= pl.any_closer(1, k, x, thr);   // :689-698
         if (!bad || tries >= kMaxTries) {
-            p.agent_pos[a0 + k] = x; p.agent_vel[a0 + k] = make_double2(0.0, 0.0);
+            pl.set_agent(k, x); p.agent_vel[a0 + k] = make_double2(0.0, 0.0);
             ++k; tries = 0;
         }
     }
-    const size_t l0 = (size_t)env * L;
     for (int k = 0, tries = 0; k < L;) {   // :472-535
         double2 u = rng.uniform_pair(-ws / 2, ws / 2);
         double2 x = make_double2(0.8 * u.x, 0.8 * u.y);
         ++tries;
-        bool bad = obstacle_hit_global(p, env, x);
-        for (int j = 0; j < k && !bad; ++j) bad = dist2(p.landmark_pos[l0 + j], x) < thr;   // :707-716
-        if (!bad || tries >= kMaxTries) { p.landmark_pos[l0 + k] = x; ++k; tries = 0; }
+        bool bad = obstacle_hit(p, pl, wall, x);
+        bad |= pl.any_closer(2, k, x, thr);   // :707-716
+        if (!bad || tries >= kMaxTries) { pl.set_landmark(k, x); ++k; tries = 0; }
     }
     if (p.has_max_speed)   // :545-547, :719-728 -- previous episode's goal_match_index
         for (int i = 0; i < N; ++i)
-            p.min_time[a0 + i] = dist2(p.agent_pos[a0 + i], p.landmark_pos[l0 + p.goal_match[a0 + i]]) / p.max_speed;
+            p.min_time[a0 + i] = dist2(pl.g_agent(i), pl.g_landmark(p.goal_match[a0 + i])) / p.max_speed;
     p.episode[env] = episode + 1;
 }
 

@@ -82,6 +82,7 @@ struct Handle {
     int grid;
     bool lockstep;      // all envs share one step counter, known on the host
     int host_step;
+    size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int ev_cap, ev_n;
 };
@@ -108,7 +109,10 @@ Params bind(const Handle *h, void *state) {
 int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const FmarlOutputs *outs, hipStream_t st) {
     Params p = bind(h, state);
     const int blocks = (p.n_envs + 63) / 64;
-    hipLaunchKernelGGL(reset_place_kernel, dim3(blocks), dim3(64), 0, st, p, mode, mask);
+    if (h->place_lds)
+        hipLaunchKernelGGL(reset_place_kernel<true>, dim3(blocks), dim3(64), h->place_lds, st, p, mode, mask);
+    else
+        hipLaunchKernelGGL(reset_place_kernel<false>, dim3(blocks), dim3(64), 0, st, p, mode, mask);
     launch_lexifair_state(p, st);
     if (outs && (outs->obs || outs->node_obs || outs->adj))
         hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
@@ -193,6 +197,12 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
     }
+    h->place_lds = (size_t)(p.O + p.N + p.L) * 64 * sizeof(float2);
+    if (h->place_lds > 150 * 1024) h->place_lds = 0;
+    if (h->place_lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)reset_place_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)h->place_lds) != hipSuccess)
+        h->place_lds = 0;
     h->lockstep = false; h->host_step = 0;
     h->ev = nullptr; h->ev_cap = h->ev_n = 0;
     *handle = h;
