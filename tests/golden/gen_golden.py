@@ -14,6 +14,8 @@ Fixture families
                        after a seeded reference reset (or a crafted one), an action tape, and
                        per-step obs / node_obs / adj / reward / done / info + the final state.
   kat_world.npz        single World.step() known answers (SURVEY.md App. B KAT 1-5).
+  form_<case>.npz      the same for fair_graph_formation (BASELINE config 4), form_dummy4.npz its
+                       GraphDummyVecEnv x 4 run incl. auto-resets.
 """
 import json
 import os
@@ -27,17 +29,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import refharness as rh  # noqa: E402
 from oracle.nav_oracle import INFO_KEYS, State  # noqa: E402
+from oracle import formation_oracle as fo  # noqa: E402
 
 rh.install_stubs()
 
 STATE_FIELDS = State.FIELDS
 
 
-def stack_states(states):
-    return {k: np.stack([np.asarray(s[k]) for s in states]) for k in STATE_FIELDS}
+def stack_states(states, fields=STATE_FIELDS):
+    return {k: np.stack([np.asarray(s[k]) for s in states]) for k in fields}
 
 
-def run_traj(args, states_or_seeds, actions, crafted=None):
+def run_traj(args, states_or_seeds, actions, crafted=None, info_keys=INFO_KEYS, fields=STATE_FIELDS):
     """actions: (T, n, N) int or (T, n, N, 5) float.  Returns dict of arrays."""
     n = len(states_or_seeds)
     T = actions.shape[0]
@@ -67,15 +70,15 @@ def run_traj(args, states_or_seeds, actions, crafted=None):
             assert [int(i[0]) for i in ids] == list(range(len(ids)))
             rows['obs'].append(np.array(obs)); rows['node_obs'].append(np.array(node))
             rows['adj'].append(np.array(adj[0])); rows['reward'].append(np.array(rew, dtype=np.float64))
-            rows['done'].append(np.array(done)); rows['info'].append(rh.info_array(info, INFO_KEYS))
+            rows['done'].append(np.array(done)); rows['info'].append(rh.info_array(info, info_keys))
         for k in out:
             out[k].append(np.stack(rows[k]))
     res = {k: np.stack(v) for k, v in out.items()}
-    res.update({'init_' + k: v for k, v in stack_states(init).items()})
-    res.update({'final_' + k: v for k, v in stack_states([rh.capture_state(e) for e in envs]).items()})
+    res.update({'init_' + k: v for k, v in stack_states(init, fields).items()})
+    res.update({'final_' + k: v for k, v in stack_states([rh.capture_state(e) for e in envs], fields).items()})
     res['actions'] = actions
     res['args'] = np.array(json.dumps(vars(args)))
-    res['info_keys'] = np.array(INFO_KEYS)
+    res['info_keys'] = np.array(info_keys)
     return res
 
 
@@ -124,6 +127,61 @@ def gen_traj():
     actions = rs.randint(0, 5, size=(15, 2, 3)).astype(np.int64)
     actions[:3, 0, 0] = 0
     save('traj_crafted.npz', run_traj(args, [c0, c1], actions, crafted=True))
+
+
+def gen_formation():
+    """fair_graph_formation (BASELINE config 4 shapes: N=10, L=1, O=3, W=2 -> E=16) + edge cases."""
+    rs = np.random.RandomState(77)
+    kw = dict(info_keys=fo.INFO_KEYS, fields=fo.State.FIELDS)
+    cases = [  # name, N, L, O, thr, n_envs, T
+        ('n3', 3, 1, 3, 0.05, 3, 25), ('n10', 10, 1, 3, 0.05, 2, 25), ('n5l3', 5, 3, 2, 0.05, 2, 12),
+        ('n4_thr04', 4, 1, 2, 0.4, 3, 20), ('n3_thr07', 3, 1, 1, 0.7, 3, 20), ('n1', 1, 1, 0, 0.05, 2, 8)]
+    for name, N, L, O, thr, n, T in cases:
+        args = rh.make_args(scenario_name='fair_graph_formation', num_agents=N, num_landmarks=L, num_obstacles=O,
+                            min_dist_thresh=thr)
+        actions = rs.randint(0, 5, size=(T, n, N)).astype(np.int64)
+        save('form_%s.npz' % name, run_traj(args, [41 + 3 * e for e in range(n)], actions, **kw))
+    # agents parked on the circle (arrival / formation_complete / occupied slots) and near the walls
+    args = rh.make_args(scenario_name='fair_graph_formation', num_agents=4, num_landmarks=1, num_obstacles=1)
+    ang = np.array([0.3, 0.3 + np.pi / 2, 0.3 + np.pi, 4.0])
+    ring = 0.5 * np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    c0 = dict(agent_pos=ring + np.array([0.1, -0.05]), agent_vel=np.zeros((4, 2)), landmark_pos=np.array([[0.1, -0.05]]),
+              obstacle_pos=np.array([[0.9, 0.9]]))
+    c1 = dict(agent_pos=np.array([[0.52, 0.1], [-0.47, -0.2], [0.0, 0.49], [0.3, 0.3]]),
+              agent_vel=np.array([[0.4, 0.0], [0.0, 0.3], [-0.2, 0.1], [0.0, 0.0]]), landmark_pos=np.array([[0.0, 0.0]]),
+              obstacle_pos=np.array([[0.33, 0.31]]), wall_axis=np.array([0.5, -0.5]), wall_e0=np.array([-0.3, -0.3]),
+              wall_e1=np.array([0.3, 0.3]))
+    actions = rs.randint(0, 5, size=(12, 2, 4)).astype(np.int64)
+    actions[:4, 0] = 0
+    save('form_crafted.npz', run_traj(args, [c0, c1], actions, crafted=True, **kw))
+    # the reference's GraphDummyVecEnv x 4 incl. auto-resets on the NumPy global stream
+    from onpolicy.envs.env_wrappers import GraphDummyVecEnv
+    from multiagent.MPE_env import GraphMPEEnv
+    n, N, seed, T = 4, 3, 2, 55
+    args = rh.make_args(scenario_name='fair_graph_formation', num_agents=N, num_landmarks=1, num_obstacles=2)
+
+    def fn(r):
+        def init():
+            env = GraphMPEEnv(args)
+            env.seed(seed + r * 1000)
+            return env
+        return init
+    acts = np.eye(5)[rs.randint(0, 5, size=(T, n, N))]
+    np.random.seed(seed)
+    venv = GraphDummyVecEnv([fn(r) for r in range(n)])
+    r0 = venv.reset()
+    d = dict(reset_obs=r0[0], reset_id=r0[1], reset_node_obs=r0[2], reset_adj=r0[3][:, 0], actions=acts,
+             args=np.array(json.dumps(vars(args))), seed=np.int64(seed), info_keys=np.array(fo.INFO_KEYS))
+    keys = ('obs', 'agent_id', 'node_obs', 'adj', 'reward', 'done')
+    rec = {k: [] for k in keys + ('info', 'reset_count')}
+    for t in range(T):
+        res = venv.step(acts[t])
+        for k, v in zip(keys, res[:6]):
+            rec[k].append(v[:, 0] if k == 'adj' else v)
+        rec['info'].append(np.stack([rh.info_array(res[6][e], fo.INFO_KEYS) for e in range(n)]))
+        rec['reset_count'].append(res[7])
+    d.update({k: np.stack(v) for k, v in rec.items()})
+    save('form_dummy4.npz', d)
 
 
 def gen_cfg1():
@@ -212,6 +270,12 @@ def gen_kat_world():
 
 if __name__ == '__main__':
     assert rh.available(), 'needs /root/reference (build container only)'
-    gen_kat_world()
-    gen_cfg1()
-    gen_traj()
+    which = sys.argv[1:] or ['kat', 'cfg1', 'traj', 'formation']
+    if 'kat' in which:
+        gen_kat_world()
+    if 'cfg1' in which:
+        gen_cfg1()
+    if 'traj' in which:
+        gen_traj()
+    if 'formation' in which:
+        gen_formation()

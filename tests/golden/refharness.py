@@ -125,6 +125,11 @@ def capture_state(env):
         min_time=np.array([a.goal_min_time for a in w.agents], dtype=np.float64),
         cur_step=np.int64(env.current_step),
     )
+    if hasattr(sc, 'expected_poses'):  # fair_graph_formation.py scenario-level state
+        s.update(slot_pos=np.array(sc.expected_poses, dtype=np.float64).reshape(N, 2),
+                 slot_occ=np.array(sc.expected_poses_occupied, dtype=np.float64),
+                 slot_delta=np.array(getattr(sc, 'delta_dists', np.zeros(N)), dtype=np.float64),
+                 formation_done=np.array(w.formation_complete, dtype=np.float64))
     return s
 
 
@@ -160,6 +165,11 @@ def inject_state(env, s):
     w.time_taken_stddev = np.std(w.times_required)
     env.current_step = int(s['cur_step'])
     w.current_time_step = int(s['cur_step'])
+    if 'slot_pos' in s and hasattr(sc, 'expected_poses'):
+        sc.expected_poses = np.array(s['slot_pos'], dtype=np.float64)
+        sc.expected_poses_occupied = np.array(s['slot_occ'], dtype=np.float64)
+        sc.delta_dists = np.array(s['slot_delta'], dtype=np.float64)
+        w.formation_complete = np.array(s['formation_done'], dtype=np.float64)
     w.calculate_distances()
 
 

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 
+from oracle import formation_oracle as fo
 from oracle import nav_oracle as no
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -28,3 +29,22 @@ def state_from(fx, cfg, prefix='init_'):
 
 TRAJ = ['traj_n3.npz', 'traj_n3w2.npz', 'traj_n1.npz', 'traj_n2o1w1.npz', 'traj_n10.npz', 'traj_n32.npz',
         'traj_n3_ep5.npz', 'traj_n3_float.npz', 'traj_n4_knobs.npz', 'traj_crafted.npz']
+
+
+FORM = ['form_n3.npz', 'form_n10.npz', 'form_n5l3.npz', 'form_n4_thr04.npz', 'form_n3_thr07.npz', 'form_n1.npz',
+        'form_crafted.npz']
+
+
+def form_cfg_of(fx):
+    args = json.loads(str(fx['args']))
+    kw = {k: v for k, v in args.items() if k in fo.Config.__dataclass_fields__}
+    kw['num_walls'] = 2
+    return fo.Config(**kw)
+
+
+def form_state_from(fx, cfg, prefix='init_'):
+    n = fx[prefix + 'agent_pos'].shape[0]
+    st = fo.State(cfg, n)
+    for k in fo.State.FIELDS:
+        getattr(st, k)[...] = fx[prefix + k]
+    return st
