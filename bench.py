@@ -38,6 +38,10 @@ CONFIGS = {
     # BASELINE.json configs[2] (and configs[4] per GPU): the configuration the target is quoted on
     'cfg3': dict(workload='navigation_graph, 32 agents + 8 obstacles (E=72), 65536 envs per GPU',
                  env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=64, cpu_episodes=5),
+    # BASELINE.json configs[3]
+    'cfg4': dict(workload='fair_graph_formation, 10 agents + 1 landmark + 3 obstacles + 2 walls (E=16), 65536 envs per GPU',
+                 env=dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3),
+                 n_envs=65536, cpu_envs=16, cpu_episodes=4),
     # BASELINE.json configs[1]
     'cfg2': dict(workload='navigation_graph, 3 agents + 3 obstacles (E=9), 4096 envs per GPU',
                  env=dict(num_agents=3, num_landmarks=3, num_obstacles=3), n_envs=4096, cpu_envs=512, cpu_episodes=20),
@@ -48,6 +52,8 @@ def algorithmic_bytes(cfg, emit=True):
     """bytes per agent-step, B = 4 [A + S + D + R + F E + E^2/N + C/N]."""
     N, E = cfg.N, cfg.E
     C = 2 * (cfg.num_landmarks + cfg.num_obstacles) + 6 * cfg.num_walls
+    if cfg.scenario_name == 'fair_graph_formation':
+        C += 6 * N   # slot words read + written per env (SURVEY section 8 d, cfg 4 row)
     A, S, R = 1, 2 * 12, 3
     words = A + S + R
     if emit:
@@ -57,10 +63,16 @@ def algorithmic_bytes(cfg, emit=True):
 
 def cpu_baseline(cfg, n_envs, episodes):
     """The oracle (NumPy float64 restatement, single core) on a bounded sample of the same workload."""
+    from oracle import formation_oracle as fo
     from oracle import nav_oracle as no
     from oracle.philox import PhiloxStream
-    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
-    env = no.OracleGraphVecEnv(ocfg, n_envs, mode='subproc', streams=lambda e, ep: PhiloxStream(1, e, ep))
+    streams = lambda e, ep: PhiloxStream(1, e, ep)  # noqa: E731
+    if cfg.scenario_name == 'fair_graph_formation':
+        ocfg = fo.Config(**{k: getattr(cfg, k) for k in fo.Config.__dataclass_fields__})
+        env = fo.OracleFormationVecEnv(ocfg, n_envs, mode='subproc', streams=streams)
+    else:
+        ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+        env = no.OracleGraphVecEnv(ocfg, n_envs, mode='subproc', streams=streams)
     env.reset()
     rs = np.random.RandomState(0)
     steps = episodes * cfg.episode_length
@@ -160,7 +172,7 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get(args.config, {}).get('hbm_bytes_per_launch')
         out = {
-            'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), navigation_graph random-action rollout',
+            'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), %s random-action rollout' % cfg.scenario_name,
             'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 state and contact math, f32 outputs', 'data': 'synthetic',
@@ -169,7 +181,7 @@ def main():
                        'exchange': ('RCCL gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'step_kernel',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'formation_kernel<true>' if cfg.scenario_name == 'fair_graph_formation' else 'step_kernel',
                          'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},

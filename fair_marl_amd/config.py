@@ -28,6 +28,10 @@ class EnvConfig:
     graph_feat_type: str = 'relative'
     num_scripted_agents: int = 0
 
+    def __post_init__(self):
+        if self.scenario_name == 'fair_graph_formation':
+            self.num_walls = 2  # hard-coded by the scenario (reference fair_graph_formation.py:184), args ignored
+
     @classmethod
     def from_args(cls, args):
         """Build from an argparse.Namespace (or any object / dict with these attributes)."""

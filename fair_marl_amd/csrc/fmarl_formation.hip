@@ -1,0 +1,364 @@
+// fair_graph_formation (BASELINE config 4) on gfx950: step + reset observation.
+//
+// Restates reference multiagent/custom_scenarios/fair_graph_formation.py ("ff:<line>") behind the same
+// World.step physics (fmarl_step.hip world_step_agent):
+//   ff:622-700 reward      slots on a circle about landmark 0 anchored at the smallest agent angle,
+//                          agent x slot distances, occupancy, Hungarian matching (scipy at ff:615-618)
+//   ff:703-741 observation three-way goal branch, concat(v, x, goal - x) + flag (list + ndarray quirk)
+//   ff:810-971 graph_observation  12 features, agent rows run the same branch with the EGO's index
+//   ff:441-501 info_callback      ring test, frozen dists_to_goal, statistics
+// The reference walks the agents sequentially (environment.py:832-864) and the scenario mutates the
+// slot occupancy inside observation / graph_observation; reward(agent 0) replaces slots and occupancy
+// between observation(0) and observation(1).  Positions are fixed during that walk, so everything
+// geometric is computed in parallel (one thread per agent) and only the occupancy bit-mask is walked
+// sequentially by one lane per env (N (N + 1) branch events on a 32-bit mask).
+#pragma once
+#include "fmarl_dev.h"
+#include "fmarl_kernels.h"
+#include "fmarl_step.hip"
+
+namespace fmarl {
+
+constexpr double kTargetRadius = 0.5;   // ff:105
+
+// Kuhn-Munkres with potentials (shortest augmenting paths), one lane, O(N^3).  a: N x N row-major costs.
+// ans[row] = col.  For generic real costs the optimum is unique, so it equals SciPy's (ff:615-618).
+__device__ void hungarian_lane(const double *a, int N, int *ans, double *u, double *v, double *minv, int *pcol, int *way) {
+    const double INF = 1e300;
+    for (int j = 0; j <= N; ++j) { u[j] = 0.0; v[j] = 0.0; pcol[j] = 0; }
+    for (int i = 1; i <= N; ++i) {
+        pcol[0] = i;
+        int j0 = 0;
+        uint64_t used = 0;
+        for (int j = 0; j <= N; ++j) minv[j] = INF;
+        do {
+            used |= 1ull << j0;
+            const int i0 = pcol[j0];
+            double delta = INF;
+            int j1 = 0;
+            for (int j = 1; j <= N; ++j) {
+                if ((used >> j) & 1) continue;
+                const double cur = a[(i0 - 1) * N + (j - 1)] - u[i0] - v[j];
+                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+            }
+            for (int j = 0; j <= N; ++j) {
+                if ((used >> j) & 1) { u[pcol[j]] += delta; v[j] -= delta; }
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (pcol[j0] != 0);
+        do {
+            const int j1 = way[j0];
+            pcol[j0] = pcol[j1];
+            j0 = j1;
+        } while (j0);
+    }
+    for (int j = 1; j <= N; ++j) ans[pcol[j] - 1] = j - 1;
+}
+
+// Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
+struct FormLds {
+    char *base;
+    const Params &p;
+    __device__ FormLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
+    __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
+    __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }
+    __device__ double *wall() const { return (double *)(base + p.lds_wall); }
+    __device__ int *flag() const { return (int *)(base + p.lds_flag); }
+    __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
+    __device__ double2 *slot_old() const { return (double2 *)(base + p.f_slot_old); }
+    __device__ double *dm_new() const { return (double *)(base + p.f_dm_new); }
+    __device__ double *dm_old() const { return (double *)(base + p.f_dm_old); }
+    __device__ double *hung(int which) const { return (double *)(base + p.f_hung + which * p.f_hung_bytes); }
+    __device__ int *g_new() const { return (int *)(base + p.f_g); }
+    __device__ int *g_old() const { return (int *)(base + p.f_g) + p.N; }
+    __device__ int *near_new() const { return (int *)(base + p.f_g) + 2 * p.N; }
+    __device__ uint32_t *masks() const { return (uint32_t *)(base + p.f_masks); }   // [N][4]: b, c, flag, obs code
+    __device__ double *theta() const { return (double *)(base + p.f_theta); }
+    __device__ uint32_t *words() const { return (uint32_t *)(base + p.f_words); }     // occ_old, occ_new, occ_final, near_old0
+    __device__ bool skip() const { return *flag() != 0; }
+
+    // goal of agent entity e as seen in the graph row of ego i (ff:916-943)
+    __device__ double2 graph_goal(uint32_t i, uint32_t e) const {
+        const int nr = near_new()[e];
+        if (nr >= 0) return slot_new()[nr];
+        const uint32_t *m = masks() + 4 * i;
+        if ((m[0] >> e) & 1) return slot_new()[g_new()[i]];
+        return pos()[e];
+    }
+    // feature column f of entity e in the row block of ego i (ff:896-971), ego part included
+    __device__ float node_feature(uint32_t i, uint32_t e, uint32_t f) const {
+        const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
+        if (f == 11) return e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
+        const double2 xi = pos()[i];
+        if (f < 2) {
+            const float4 ai = agentf()[i];
+            const float vi = f == 0 ? ai.x : ai.y;
+            if (e >= N) return 0.f - vi;
+            const float4 ae = agentf()[e];
+            return (f == 0 ? ae.x : ae.y) - vi;
+        }
+        if (f == 6) return e < N ? (float)((masks()[4 * i + 2] >> e) & 1) : 1.f;
+        if (e < N && (f == 4 || f == 5)) {
+            const double2 gl = graph_goal(i, e);
+            return (float)(f == 4 ? gl.x - xi.x : gl.y - xi.y);
+        }
+        if (e >= first_wall && f >= 7) {   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
+            const double *wl = wall() + (e - first_wall) * 4;
+            const double c = f == 7 ? wl[1] : (f == 8 ? wl[0] + kWallWidth / 2 : (f == 9 ? wl[2] : wl[0] - kWallWidth / 2));
+            return (float)(c - ((f & 1) ? xi.x : xi.y));   // f = 7, 9 -> x ; 8, 10 -> y
+        }
+        const double2 xe = pos()[e];
+        const bool is_y = f < 6 ? (f & 1) : !(f & 1);   // columns 2..5: x y x y ; 7..10: x y x y
+        return (float)(is_y ? xe.y - xi.y : xe.x - xi.x);
+    }
+};
+
+// ff:518-530: wall box WITHOUT the 1.05 factors of navigation_graph
+__device__ __forceinline__ bool wall_box_hit_plain(double2 x, double axis, double e0, double e1, int orient) {
+    const double s = kEntitySize;
+    const double pperp = orient == 0 ? x.y : x.x, ppar = orient == 0 ? x.x : x.y;
+    return (axis - s / 2 <= pperp) && (pperp <= axis + s / 2) && (e0 - s / 2 <= ppar) && (ppar <= e1 + s / 2);
+}
+
+// One branch event of ff:707-739 / ff:916-943 on the occupancy mask.  Returns type (0 = near slot,
+// 1 = Hungarian slot of `ego`, 2 = own position) in bits 1..2 and the observed flag in bit 0.
+__device__ __forceinline__ uint32_t branch_event(int near_e, int g_ego, uint32_t full, uint32_t &occ) {
+    if (near_e >= 0) { occ |= 1u << near_e; return 1u; }
+    if ((~occ) & full) return 2u | ((occ >> g_ego) & 1u);
+    occ = 0;
+    return 4u;
+}
+
+// STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877)
+// STEP = false: observation of freshly reset envs (MultiAgentGraphEnv.reset, environment.py:892-897)
+template <bool STEP>
+__global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                             const float *action_vec, int auto_reset) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, N = p.N;
+    const int env0 = blockIdx.x * p.epb;
+    const int nenv = min(p.epb, p.n_envs - env0);
+    const int el = tid / N, i = tid - el * N;
+    const bool active = el < nenv;
+    const int env = env0 + el;
+    const size_t g = (size_t)env * N + i;
+    const FormLds t(p, lds, el);
+    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
+    const uint32_t full = N >= 32 ? ~0u : ((1u << N) - 1);
+
+    double2 x = make_double2(0, 0), v = make_double2(0, 0);
+    double pd = 0;
+    int step = 0;
+    bool emit = false;   // this env's obs / node_obs / adj are written by this launch
+    if (active) {
+        x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
+        t.pos()[i] = x;
+        t.slot_old()[i] = p.slot_pos[g];
+        if (i == 0) { t.words()[0] = 0; t.words()[1] = 0; }
+        step = p.cur_step[env] + (STEP ? 1 : 0);
+        emit = STEP ? !(auto_reset && step >= p.episode_length) : p.reset_flag[env] != 0;
+        if (i == 0) *t.flag() = emit ? 0 : 1;
+    }
+    load_statics(p, lds, env0, nenv);
+    __syncthreads();
+    if (active && p.slot_occ[g] != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
+
+    if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd);
+    __syncthreads();   // every lane has finished reading the old positions
+
+    double Dg_old = 0, Tr_old = 0, Tr_new = 0, fdone = 0;
+    const double2 L0 = active ? t.pos()[N] : make_double2(0, 0);   // landmark 0
+    if (active) {
+        t.pos()[i] = x;
+        t.agentf()[i] = make_float4((float)v.x, (float)v.y, 0.f, 0.f);
+        double th = atan2(x.y - L0.y, x.x - L0.x);   // ff:35-40
+        if (th < 0) th += 2 * M_PI;
+        t.theta()[i] = th;
+        if (STEP) {
+            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; fdone = p.formation_done[g];
+            const bool open = Tr_old == -1.0;
+            const double fd = dist2(x, L0);   // ff:445-451 ring test
+            const bool ring = fd < 1.05 * kTargetRadius && fd > 0.95 * kTargetRadius;
+            if (ring) fdone = 1.0;
+            Tr_new = (ring && open) ? step * kDt : Tr_old;
+            s_stat[i] = pd; s_stat[N + i] = Dg_old; s_stat[2 * N + i] = open ? pd : Dg_old;
+            s_stat[3 * N + i] = Tr_old; s_stat[4 * N + i] = Tr_new;
+        }
+    }
+    __syncthreads();
+
+    if (active) {   // slots: ff:630-648 (step: inside reward(agent 0)); on reset they come from the state
+        double2 P;
+        if (STEP) {
+            double tmin = t.theta()[0];
+            for (int j = 1; j < N; ++j) tmin = fmin(tmin, t.theta()[j]);
+            const double ang = tmin + i * ((2 * M_PI) / N);
+            P = make_double2(L0.x + kTargetRadius * cos(ang), L0.y + kTargetRadius * sin(ang));
+        } else {
+            P = t.slot_old()[i];
+        }
+        t.slot_new()[i] = P;
+    }
+    __syncthreads();
+
+    double left = 0;
+    if (active) {   // agent x slot distances (ff:650-655), nearest slot within thr, dist_left (ff:453)
+        double best = 1e300, best_old = 1e300;
+        int kb = 0, kb_old = 0;
+        for (int k = 0; k < N; ++k) {
+            const double d = dist2(x, t.slot_new()[k]);
+            t.dm_new()[i * N + k] = d;
+            if (d < best) { best = d; kb = k; }
+            if (STEP) {
+                const double d0 = dist2(x, t.slot_old()[k]);
+                t.dm_old()[i * N + k] = d0;
+                if (d0 < best_old) { best_old = d0; kb_old = k; }
+            }
+        }
+        left = best;
+        t.near_new()[i] = best < p.thr ? kb : -1;
+        if (i == 0) t.words()[3] = (uint32_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
+    }
+    __syncthreads();
+
+    if (active) {
+        // occupancy recomputed in reward(agent 0): any agent within thr of slot i (ff:660-661)
+        bool occ = false;
+        for (int a = 0; a < N; ++a) occ |= t.dm_new()[a * N + i] < p.thr;
+        if (occ) atomicOr(&t.words()[1], 1u << i);
+        // the two matchings: lane 0 -> current slots, lane 1 (or 0) -> previous slots (observation(0))
+        const int hl = STEP ? (N > 1 ? 1 : 0) : -1;
+        if (i == 0) {
+            double *w = t.hung(0);
+            hungarian_lane(t.dm_new(), N, t.g_new(), w, w + (N + 1), w + 2 * (N + 1), (int *)(w + 3 * (N + 1)), (int *)(w + 3 * (N + 1)) + (N + 1));
+        }
+        if (i == hl) {
+            double *w = t.hung(1);
+            hungarian_lane(t.dm_old(), N, t.g_old(), w, w + (N + 1), w + 2 * (N + 1), (int *)(w + 3 * (N + 1)), (int *)(w + 3 * (N + 1)) + (N + 1));
+        }
+    }
+    __syncthreads();
+
+    if (active && i == 0) {   // sequential walk of the occupancy mask (one lane per env)
+        uint32_t occ = t.words()[0];
+        uint32_t *m = t.masks();
+        const int *gn = t.g_new(), *nr = t.near_new();
+        for (int a = 0; a < N; ++a) {
+            uint32_t code;
+            if (STEP && a == 0) {
+                code = branch_event((int)t.words()[3], t.g_old()[0], full, occ);   // observation(0): previous slots
+                occ = t.words()[1];                                                  // reward(0)
+            } else {
+                code = branch_event(a == 0 ? (int)t.words()[3] : nr[a], gn[a], full, occ);
+            }
+            uint32_t mb = 0, mc = 0, mf = 0;
+            for (int e = 0; e < N; ++e) {
+                const uint32_t c = branch_event(nr[e], gn[a], full, occ);
+                mb |= ((c >> 1) & 1u) << e;
+                mc |= ((c >> 2) & 1u) << e;
+                mf |= (c & 1u) << e;
+            }
+            m[4 * a] = mb; m[4 * a + 1] = mc; m[4 * a + 2] = mf; m[4 * a + 3] = code;
+        }
+        t.words()[2] = occ;
+    }
+    __syncthreads();
+
+    if (active) {
+        const uint32_t code = t.masks()[4 * i + 3];
+        const bool old_slots = STEP && i == 0;
+        const int nr = i == 0 ? (int)t.words()[3] : t.near_new()[i];
+        double2 goal = x;   // type 2
+        if (code & 1u && !(code & 6u)) goal = (old_slots ? t.slot_old() : t.slot_new())[nr];                 // type 0
+        else if (code & 2u) goal = old_slots ? t.slot_old()[t.g_old()[0]] : t.slot_new()[t.g_new()[i]];     // type 1
+        const double flag = (double)(code & 1u);
+        if (o.obs && emit) {   // ff:740-741: concat(v, x, goal - x) + flag
+            float *ob = o.obs + g * p.D;
+            ob[0] = (float)(v.x + flag); ob[1] = (float)(v.y + flag); ob[2] = (float)(x.x + flag); ob[3] = (float)(x.y + flag);
+            ob[4] = (float)(goal.x - x.x + flag); ob[5] = (float)(goal.y - x.y + flag);
+        }
+        if (STEP || emit) p.slot_occ[g] = (double)((t.words()[2] >> i) & 1u);
+        if (STEP) {
+            const bool open = Tr_old == -1.0;
+            const double Dg_new = open ? pd : Dg_old;
+            const double delta = t.dm_new()[i * N + t.g_new()[i]];   // ff:665
+            double fairness, m, sd;   // ff:623-628, same stale/fresh rule as navigation_graph
+            if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
+            else mixed_stats(s_stat + 2 * N, s_stat + N, N, i, m, sd);
+            fairness = m / (sd + 0.0001);
+            int ag_hits = 0;
+            for (int j = 0; j < N; ++j)
+                if (j != i && closer_than(x, t.pos()[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
+            bool ob_hit = false;
+            for (int k = 0; k < p.O; ++k)
+                ob_hit |= closer_than(t.pos()[N + p.L + k], x, 1.05 * (kEntitySize + kEntitySize));
+            const double *wl = t.wall();
+            for (int w = 0; w < p.W; ++w)
+                ob_hit |= wall_box_hit_plain(x, wl[w * 4], wl[w * 4 + 1], wl[w * 4 + 2], (int)wl[w * 4 + 3]);
+            double rew = delta < p.thr ? p.goal_rew : -delta;   // ff:668-699
+            rew -= p.collision_rew * ag_hits;
+            if (ob_hit) rew -= p.collision_rew;
+            rew += p.fair_rew * tanh(fairness - 5.0);
+            rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
+
+            const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
+            p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
+            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left;
+            p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
+            p.slot_pos[g] = t.slot_new()[i]; p.slot_delta[g] = delta; p.formation_done[g] = fdone;
+            if (i == 0) p.cur_step[env] = step;
+            if (o.reward) o.reward[g] = (float)rew;
+            if (o.done) o.done[g] = step >= p.episode_length;
+            if (o.info) {   // ff:477-499
+                double dm, ds;
+                mixed_stats(s_stat + 2 * N, s_stat + N, N, i + 1, dm, ds);
+                const size_t plane = (size_t)p.n_envs * N;
+                float *inf = o.info + g;
+                inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left;
+                inf[FMARL_INFO_TIME_REQ_TO_GOAL * plane] = (float)Tr_new;
+                inf[FMARL_INFO_NUM_AGENT_COLLISIONS * plane] = (float)nac;
+                inf[FMARL_INFO_NUM_OBST_COLLISIONS * plane] = (float)noc;
+                inf[FMARL_INFO_DISTANCE_MEAN * plane] = (float)dm;
+                inf[FMARL_INFO_DISTANCE_VARIANCE * plane] = (float)ds;
+                inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)(dm / (ds + 0.0001));
+                inf[FMARL_INFO_DISTS_TRAVELED * plane] = (float)Dg_new;
+                inf[FMARL_INFO_TIME_TAKEN * plane] = 0.f;                      // never updated by this scenario
+                inf[FMARL_INFO_FORMATION_DIST * plane] = (float)fdone;          // 'Formation_dist' (ff:495)
+                inf[FMARL_INFO_TIME_STDDEV * plane] = 0.f;
+                inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = 0.f;
+                inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
+                inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
+            }
+        }
+    }
+    // ---- emission: node_obs (one float per lane, 256 contiguous bytes per wave store) and adj
+    if (o.node_obs) {
+        const uint32_t EF = p.E * p.F, NEF = N * EF, total = nenv * NEF;
+        float *dst = o.node_obs + (size_t)env0 * NEF;
+        for (uint32_t q = tid; q < total; q += kThreads) {
+            const uint32_t e_l = p.dNEF.div(q);
+            const FormLds te(p, lds, e_l);
+            if (te.skip()) continue;
+            const uint32_t r = q - e_l * NEF, a = p.dEF.div(r), s = r - a * EF;
+            const uint32_t e = p.dF.div(s), f = s - e * p.F;
+            dst[q] = te.node_feature(a, e, f);
+        }
+    }
+    if (o.adj) {
+        const uint32_t EE = p.E * p.E, total = nenv * EE;
+        float *dst = o.adj + (size_t)env0 * EE;
+        for (uint32_t q = tid; q < total; q += kThreads) {
+            const uint32_t e_l = p.dEE.div(q);
+            const FormLds te(p, lds, e_l);
+            if (te.skip()) continue;
+            const uint32_t r = q - e_l * EE, a = p.dE.div(r), b = r - a * p.E;
+            const double2 pa = te.pos()[a], pb = te.pos()[b];
+            const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
+            dst[q] = sqrtf(dx * dx + dy * dy);
+        }
+    }
+}
+
+}  // namespace fmarl

@@ -17,6 +17,10 @@ __global__ void reset_emit_kernel(Params p, FmarlOutputs o);
 __global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal_pos, double *costs,
                                    int n_envs, int N, int L);
 
+// fmarl_formation.hip
+template <bool STEP> __global__ void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                     const float *action_vec, int auto_reset);
+
 // fmarl_lexifair.hip
 void launch_lexifair_costs(const double *costs, int32_t *perm, int n_envs, int N, hipStream_t stream);
 void launch_lexifair_state(const Params &p, hipStream_t stream);

@@ -64,8 +64,15 @@ struct Placed {
 template <bool LDS>
 __device__ bool obstacle_hit(const Params &p, const Placed<LDS> &pl, const double *wall, double2 x) {
     bool hit = pl.any_closer(0, p.O, x, 1.05 * (kEntitySize + kEntitySize));
-    for (int w = 0; w < p.W; ++w)
-        hit |= wall_box_hit(x, wall[w * 4], wall[w * 4 + 1], wall[w * 4 + 2], (int)wall[w * 4 + 3]);
+    const bool plain = p.scenario == FMARL_SCENARIO_FORMATION;   // fair_graph_formation.py:518-530: no 1.05 factors
+    for (int w = 0; w < p.W; ++w) {
+        const double axis = wall[w * 4], e0 = wall[w * 4 + 1], e1 = wall[w * 4 + 2];
+        const int orient = (int)wall[w * 4 + 3];
+        const double s = kEntitySize;
+        const double pperp = orient == 0 ? x.y : x.x, ppar = orient == 0 ? x.x : x.y;
+        hit |= plain ? ((axis - s / 2 <= pperp) && (pperp <= axis + s / 2) && (e0 - s / 2 <= ppar) && (ppar <= e1 + s / 2))
+                     : wall_box_hit(x, axis, e0, e1, orient);
+    }
     return hit;
 }
 
@@ -93,6 +100,8 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     if (mode == kResetInit)   // make_world: navigation_graph.py:183-185
         p.wall_length[env] = rng.uniform(0.2, 0.8) * p.world_size / 4;
     const double ws = p.world_size, wlen = p.wall_length[env];
+    const bool formation = p.scenario == FMARL_SCENARIO_FORMATION;
+    const double goal_scale = formation ? 0.5 : 0.8;   // fair_graph_formation.py:363 vs navigation_graph.py:492
 
     for (int i = 0; i < N; ++i) {   // :215-225, :239-240
         p.times_required[a0 + i] = -1.0; p.dists_to_goal[a0 + i] = -1.0; p.dist_left[a0 + i] = -1.0;
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     double wall[2 * 4] = {0, 0, 0, 0, 0, 0, 0, 0};   // W <= 2 (axis, e0, e1, orient)
     for (int w = 0; w < p.W; ++w) {   // :294-324
         size_t g = (size_t)env * p.W + w;
-        const int orient = rng.choice_hv();
+        const int orient = formation ? 1 : rng.choice_hv();   // fair_graph_formation.py:276: always 'V', no draw
         const double axis = (w == 0 ? wall_position : -wall_position) * ws / 2;
         p.wall_orient[g] = orient; p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; p.wall_axis[g] = axis;
         if (w == 0) { wall[0] = axis; wall[1] = -wlen; wall[2] = wlen; wall[3] = orient; }
@@ -126,15 +135,33 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     }
     for (int k = 0, tries = 0; k < L;) {   // :472-535
         double2 u = rng.uniform_pair(-ws / 2, ws / 2);
-        double2 x = make_double2(0.8 * u.x, 0.8 * u.y);
+        double2 x = make_double2(goal_scale * u.x, goal_scale * u.y);
         ++tries;
         bool bad = obstacle_hit(p, pl, wall, x);
         bad |= pl.any_closer(2, k, x, thr);   // :707-716
         if (!bad || tries >= kMaxTries) { pl.set_landmark(k, x); ++k; tries = 0; }
     }
-    if (p.has_max_speed)   // :545-547, :719-728 -- previous episode's goal_match_index
+    if (formation) {
+        // fair_graph_formation.py:394-417: slots on the circle about landmark 0, occupancy cleared;
+        // min_time against the agent's OWN slot index (:573-580); formation_complete cleared (:231)
+        const double2 L0 = pl.g_landmark(0);
+        double tmin = 1e300;
+        for (int i = 0; i < N; ++i) {
+            const double2 a = pl.g_agent(i);
+            double th = atan2(a.y - L0.y, a.x - L0.x);
+            if (th < 0) th += 2 * M_PI;
+            tmin = fmin(tmin, th);
+        }
+        for (int i = 0; i < N; ++i) {
+            const double ang = tmin + i * ((2 * M_PI) / N);
+            const double2 P = make_double2(L0.x + 0.5 * cos(ang), L0.y + 0.5 * sin(ang));
+            p.slot_pos[a0 + i] = P; p.slot_occ[a0 + i] = 0.0; p.formation_done[a0 + i] = 0.0;
+            if (p.has_max_speed) p.min_time[a0 + i] = dist2(pl.g_agent(i), P) / p.max_speed;
+        }
+    } else if (p.has_max_speed) {   // :545-547, :719-728 -- previous episode's goal_match_index
         for (int i = 0; i < N; ++i)
             p.min_time[a0 + i] = dist2(pl.g_agent(i), pl.g_landmark(p.goal_match[a0 + i])) / p.max_speed;
+    }
     p.episode[env] = episode + 1;
 }
 

@@ -211,6 +211,86 @@ __device__ __forceinline__ void mixed_stats(const double *fresh, const double *s
     sd = sqrt(q / n);
 }
 
+// World.step (core.py:250-274) for agent i of one env: action force (core.py:277-298 with the
+// decode of environment.py:265-311), entity and wall collision forces (core.py:301-335, :370-462) out of
+// the LDS entity table (positions of the PREVIOUS step), integrate (core.py:338-356).  Updates x, v, pd.
+__device__ __forceinline__ void world_step_agent(const Params &p, const char *base, int i, size_t g,
+                                                 const int32_t *action_idx, const float *action_vec,
+                                                 double2 &x, double2 &v, double &pd) {
+    const double2 *s_pos = (const double2 *)(base + p.lds_pos);
+    double ux, uy;
+    if (action_idx) {
+        int a = action_idx[g];
+        ux = kSensitivity * (double)((a == 1) - (a == 2));
+        uy = kSensitivity * (double)((a == 3) - (a == 4));
+    } else {
+        const float *a = action_vec + g * 5;
+        ux = ((double)a[1] - (double)a[2]) * kSensitivity;
+        uy = ((double)a[3] - (double)a[4]) * kSensitivity;
+    }
+    double Fx = ux, Fy = uy;   // core.py:277-298, mass 1
+    // core.py:301-316 + :370-404: agent-agent, agent-obstacle, agent-wall-entity pairs
+    const int first_obst = p.N + p.L, first_wall = first_obst + p.O;
+    for (int b = 0; b < ((p.ablate & 1) ? 0 : p.E); ++b) {
+        if (b == i || (b >= p.N && b < first_obst)) continue;   // self; landmarks do not collide
+        const double2 q = s_pos[b];
+        const double dx = x.x - q.x, dy = x.y - q.y;
+        const double d2 = dx * dx + dy * dy;
+        const double dmin = b < first_wall ? 2 * kEntitySize : kEntitySize + kWallWidth;
+        // z = -(d - dmin) / margin.  Three regimes by distance (all exact to ~1e-16 in the force):
+        //   z < -37      : softplus tail < 1e-16 * margin, below f64 resolution of the sum -> skip
+        //   -37 <= z < -24: force < 2.3e-10, evaluated in f32 (relative 1e-6 -> absolute 2e-16)
+        //   otherwise    : f64
+        const double far = dmin + 37.0 * kContactMargin, mid = dmin + 24.0 * kContactMargin;
+        if (d2 > far * far) continue;
+        if (d2 > mid * mid) {
+            const float fdx = (float)dx, fdy = (float)dy;
+            const float r = rsqrtf(fdx * fdx + fdy * fdy), d = 1.0f / r;
+            const float e = __expf(((float)dmin - d) * (float)(1.0 / kContactMargin));
+            const float c = (float)(kContactForce * kContactMargin) * e * r;
+            Fx += (double)(c * fdx);
+            Fy += (double)(c * fdy);
+            continue;
+        }
+        const double d = sqrt(d2);
+        const double z = -(d - dmin) / kContactMargin;
+        const double c = kContactForce * softplus_pen(z, kContactMargin) / d;
+        Fx += c * dx;
+        Fy += c * dy;
+    }
+    // core.py:317-326 + :407-462 walls proper
+    const double *wl = (const double *)(base + p.lds_wall);
+    for (int w = 0; w < p.W; ++w) {
+        double axis = wl[w * 4], e0 = wl[w * 4 + 1], e1 = wl[w * 4 + 2];
+        bool horiz = wl[w * 4 + 3] == 0.0;
+        double ppar = horiz ? x.x : x.y, pperp = horiz ? x.y : x.x;
+        const double s = kEntitySize;
+        if (ppar < e0 - s || ppar > e1 + s) continue;
+        double theta = 0.0, dmin = s + 0.5 * kWallWidth;
+        if (ppar < e0 || ppar > e1) {
+            double past = ppar < e0 ? ppar - e0 : ppar - e1;
+            theta = asin(past / s);
+            dmin = cos(theta) * s + 0.5 * kWallWidth;
+        }
+        double dpos = pperp - axis, d = fabs(dpos);
+        double pen = softplus_pen(-(d - dmin) / kWallContactMargin, kWallContactMargin);
+        double fm = kWallContactForce * dpos / d * pen;
+        double fperp = cos(theta) * fm, fpar = sin(theta) * fabs(fm);
+        Fx += horiz ? fpar : fperp;
+        Fy += horiz ? fperp : fpar;
+    }
+    // core.py:338-356 integrate
+    v.x = v.x * (1 - kDamping) + Fx * kDt;
+    v.y = v.y * (1 - kDamping) + Fy * kDt;
+    if (p.has_max_speed) {
+        double speed = sqrt(v.x * v.x + v.y * v.y);
+        if (speed > p.max_speed) { v.x = v.x / speed * p.max_speed; v.y = v.y / speed * p.max_speed; }
+    }
+    x.x += v.x * kDt; x.y += v.y * kDt;
+    double sx = v.x * kDt, sy = v.y * kDt;
+    pd += sqrt(sx * sx + sy * sy);
+}
+
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -240,78 +320,8 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     // ---- World.step (core.py:250-274) ---------------------------------------------------------
     double2 goal = make_double2(0, 0);
     if (active) {
-        double ux, uy;
-        if (action_idx) {
-            int a = action_idx[g];
-            ux = kSensitivity * (double)((a == 1) - (a == 2));
-            uy = kSensitivity * (double)((a == 3) - (a == 4));
-        } else {
-            const float *a = action_vec + g * 5;
-            ux = ((double)a[1] - (double)a[2]) * kSensitivity;
-            uy = ((double)a[3] - (double)a[4]) * kSensitivity;
-        }
-        double Fx = ux, Fy = uy;   // core.py:277-298, mass 1
         goal = s_pos[p.N + match];
-        // core.py:301-316 + :370-404: agent-agent, agent-obstacle, agent-wall-entity pairs
-        const int first_obst = p.N + p.L, first_wall = first_obst + p.O;
-        for (int b = 0; b < ((p.ablate & 1) ? 0 : p.E); ++b) {
-            if (b == i || (b >= p.N && b < first_obst)) continue;   // self; landmarks do not collide
-            const double2 q = s_pos[b];
-            const double dx = x.x - q.x, dy = x.y - q.y;
-            const double d2 = dx * dx + dy * dy;
-            const double dmin = b < first_wall ? 2 * kEntitySize : kEntitySize + kWallWidth;
-            // z = -(d - dmin) / margin.  Three regimes by distance (all exact to ~1e-16 in the force):
-            //   z < -37      : softplus tail < 1e-16 * margin, below f64 resolution of the sum -> skip
-            //   -37 <= z < -24: force < 2.3e-10, evaluated in f32 (relative 1e-6 -> absolute 2e-16)
-            //   otherwise    : f64
-            const double far = dmin + 37.0 * kContactMargin, mid = dmin + 24.0 * kContactMargin;
-            if (d2 > far * far) continue;
-            if (d2 > mid * mid) {
-                const float fdx = (float)dx, fdy = (float)dy;
-                const float r = rsqrtf(fdx * fdx + fdy * fdy), d = 1.0f / r;
-                const float e = __expf(((float)dmin - d) * (float)(1.0 / kContactMargin));
-                const float c = (float)(kContactForce * kContactMargin) * e * r;
-                Fx += (double)(c * fdx);
-                Fy += (double)(c * fdy);
-                continue;
-            }
-            const double d = sqrt(d2);
-            const double z = -(d - dmin) / kContactMargin;
-            const double c = kContactForce * softplus_pen(z, kContactMargin) / d;
-            Fx += c * dx;
-            Fy += c * dy;
-        }
-        // core.py:317-326 + :407-462 walls proper
-        const double *wl = (const double *)(base + p.lds_wall);
-        for (int w = 0; w < p.W; ++w) {
-            double axis = wl[w * 4], e0 = wl[w * 4 + 1], e1 = wl[w * 4 + 2];
-            bool horiz = wl[w * 4 + 3] == 0.0;
-            double ppar = horiz ? x.x : x.y, pperp = horiz ? x.y : x.x;
-            const double s = kEntitySize;
-            if (ppar < e0 - s || ppar > e1 + s) continue;
-            double theta = 0.0, dmin = s + 0.5 * kWallWidth;
-            if (ppar < e0 || ppar > e1) {
-                double past = ppar < e0 ? ppar - e0 : ppar - e1;
-                theta = asin(past / s);
-                dmin = cos(theta) * s + 0.5 * kWallWidth;
-            }
-            double dpos = pperp - axis, d = fabs(dpos);
-            double pen = softplus_pen(-(d - dmin) / kWallContactMargin, kWallContactMargin);
-            double fm = kWallContactForce * dpos / d * pen;
-            double fperp = cos(theta) * fm, fpar = sin(theta) * fabs(fm);
-            Fx += horiz ? fpar : fperp;
-            Fy += horiz ? fperp : fpar;
-        }
-        // core.py:338-356 integrate
-        v.x = v.x * (1 - kDamping) + Fx * kDt;
-        v.y = v.y * (1 - kDamping) + Fy * kDt;
-        if (p.has_max_speed) {
-            double speed = sqrt(v.x * v.x + v.y * v.y);
-            if (speed > p.max_speed) { v.x = v.x / speed * p.max_speed; v.y = v.y / speed * p.max_speed; }
-        }
-        x.x += v.x * kDt; x.y += v.y * kDt;
-        double sx = v.x * kDt, sy = v.y * kDt;
-        pd += sqrt(sx * sx + sy * sy);
+        world_step_agent(p, base, i, g, action_idx, action_vec, x, v, pd);
     }
     __syncthreads();   // every lane has finished reading the old positions
 

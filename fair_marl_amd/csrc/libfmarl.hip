@@ -9,6 +9,7 @@
 #include "fmarl_step.hip"
 #include "fmarl_reset.hip"
 #include "fmarl_lexifair.hip"
+#include "fmarl_formation.hip"
 #include "fmarl_graph.hip"
 
 using namespace fmarl;
@@ -36,12 +37,15 @@ struct Layout {
 bool config_ok(const FmarlConfig *c, const char **why) {
     *why = "";
     if (!c) { *why = "null config"; return false; }
-    if (c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH) { *why = "unsupported scenario"; return false; }
+    const bool form = c->scenario == FMARL_SCENARIO_FORMATION;
+    if (c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH && !form) { *why = "unsupported scenario"; return false; }
     if (c->n_envs < 1) { *why = "n_envs < 1"; return false; }
-    if (c->num_agents < 1 || c->num_agents > 64) { *why = "num_agents must be in 1..64"; return false; }
-    if (c->num_landmarks != c->num_agents) { *why = "navigation_graph needs num_landmarks == num_agents"; return false; }
+    if (c->num_agents < 1 || c->num_agents > (form ? 32 : 64)) { *why = "num_agents must be in 1..64 (formation: 1..32)"; return false; }
+    if (!form && c->num_landmarks != c->num_agents) { *why = "navigation_graph needs num_landmarks == num_agents"; return false; }
+    if (form && c->num_landmarks < 1) { *why = "fair_graph_formation needs num_landmarks >= 1"; return false; }
     if (c->num_obstacles < 0 || c->num_obstacles > 4096) { *why = "bad num_obstacles"; return false; }
     if (c->num_walls < 0 || c->num_walls > 2) { *why = "num_walls must be 0..2"; return false; }
+    if (form && c->num_walls != 2) { *why = "fair_graph_formation always has 2 walls"; return false; }
     if (c->episode_length < 1) { *why = "episode_length < 1"; return false; }
     return true;
 }
@@ -103,6 +107,8 @@ Params bind(const Handle *h, void *state) {
     p.goal_match = (int *)(s + o[FMARL_F_GOAL_MATCH]);         p.num_obst_coll = (int *)(s + o[FMARL_F_NUM_OBST_COLL]);
     p.num_agent_coll = (int *)(s + o[FMARL_F_NUM_AGENT_COLL]); p.cur_step = (int *)(s + o[FMARL_F_CUR_STEP]);
     p.episode = (int *)(s + o[FMARL_F_EPISODE]);               p.reset_flag = (int *)(s + o[FMARL_F_RESET_FLAG]);
+    p.slot_pos = (double2 *)(s + o[FMARL_F_SLOT_POS]);         p.slot_occ = (double *)(s + o[FMARL_F_SLOT_OCC]);
+    p.slot_delta = (double *)(s + o[FMARL_F_SLOT_DELTA]);      p.formation_done = (double *)(s + o[FMARL_F_FORMATION_DONE]);
     return p;
 }
 
@@ -113,9 +119,17 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
         hipLaunchKernelGGL(reset_place_kernel<true>, dim3(blocks), dim3(64), h->place_lds, st, p, mode, mask);
     else
         hipLaunchKernelGGL(reset_place_kernel<false>, dim3(blocks), dim3(64), 0, st, p, mode, mask);
-    launch_lexifair_state(p, st);
-    if (outs && (outs->obs || outs->node_obs || outs->adj))
-        hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
+    const bool form = p.scenario == FMARL_SCENARIO_FORMATION;
+    if (!form) launch_lexifair_state(p, st);
+    if (outs && (outs->obs || outs->node_obs || outs->adj)) {
+        if (form)
+            hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
+                               (const int32_t *)nullptr, (const float *)nullptr, 0);
+        else
+            hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
+    } else if (form && mode != kResetInit) {
+        return fail(FMARL_EINVAL, "fmarl_reset: fair_graph_formation needs output buffers (the reset observation updates the slot flags)");
+    }
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }
@@ -157,7 +171,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     Params &p = h->base;
     memset(&p, 0, sizeof p);
     p.n_envs = cfg->n_envs; p.N = cfg->num_agents; p.L = cfg->num_landmarks; p.O = cfg->num_obstacles;
-    p.W = cfg->num_walls; p.E = p.N + p.L + p.O + p.W; p.D = 7; p.F = 11;
+    const bool form = cfg->scenario == FMARL_SCENARIO_FORMATION;
+    p.W = cfg->num_walls; p.E = p.N + p.L + p.O + p.W; p.D = form ? 6 : 7; p.F = form ? 12 : 11;
     p.episode_length = cfg->episode_length; p.has_max_speed = cfg->has_max_speed; p.env_offset = cfg->env_offset;
     p.scenario = cfg->scenario;
     p.world_size = cfg->world_size; p.max_speed = cfg->max_speed; p.collision_rew = cfg->collision_rew;
@@ -171,6 +186,18 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_stat = off;   off = align16(off + 5 * p.N * 8);
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 4);
+    if (form) {   // fmarl_formation.hip FormLds
+        p.f_slot_new = off; off = align16(off + p.N * 16);
+        p.f_slot_old = off; off = align16(off + p.N * 16);
+        p.f_dm_new = off;   off = align16(off + p.N * p.N * 8);
+        p.f_dm_old = off;   off = align16(off + p.N * p.N * 8);
+        p.f_hung_bytes = align16(3 * (p.N + 1) * 8 + 2 * (p.N + 1) * 4);
+        p.f_hung = off;     off = align16(off + 2 * p.f_hung_bytes);
+        p.f_g = off;        off = align16(off + 3 * p.N * 4);
+        p.f_masks = off;    off = align16(off + 4 * p.N * 4);
+        p.f_theta = off;    off = align16(off + p.N * 8);
+        p.f_words = off;    off = align16(off + 16);
+    }
     p.lds_env_bytes = off;
     int epb = kThreads / p.N;
     const int budget = 48 * 1024;
@@ -186,7 +213,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
     p.dLO.set(p.L + p.O > 0 ? p.L + p.O : 1);
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
-    p.vec_node = (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
+    p.vec_node = !form && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
     p.vec_adj = p.E % 4 == 0;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
@@ -195,6 +222,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
     }
     h->place_lds = (size_t)(p.O + p.N + p.L) * 64 * sizeof(float2);
@@ -272,8 +301,12 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     Params p = bind(h, state);
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
-    hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
-                       auto_reset ? 1 : 0);
+    if (p.scenario == FMARL_SCENARIO_FORMATION)
+        hipLaunchKernelGGL(formation_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
+                           action_vec, auto_reset ? 1 : 0);
+    else
+        hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
+                           auto_reset ? 1 : 0);
     if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
     HIP_OK(hipGetLastError());
     if (h->lockstep) ++h->host_step;

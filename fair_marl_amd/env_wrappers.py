@@ -110,7 +110,7 @@ class GraphSubprocVecEnv(_EngineVecEnv):
         obs, ids, node, adj, rew, done, info = self._step_device()
         return (self._np(obs, np.float64), self._np(ids, np.int64), self._np(node, np.float64),
                 self._np(adj, np.float64), self._np(rew, np.float64), self._np(done, bool),
-                LazyInfos(self._np(info, np.float64)))
+                LazyInfos(self._np(info, np.float64), self.spec.cfg.scenario_name))
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()
@@ -139,7 +139,7 @@ class SubprocVecEnv(_EngineVecEnv):
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
         return (self._np(obs, np.float64), self._np(rew, np.float64), self._np(done, bool),
-                LazyInfos(self._np(info, np.float64)))
+                LazyInfos(self._np(info, np.float64), self.spec.cfg.scenario_name))
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()

@@ -81,6 +81,9 @@ enum {
     FMARL_INFO_TIME_MEAN, FMARL_INFO_TIME_STDDEV, FMARL_INFO_TIME_MEAN_BY_STDDEV,
     FMARL_INFO_MIN_TIME_TO_GOAL, FMARL_INFO_INDIVIDUAL_REWARD
 };
+/* fair_graph_formation has no time statistics; slot 9 carries its 'Formation_dist' key and slots
+ * 8, 10, 11 are zero (fair_graph_formation.py:484-499). */
+#define FMARL_INFO_FORMATION_DIST FMARL_INFO_TIME_MEAN
 
 /* World state: ONE caller-owned device buffer of fmarl_state_bytes() bytes holding the fields
  * below back to back (each 256-byte aligned, row-major, env-major), i.e. the SoA restatement of

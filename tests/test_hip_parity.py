@@ -253,3 +253,103 @@ def test_full_size_properties_cfg3():
     out = no.env_step(ocfg, st, a[sample].cpu().numpy())
     s = sample
     check_outputs((obs[s], ids[s], node[s], adj[s], rew[s], done[s], info[s]), out, 'cfg3 sample')
+
+
+# ------------------------------------------------------------------ fair_graph_formation (BASELINE config 4)
+from oracle import formation_oracle as fo  # noqa: E402
+from helpers import FORM, form_cfg_of, form_state_from  # noqa: E402
+
+FORM_INFO = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13]   # record slots of fo.INFO_KEYS
+
+
+def form_env_cfg(ocfg):
+    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__})
+
+
+def check_form_outputs(got, want, msg=''):
+    obs, ids, node, adj, rew, done, info = got
+    np.testing.assert_allclose(obs.cpu().numpy(), want['obs'], err_msg=msg + ' obs', **OUT)
+    np.testing.assert_allclose(node.cpu().numpy(), want['node_obs'], err_msg=msg + ' node_obs', **OUT)
+    np.testing.assert_allclose(adj.cpu().numpy()[:, 0], want['adj'], err_msg=msg + ' adj', **OUT)
+    np.testing.assert_allclose(rew.cpu().numpy(), want['reward'], err_msg=msg + ' reward', **OUT)
+    assert np.array_equal(done.cpu().numpy().astype(bool), want['done']), msg + ' done'
+    np.testing.assert_allclose(info.cpu().numpy()[..., FORM_INFO], want['info'], err_msg=msg + ' info', **OUT)
+
+
+def form_state_dict(st):
+    return {k: getattr(st, k) for k in fo.State.FIELDS if k != 'time'}
+
+
+@pytest.mark.parametrize('name', FORM)
+def test_formation_golden_trajectory(name):
+    fx = load(name)
+    ocfg = form_cfg_of(fx)
+    st = form_state_from(fx, ocfg)
+    n = st.agent_pos.shape[0]
+    eng = fm.RolloutEngine(form_env_cfg(ocfg), n, device=DEV)
+    eng.set_state(form_state_dict(st))
+    for t in range(fx['actions'].shape[0]):
+        got = eng.step(fx['actions'][t], auto_reset=False)
+        want = {k: fx[k][t] for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
+        check_form_outputs(got, want, '%s step %d' % (name, t))
+    final = eng.get_state()
+    for k in fo.State.FIELDS:
+        if k != 'time':
+            np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
+
+
+@pytest.mark.parametrize('N,L,O,thr,n', [(10, 1, 3, 0.05, 120), (3, 1, 3, 0.05, 200), (6, 2, 2, 0.45, 64), (24, 1, 4, 0.05, 9)])
+def test_formation_reset_and_rollout_vs_philox_oracle(N, L, O, thr, n):
+    seed = 99 + N
+    cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=N, num_landmarks=L, num_obstacles=O, min_dist_thresh=thr)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
+    ocfg = fo.Config(**{k: getattr(cfg, k) for k in fo.Config.__dataclass_fields__})
+    orc = fo.OracleFormationVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    obs, ids, node, adj = eng.reset()
+    o = orc.reset()
+    got = eng.get_state()
+    for k in ('agent_pos', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_orient'):
+        assert np.array_equal(got[k], getattr(orc.st, k)), k
+    for k in ('slot_pos', 'slot_occ', 'min_time'):
+        np.testing.assert_allclose(got[k], getattr(orc.st, k), err_msg=k, **STATE)
+    np.testing.assert_allclose(obs.cpu().numpy(), o[0], **OUT)
+    np.testing.assert_allclose(node.cpu().numpy(), o[2], **OUT)
+    np.testing.assert_allclose(adj.cpu().numpy(), o[3], **OUT)
+    rs = np.random.RandomState(N)
+    for t in range(28):   # crosses an auto-reset
+        a = rs.randint(0, 5, size=(n, N))
+        res = eng.step(torch.as_tensor(a, device=DEV))
+        ref = orc.step(a)
+        want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
+        check_form_outputs(res, want, 'formation N=%d step %d' % (N, t))
+    got = eng.get_state()
+    for k in fo.State.FIELDS:
+        if k != 'time':
+            np.testing.assert_allclose(got[k], getattr(orc.st, k), err_msg='end ' + k, **STATE)
+
+
+def test_formation_full_size_cfg4():
+    """BASELINE config 4 shapes: 10 agents, E = 16, 65 536 envs; oracle parity on a strided sample."""
+    cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3)
+    n = 65536
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=5)
+    eng.reset()
+    assert eng.node_obs.shape == (n, 10, 16, 12) and eng.obs.shape == (n, 10, 6)
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    sample = np.arange(0, n, 2053)
+    ocfg = fo.Config(**{k: getattr(cfg, k) for k in fo.Config.__dataclass_fields__})
+    for t in range(4):
+        a = torch.randint(0, 5, (n, 10), device=DEV, generator=g, dtype=torch.int32)
+        if t == 3:
+            st = fo.State(ocfg, len(sample))
+            pre = eng.get_state()
+            for k in fo.State.FIELDS:
+                if k != 'time':
+                    getattr(st, k)[...] = pre[k][sample]
+        res = eng.step(a, auto_reset=False)
+    out = fo.env_step(ocfg, st, a[torch.as_tensor(sample, device=DEV)].cpu().numpy())
+    s = torch.as_tensor(sample, device=DEV)
+    check_form_outputs(tuple(x[s] for x in res), out, 'cfg4 sample')
+    adj_env = eng.adj_env
+    assert torch.equal(adj_env, adj_env.transpose(1, 2)) and (torch.diagonal(adj_env, dim1=1, dim2=2) == 0).all()
+    assert torch.isfinite(eng.node_obs).all()

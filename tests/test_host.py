@@ -102,6 +102,8 @@ def test_lazy_infos_match_reference_structure():
     assert d['Dist_to_goal'] == rec[1, 2, 0] and d['individual_reward'] == rec[1, 2, 13]
     assert [len(e) for e in infos] == [3, 3]
     assert [a['Time_taken'] for a in infos[0]] == list(rec[0, :, 8])
+    f = LazyInfos(rec, 'fair_graph_formation')[0][1]
+    assert len(f) == 12 and f['Formation_dist'] == rec[0, 1, 9] and 'Time_mean' not in f
 
 
 def test_shard_range_partitions_exactly():
