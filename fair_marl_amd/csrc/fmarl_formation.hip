@@ -21,41 +21,61 @@ namespace fmarl {
 
 constexpr double kTargetRadius = 0.5;   // ff:105
 
-// Kuhn-Munkres with potentials (shortest augmenting paths), one lane, O(N^3).  a: N x N row-major costs.
-// ans[row] = col.  For generic real costs the optimum is unique, so it equals SciPy's (ff:615-618).
-__device__ void hungarian_lane(const double *a, int N, int *ans, double *u, double *v, double *minv, int *pcol, int *way) {
+// Min-sum assignment (Kuhn-Munkres with potentials, shortest augmenting paths) by a group of G lanes
+// (G = power of two >= N, G <= 32): lane c owns column c (v, minv, way, matched row) and row c (u, in-tree
+// flag); the only cross-lane traffic is the argmin reduction and a few broadcasts (shuffles of width G).
+// a: N x N row-major costs in LDS.  ans[row] = col.  For generic real costs the optimum is unique, so it
+// equals SciPy's linear_sum_assignment (ff:615-618).
+template <int G>
+__device__ void hungarian_group(const double *a, int N, int *ans) {
+    const int lane = threadIdx.x & (G - 1);
     const double INF = 1e300;
-    for (int j = 0; j <= N; ++j) { u[j] = 0.0; v[j] = 0.0; pcol[j] = 0; }
-    for (int i = 1; i <= N; ++i) {
-        pcol[0] = i;
-        int j0 = 0;
-        uint64_t used = 0;
-        for (int j = 0; j <= N; ++j) minv[j] = INF;
-        do {
-            used |= 1ull << j0;
-            const int i0 = pcol[j0];
-            double delta = INF;
-            int j1 = 0;
-            for (int j = 1; j <= N; ++j) {
-                if ((used >> j) & 1) continue;
-                const double cur = a[(i0 - 1) * N + (j - 1)] - u[i0] - v[j];
-                if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-                if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+    double u = 0.0, v = 0.0;
+    int prow = -1;   // row matched to column `lane`
+    for (int i = 0; i < N; ++i) {
+        double minv = INF;
+        int way = -1, j0 = -1, i0 = i, j1;
+        bool usedc = false, in_tree = lane == i;
+        for (int it = 0; it <= N; ++it) {   // at most N columns can join the tree
+            const double ui0 = __shfl(u, i0, G);
+            const bool open = lane < N && !usedc;
+            if (open) {
+                const double cur = a[i0 * N + lane] - ui0 - v;
+                if (cur < minv) { minv = cur; way = j0; }
             }
-            for (int j = 0; j <= N; ++j) {
-                if ((used >> j) & 1) { u[pcol[j]] += delta; v[j] -= delta; }
-                else minv[j] -= delta;
+            double best = open ? minv : INF;
+            int bj = open ? lane : G;
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) {
+                const double ob = __shfl_xor(best, off, G);
+                const int oj = __shfl_xor(bj, off, G);
+                if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
             }
+            const double delta = best;
+            j1 = bj;
+            if (in_tree) u += delta;
+            if (usedc) v -= delta; else if (lane < N) minv -= delta;
+            if (lane == j1) usedc = true;
             j0 = j1;
-        } while (pcol[j0] != 0);
-        do {
-            const int j1 = way[j0];
-            pcol[j0] = pcol[j1];
-            j0 = j1;
-        } while (j0);
+            const int r1 = __shfl(prow, j1, G);
+            if (r1 < 0) break;
+            if (lane == r1) in_tree = true;
+            i0 = r1;
+        }
+        for (int j = j1; j >= 0;) {   // flip the augmenting path back to the root (row i)
+            const int jprev = __shfl(way, j, G);
+            const int row = jprev < 0 ? i : __shfl(prow, jprev, G);
+            if (lane == j) prow = row;
+            j = jprev;
+        }
     }
-    for (int j = 1; j <= N; ++j) ans[pcol[j] - 1] = j - 1;
+    if (lane < N) ans[prow] = lane;
 }
+
+// All matchings of the workgroup's envs: task = (env, which) with which 0 = current slots, 1 = previous
+// slots (needed by observation(0) of a step); groups of G lanes take tasks round-robin.
+template <int G>
+__device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_env);
 
 // Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
 struct FormLds {
@@ -114,6 +134,16 @@ struct FormLds {
         return (float)(is_y ? xe.y - xi.y : xe.x - xi.x);
     }
 };
+
+template <int G>
+__device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_env) {
+    const int group = threadIdx.x / G, ngroups = kThreads / G;
+    for (int task = group; task < nenv * per_env; task += ngroups) {
+        const int el = task / per_env, which = task - el * per_env;
+        const FormLds t(p, lds, el);
+        hungarian_group<G>(which == 0 ? t.dm_new() : t.dm_old(), p.N, which == 0 ? t.g_new() : t.g_old());
+    }
+}
 
 // ff:518-530: wall box WITHOUT the 1.05 factors of navigation_graph
 __device__ __forceinline__ bool wall_box_hit_plain(double2 x, double axis, double e0, double e1, int orient) {
@@ -228,20 +258,18 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         bool occ = false;
         for (int a = 0; a < N; ++a) occ |= t.dm_new()[a * N + i] < p.thr;
         if (occ) atomicOr(&t.words()[1], 1u << i);
-        // the two matchings: lane 0 -> current slots, lane 1 (or 0) -> previous slots (observation(0))
-        const int hl = STEP ? (N > 1 ? 1 : 0) : -1;
-        if (i == 0) {
-            double *w = t.hung(0);
-            hungarian_lane(t.dm_new(), N, t.g_new(), w, w + (N + 1), w + 2 * (N + 1), (int *)(w + 3 * (N + 1)), (int *)(w + 3 * (N + 1)) + (N + 1));
-        }
-        if (i == hl) {
-            double *w = t.hung(1);
-            hungarian_lane(t.dm_old(), N, t.g_old(), w, w + (N + 1), w + 2 * (N + 1), (int *)(w + 3 * (N + 1)), (int *)(w + 3 * (N + 1)) + (N + 1));
-        }
+    }
+    __syncthreads();
+    {   // the matchings (current slots; on a step also the previous slots for observation(0))
+        const int per_env = (p.ablate & 64) ? 0 : (STEP ? 2 : 1);
+        if (N <= 4) hungarian_tasks<4>(p, lds, nenv, per_env);
+        else if (N <= 8) hungarian_tasks<8>(p, lds, nenv, per_env);
+        else if (N <= 16) hungarian_tasks<16>(p, lds, nenv, per_env);
+        else hungarian_tasks<32>(p, lds, nenv, per_env);
     }
     __syncthreads();
 
-    if (active && i == 0) {   // sequential walk of the occupancy mask (one lane per env)
+    if (active && i == 0 && !(p.ablate & 128)) {   // sequential walk of the occupancy mask (one lane per env)
         uint32_t occ = t.words()[0];
         uint32_t *m = t.masks();
         const int *gn = t.g_new(), *nr = t.near_new();
@@ -334,6 +362,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         }
     }
     // ---- emission: node_obs (one float per lane, 256 contiguous bytes per wave store) and adj
+    if (p.ablate & 32) return;
     if (o.node_obs) {
         const uint32_t EF = p.E * p.F, NEF = N * EF, total = nenv * NEF;
         float *dst = o.node_obs + (size_t)env0 * NEF;
