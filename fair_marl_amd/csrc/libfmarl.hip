@@ -203,6 +203,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     const int budget = 48 * 1024;
     if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
     if (epb < 1) epb = 1;
+    // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
+    if ((p.n_envs + epb - 1) / epb < 512) { int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb); }
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     h->lds_bytes = (size_t)epb * p.lds_env_bytes;

@@ -35,15 +35,16 @@ def counter_mean(path, kernel, counter):
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, cfg)))
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
-f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), 'step_kernel', 'FETCH_SIZE')
-w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), 'step_kernel', 'WRITE_SIZE')
+kname = 'formation_kernel<true>' if cfg == 'cfg4' else 'step_kernel'
+f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
+w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), kname, 'WRITE_SIZE')
 traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
 traffic_full = (2.0 * f_max + w_max) * 1024.0
 tpath = os.path.join(dst, 'pmc_traffic.json')
 allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
 allt[cfg] = dict(hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
                  write_kib_mean=w_mean, launches=nf, source='%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
-                 '(separate passes), step_kernel rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % tag)
+                 '(separate passes), %s rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % (tag, kname))
 json.dump(allt, open(tpath, 'w'), indent=1, sort_keys=True)
 
 rows = list(csv.DictReader(open(stats)))
@@ -60,9 +61,14 @@ with open(out, 'w') as f:
         f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'].split('(')[0][:60], r['Calls'], float(r['AverageNs']) / 1e3,
                                                        float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
     rl = bench['roofline']
-    f.write('\nstep_kernel average: rocprofv3 %.1f us over %s launches vs %.1f us measured live by bench.py with hipEvents '
-            '(%d launches).\n' % (float(rows[0]['AverageNs']) / 1e3, rows[0]['Calls'], rl['kernel_avg_ms'] * 1e3, rl['kernel_launches']))
-    f.write('\n## HBM traffic of step_kernel (PMC)\n\n')
+    krow = [r for r in rows if kname in r['Name']][0]
+    traced = [l for l in open(os.path.join(src, 'trace.log')) if l.startswith('{')]
+    traced_ms = json.loads(traced[-1])['roofline']['kernel_avg_ms'] if traced else float('nan')
+    f.write('\n%s average: rocprofv3 %.1f us over %s launches vs %.1f us measured live by bench.py with hipEvents '
+            '(%d launches, un-profiled run).  Inside the traced run itself bench.py measured %.1f us over its 200 timed '
+            'launches (the trace also contains the 50 warm-up launches; profiled runs clock lower, MI355X_MICROARCH.md DVFS note 2).\n'
+            % (kname, float(krow['AverageNs']) / 1e3, krow['Calls'], rl['kernel_avg_ms'] * 1e3, rl['kernel_launches'], traced_ms * 1e3))
+    f.write('\n## HBM traffic of %s (PMC)\n\n' % kname)
     f.write('| counter | mean KiB / launch | max KiB / launch | launches |\n|---|---|---|---|\n')
     f.write('| FETCH_SIZE | %.0f | %.0f | %d |\n| WRITE_SIZE | %.0f | %.0f | %d |\n\n' % (f_mean, f_max, nf, w_mean, w_max, nw))
     f.write('HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = **%.3f GB** mean (%.3f GB for a full, '
