@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--n-envs', type=int, default=0, help='envs per GPU (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: skip the RCCL trajectory gather')
+    ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,7 +112,7 @@ def main():
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
-    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs)
+    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset)
     gather = world > 1 and not args.no_gather
     depth = 2
     tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth) if gather else None
@@ -178,6 +179,7 @@ def main():
             'dtype': 'f64 state and contact math, f32 outputs', 'data': 'synthetic',
             'config': {'workload': spec['workload'], 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
+                       'reset': 'synchronous' if args.sync_reset else 'next episode staged on a side stream, committed at episode end',
                        'exchange': ('RCCL gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

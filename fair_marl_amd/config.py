@@ -59,8 +59,9 @@ class EnvConfig:
     @property
     def node_feat(self): return 11 if self.scenario_name == 'navigation_graph' else 12
 
-    def to_c(self, n_envs, seed=0, env_offset=0):
+    def to_c(self, n_envs, seed=0, env_offset=0, async_reset=False):
         c = _lib.FmarlConfig()
+        c.flags = _lib.FLAG_ASYNC_RESET if async_reset else 0
         c.scenario = _lib.SCENARIOS[self.scenario_name]
         c.n_envs = int(n_envs)
         c.num_agents, c.num_landmarks = int(self.num_agents), int(self.num_landmarks)

@@ -50,6 +50,10 @@ struct Params {
     double *p_dist, *wall_axis, *wall_e0, *wall_e1, *wall_length;
     double *dists_to_goal, *times_required, *dist_left, *min_time;
     int *wall_orient, *goal_match, *num_obst_coll, *num_agent_coll, *cur_step, *episode, *reset_flag;
+    // staged next episode (FMARL_FLAG_ASYNC_RESET)
+    double2 *st_agent_pos, *st_landmark_pos, *st_obstacle_pos;
+    double *st_wall_axis;
+    int *st_wall_orient, *st_goal_match, *stage_valid, *stage_need;
 };
 
 // ---------------------------------------------------------------- Philox4x32-10 (oracle/philox.py)

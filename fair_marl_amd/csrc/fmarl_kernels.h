@@ -11,7 +11,9 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, const char *l
 __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
 
 // fmarl_reset.hip
-enum ResetMode { kResetAll = 0, kResetMask = 1, kResetAuto = 2, kResetInit = 3 };
+enum ResetMode { kResetAll = 0, kResetMask = 1, kResetAuto = 2, kResetInit = 3, kResetStage = 4 };
+__global__ void reset_commit_kernel(Params p, int mode, const uint8_t *mask);
+__global__ void stage_finish_kernel(Params p);
 template <bool LDS> __global__ void reset_place_kernel(Params p, int mode, const uint8_t *mask);
 __global__ void reset_emit_kernel(Params p, FmarlOutputs o);
 __global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal_pos, double *costs,

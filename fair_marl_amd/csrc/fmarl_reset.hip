@@ -81,11 +81,17 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= p.n_envs) return;
+    // kResetStage: the position / wall / goal_match pointers of `p` are bound to the staging fields and
+    // only placement is done (for envs without valid staged data); everything else belongs to the commit.
+    const bool stage = mode == kResetStage;
     bool doit = true;
     if (mode == kResetMask) doit = mask[env] != 0;
     else if (mode == kResetAuto) doit = p.cur_step[env] >= p.episode_length;   // all agents done
-    p.reset_flag[env] = doit ? 1 : 0;
+    else if (stage) doit = p.stage_valid[env] == 0;
+    if (stage) p.stage_need[env] = doit ? 1 : 0;
+    else p.reset_flag[env] = doit ? 1 : 0;
     if (!doit) return;
+    if (!stage) p.stage_valid[env] = 0;   // a synchronous reset consumes this episode index: staged data is stale
 
     const int N = p.N, L = p.L;
     const size_t a0 = (size_t)env * N;
@@ -103,11 +109,13 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     const bool formation = p.scenario == FMARL_SCENARIO_FORMATION;
     const double goal_scale = formation ? 0.5 : 0.8;   // fair_graph_formation.py:363 vs navigation_graph.py:492
 
-    for (int i = 0; i < N; ++i) {   // :215-225, :239-240
-        p.times_required[a0 + i] = -1.0; p.dists_to_goal[a0 + i] = -1.0; p.dist_left[a0 + i] = -1.0;
-        p.num_obst_coll[a0 + i] = 0; p.num_agent_coll[a0 + i] = 0; p.p_dist[a0 + i] = 0.0;
+    if (!stage) {
+        for (int i = 0; i < N; ++i) {   // :215-225, :239-240
+            p.times_required[a0 + i] = -1.0; p.dists_to_goal[a0 + i] = -1.0; p.dist_left[a0 + i] = -1.0;
+            p.num_obst_coll[a0 + i] = 0; p.num_agent_coll[a0 + i] = 0; p.p_dist[a0 + i] = 0.0;
+        }
+        p.cur_step[env] = 0;
     }
-    p.cur_step[env] = 0;
     for (int k = 0; k < p.O; ++k) {   // :271-275
         double2 u = rng.uniform_pair(-ws / 2, ws / 2);
         pl.set_obstacle(k, make_double2(0.8 * u.x, 0.8 * u.y));
@@ -118,7 +126,8 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         size_t g = (size_t)env * p.W + w;
         const int orient = formation ? 1 : rng.choice_hv();   // fair_graph_formation.py:276: always 'V', no draw
         const double axis = (w == 0 ? wall_position : -wall_position) * ws / 2;
-        p.wall_orient[g] = orient; p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; p.wall_axis[g] = axis;
+        p.wall_orient[g] = orient; p.wall_axis[g] = axis;
+        if (!stage) { p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; }   // staged: derived from wall_length at commit
         if (w == 0) { wall[0] = axis; wall[1] = -wlen; wall[2] = wlen; wall[3] = orient; }
         else { wall[4] = axis; wall[5] = -wlen; wall[6] = wlen; wall[7] = orient; }
     }
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         bool bad = obstacle_hit(p, pl, wall, x);
         bad |= pl.any_closer(1, k, x, thr);   // :689-698
         if (!bad || tries >= kMaxTries) {
-            pl.set_agent(k, x); p.agent_vel[a0 + k] = make_double2(0.0, 0.0);
+            pl.set_agent(k, x);
+            if (!stage) p.agent_vel[a0 + k] = make_double2(0.0, 0.0);
             ++k; tries = 0;
         }
     }
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         bad |= pl.any_closer(2, k, x, thr);   // :707-716
         if (!bad || tries >= kMaxTries) { pl.set_landmark(k, x); ++k; tries = 0; }
     }
+    if (stage) return;   // min_time, episode counter: reset_commit_kernel
     if (formation) {
         // fair_graph_formation.py:394-417: slots on the circle about landmark 0, occupancy cleared;
         // min_time against the agent's OWN slot index (:573-580); formation_complete cleared (:231)
@@ -163,6 +174,50 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
             p.min_time[a0 + i] = dist2(pl.g_agent(i), pl.g_landmark(p.goal_match[a0 + i])) / p.max_speed;
     }
     p.episode[env] = episode + 1;
+}
+
+// Asynchronous reset, step 2 of 2: make the staged episode the live one for the selected envs
+// (navigation_graph.py:212-262 vector resets, :545-547 min_time against the PREVIOUS goal_match).
+// One thread per (env, agent), same workgroup shape as the step kernel.
+__global__ __launch_bounds__(kThreads) void reset_commit_kernel(Params p, int mode, const uint8_t *mask) {
+    const int tid = threadIdx.x, N = p.N;
+    const int env0 = blockIdx.x * p.epb;
+    const int nenv = min(p.epb, p.n_envs - env0);
+    const int el = tid / N, i = tid - el * N;
+    const bool active = el < nenv;
+    const int env = env0 + el;
+    bool doit = false;
+    if (active) {
+        doit = true;
+        if (mode == kResetMask) doit = mask[env] != 0;
+        else if (mode == kResetAuto) doit = p.cur_step[env] >= p.episode_length;
+    }
+    __syncthreads();   // every lane has read cur_step before lane 0 clears it
+    if (!active) return;
+    if (i == 0) p.reset_flag[env] = doit ? 1 : 0;
+    if (!doit) return;
+    const size_t g = (size_t)env * N + i;
+    const double2 x = p.st_agent_pos[g];
+    if (p.has_max_speed)
+        p.min_time[g] = dist2(x, p.st_landmark_pos[(size_t)env * p.L + p.goal_match[g]]) / p.max_speed;
+    p.agent_pos[g] = x; p.agent_vel[g] = make_double2(0.0, 0.0); p.p_dist[g] = 0.0;
+    p.goal_match[g] = p.st_goal_match[g];
+    p.times_required[g] = -1.0; p.dists_to_goal[g] = -1.0; p.dist_left[g] = -1.0;
+    p.num_obst_coll[g] = 0; p.num_agent_coll[g] = 0;
+    for (int k = i; k < p.L; k += N) p.landmark_pos[(size_t)env * p.L + k] = p.st_landmark_pos[(size_t)env * p.L + k];
+    for (int k = i; k < p.O; k += N) p.obstacle_pos[(size_t)env * p.O + k] = p.st_obstacle_pos[(size_t)env * p.O + k];
+    for (int w = i; w < p.W; w += N) {
+        const size_t gw = (size_t)env * p.W + w;
+        p.wall_axis[gw] = p.st_wall_axis[gw]; p.wall_orient[gw] = p.st_wall_orient[gw];
+        p.wall_e0[gw] = -p.wall_length[env]; p.wall_e1[gw] = p.wall_length[env];
+    }
+    if (i == 0) { p.cur_step[env] = 0; p.episode[env] += 1; p.stage_valid[env] = 0; }
+}
+
+// Asynchronous reset, staging side: placement + assignment done -> the staged data is valid.
+__global__ void stage_finish_kernel(Params p) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < p.n_envs && p.stage_need[env]) p.stage_valid[env] = 1;
 }
 
 // obs / node_obs / adj of freshly reset envs (environment.py:882-898).  Same workgroup shape as the

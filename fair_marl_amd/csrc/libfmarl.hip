@@ -53,6 +53,7 @@ bool config_ok(const FmarlConfig *c, const char **why) {
 void make_layout(const FmarlConfig *c, Layout *l) {
     const size_t n = c->n_envs, N = c->num_agents, L = c->num_landmarks, O = c->num_obstacles, W = c->num_walls;
     auto set = [&](int f, size_t count, int dt) { l->count[f] = count; l->dtype[f] = dt; };
+    const bool form = c->scenario == FMARL_SCENARIO_FORMATION;
     set(FMARL_F_AGENT_POS, n * N * 2, FMARL_DTYPE_F64);   set(FMARL_F_AGENT_VEL, n * N * 2, FMARL_DTYPE_F64);
     set(FMARL_F_P_DIST, n * N, FMARL_DTYPE_F64);          set(FMARL_F_LANDMARK_POS, n * L * 2, FMARL_DTYPE_F64);
     set(FMARL_F_OBSTACLE_POS, n * O * 2, FMARL_DTYPE_F64); set(FMARL_F_WALL_AXIS, n * W, FMARL_DTYPE_F64);
@@ -63,12 +64,20 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     set(FMARL_F_NUM_OBST_COLL, n * N, FMARL_DTYPE_I32);   set(FMARL_F_NUM_AGENT_COLL, n * N, FMARL_DTYPE_I32);
     set(FMARL_F_MIN_TIME, n * N, FMARL_DTYPE_F64);        set(FMARL_F_CUR_STEP, n, FMARL_DTYPE_I32);
     set(FMARL_F_EPISODE, n, FMARL_DTYPE_I32);
-    const bool form = c->scenario == FMARL_SCENARIO_FORMATION;
     set(FMARL_F_SLOT_POS, form ? n * N * 2 : 0, FMARL_DTYPE_F64);
     set(FMARL_F_SLOT_OCC, form ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_SLOT_DELTA, form ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_FORMATION_DONE, form ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_RESET_FLAG, n, FMARL_DTYPE_I32);
+    const bool async = (c->flags & FMARL_FLAG_ASYNC_RESET) && !form;
+    set(FMARL_F_STAGE_AGENT_POS, async ? n * N * 2 : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_STAGE_LANDMARK_POS, async ? n * L * 2 : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_STAGE_OBSTACLE_POS, async ? n * O * 2 : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_STAGE_WALL_AXIS, async ? n * W : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_STAGE_WALL_ORIENT, async ? n * W : 0, FMARL_DTYPE_I32);
+    set(FMARL_F_STAGE_GOAL_MATCH, async ? n * N : 0, FMARL_DTYPE_I32);
+    set(FMARL_F_STAGE_VALID, n, FMARL_DTYPE_I32);
+    set(FMARL_F_STAGE_NEED, n, FMARL_DTYPE_I32);
     size_t off = 0;
     for (int f = 0; f < FMARL_NUM_FIELDS; ++f) {
         l->off[f] = off;
@@ -86,6 +95,10 @@ struct Handle {
     int grid;
     bool lockstep;      // all envs share one step counter, known on the host
     int host_step;
+    bool async;         // FMARL_FLAG_ASYNC_RESET: next episode staged on `side`
+    bool stage_dirty;   // staged data may be stale (caller wrote the state): next reset goes the synchronous way
+    hipStream_t side;
+    hipEvent_t ev_commit, ev_staged;
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int ev_cap, ev_n;
@@ -109,18 +122,52 @@ Params bind(const Handle *h, void *state) {
     p.episode = (int *)(s + o[FMARL_F_EPISODE]);               p.reset_flag = (int *)(s + o[FMARL_F_RESET_FLAG]);
     p.slot_pos = (double2 *)(s + o[FMARL_F_SLOT_POS]);         p.slot_occ = (double *)(s + o[FMARL_F_SLOT_OCC]);
     p.slot_delta = (double *)(s + o[FMARL_F_SLOT_DELTA]);      p.formation_done = (double *)(s + o[FMARL_F_FORMATION_DONE]);
+    p.st_agent_pos = (double2 *)(s + o[FMARL_F_STAGE_AGENT_POS]);   p.st_landmark_pos = (double2 *)(s + o[FMARL_F_STAGE_LANDMARK_POS]);
+    p.st_obstacle_pos = (double2 *)(s + o[FMARL_F_STAGE_OBSTACLE_POS]); p.st_wall_axis = (double *)(s + o[FMARL_F_STAGE_WALL_AXIS]);
+    p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
+    p.stage_valid = (int *)(s + o[FMARL_F_STAGE_VALID]);            p.stage_need = (int *)(s + o[FMARL_F_STAGE_NEED]);
     return p;
 }
 
-int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const FmarlOutputs *outs, hipStream_t st) {
-    Params p = bind(h, state);
+void launch_place(Handle *h, const Params &p, int mode, const uint8_t *mask, hipStream_t st) {
     const int blocks = (p.n_envs + 63) / 64;
     if (h->place_lds)
         hipLaunchKernelGGL(reset_place_kernel<true>, dim3(blocks), dim3(64), h->place_lds, st, p, mode, mask);
     else
         hipLaunchKernelGGL(reset_place_kernel<false>, dim3(blocks), dim3(64), 0, st, p, mode, mask);
+}
+
+// Stage the next episode of every env without valid staged data: placement + fair assignment into the
+// staging fields, on the side stream, ordered after everything `st` has done so far.
+int launch_stage(Handle *h, void *state, hipStream_t st) {
+    HIP_OK(hipEventRecord(h->ev_commit, st));
+    HIP_OK(hipStreamWaitEvent(h->side, h->ev_commit, 0));
+    Params p = bind(h, state);
+    if (h->stage_dirty) HIP_OK(hipMemsetAsync(p.stage_valid, 0, (size_t)p.n_envs * sizeof(int), h->side));
+    h->stage_dirty = false;
+    Params q = p;   // same kernels, pointers bound to the staging fields
+    q.agent_pos = p.st_agent_pos; q.landmark_pos = p.st_landmark_pos; q.obstacle_pos = p.st_obstacle_pos;
+    q.wall_axis = p.st_wall_axis; q.wall_orient = p.st_wall_orient; q.goal_match = p.st_goal_match;
+    q.reset_flag = p.stage_need;
+    launch_place(h, q, kResetStage, nullptr, h->side);
+    launch_lexifair_state(q, h->side);
+    hipLaunchKernelGGL(stage_finish_kernel, dim3((p.n_envs + 255) / 256), dim3(256), 0, h->side, p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(h->ev_staged, h->side));
+    return FMARL_OK;
+}
+
+int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const FmarlOutputs *outs, hipStream_t st) {
+    Params p = bind(h, state);
     const bool form = p.scenario == FMARL_SCENARIO_FORMATION;
-    if (!form) launch_lexifair_state(p, st);
+    const bool staged = h->async && !h->stage_dirty && mode != kResetInit;
+    if (h->async) HIP_OK(hipStreamWaitEvent(st, h->ev_staged, 0));   // staging in flight must finish first
+    if (staged) {   // commit the episode staged on the side stream
+        hipLaunchKernelGGL(reset_commit_kernel, dim3(h->grid), dim3(kThreads), 0, st, p, mode, mask);
+    } else {
+        launch_place(h, p, mode, mask, st);
+        if (!form) launch_lexifair_state(p, st);
+    }
     if (outs && (outs->obs || outs->node_obs || outs->adj)) {
         if (form)
             hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
@@ -131,6 +178,7 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
         return fail(FMARL_EINVAL, "fmarl_reset: fair_graph_formation needs output buffers (the reset observation updates the slot flags)");
     }
     HIP_OK(hipGetLastError());
+    if (h->async) return launch_stage(h, state, st);
     return FMARL_OK;
 }
 
@@ -234,6 +282,19 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         hipFuncSetAttribute((const void *)reset_place_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->place_lds) != hipSuccess)
         h->place_lds = 0;
+    h->async = (cfg->flags & FMARL_FLAG_ASYNC_RESET) && !form;
+    h->stage_dirty = true;   // nothing staged yet
+    h->side = nullptr; h->ev_commit = h->ev_staged = nullptr;
+    if (h->async) {
+        int prio_lo = 0, prio_hi = 0;   // lowest priority: staging only fills what the step kernels leave idle
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_commit, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_staged, hipEventDisableTiming) != hipSuccess) {
+            delete h;
+            return fail(FMARL_EHIP, "fmarl_create: cannot create the staging stream / events");
+        }
+    }
     h->lockstep = false; h->host_step = 0;
     h->ev = nullptr; h->ev_cap = h->ev_n = 0;
     *handle = h;
@@ -248,7 +309,12 @@ static void drop_events(Handle *h) {
 
 int fmarl_destroy(void *handle) {
     Handle *h = (Handle *)handle;
-    if (h) drop_events(h);
+    if (h) {
+        drop_events(h);
+        if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+        if (h->ev_commit) (void)hipEventDestroy(h->ev_commit);
+        if (h->ev_staged) (void)hipEventDestroy(h->ev_staged);
+    }
     delete h;
     return FMARL_OK;
 }
@@ -327,6 +393,7 @@ int fmarl_state_changed(void *handle) {
     Handle *h = (Handle *)handle;
     if (!h) return fail(FMARL_EINVAL, "fmarl_state_changed: null handle");
     h->lockstep = false;
+    h->stage_dirty = true;   // seed / episode counters may have changed: restage before the next commit
     return FMARL_OK;
 }
 

@@ -24,7 +24,7 @@ class OutputSet(object):
 
 
 class RolloutEngine:
-    def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True):
+    def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_args(cfg)
         cfg.validate()
@@ -34,7 +34,9 @@ class RolloutEngine:
             raise RuntimeError('fair_marl_amd needs an AMD GPU (torch.cuda.is_available() is False); '
                                'there is no CPU fallback for the rollout path')
         self.device = torch.device(device)
-        self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset)
+        # async_reset: stage the next episode (placement + fair assignment) on a side stream while the
+        # current one runs; same results, the reset leaves the critical path (see include/fmarl.h)
+        self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset, async_reset=async_reset)
         self.handle = C.c_void_p()
         _lib.check(self.lib.fmarl_create(C.byref(self.c), C.byref(self.handle)), 'fmarl_create')
         nbytes = self.lib.fmarl_state_bytes(C.byref(self.c))
@@ -98,7 +100,9 @@ class RolloutEngine:
                     wall_length=(n,), goal_match=(n, N), dists_to_goal=(n, N), times_required=(n, N),
                     dist_left=(n, N), num_obst_coll=(n, N), num_agent_coll=(n, N), min_time=(n, N),
                     cur_step=(n,), episode=(n,), slot_pos=(n, N, 2), slot_occ=(n, N), slot_delta=(n, N),
-                    formation_done=(n, N), reset_flag=(n,))
+                    formation_done=(n, N), reset_flag=(n,), stage_agent_pos=(n, N, 2), stage_landmark_pos=(n, L, 2),
+                    stage_obstacle_pos=(n, O, 2), stage_wall_axis=(n, W), stage_wall_orient=(n, W),
+                    stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -109,7 +113,8 @@ class RolloutEngine:
         return self._fields[name]
 
     def get_state(self):
-        return {k: v.detach().cpu().numpy().copy() for k, v in self._fields.items() if k != 'reset_flag'}
+        return {k: v.detach().cpu().numpy().copy() for k, v in self._fields.items()
+                if k != 'reset_flag' and not k.startswith('stage_')}
 
     def set_state(self, state):
         for k, v in state.items():

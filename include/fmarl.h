@@ -33,6 +33,13 @@ extern "C" {
 #define FMARL_SCENARIO_NAVIGATION_GRAPH 0   /* multiagent/custom_scenarios/navigation_graph.py */
 #define FMARL_SCENARIO_FORMATION 1          /* multiagent/custom_scenarios/fair_graph_formation.py */
 
+/* FmarlConfig.flags.  ASYNC_RESET: the next episode's placement + fair assignment (a pure function of
+ * seed, env and episode index) is computed ahead of time on a library-owned side stream while the current
+ * episode runs; a reset then only commits the staged state and emits the observation.  Results are
+ * identical to the synchronous path.  Leave it off when capturing single steps into a hipGraph (the
+ * side-stream work outlives the call). */
+#define FMARL_FLAG_ASYNC_RESET 1
+
 /* Scenario arguments: multiagent/custom_scenarios/navigation_graph.py:94-129,208
  * (defaults onpolicy/config.py:176-252, onpolicy/scripts/train_mpe.py:71-106). */
 typedef struct FmarlConfig {
@@ -45,7 +52,7 @@ typedef struct FmarlConfig {
     int32_t episode_length;  /* done when current_step >= episode_length (environment.py:237-247) */
     int32_t has_max_speed;   /* 0 = max_speed None */
     int32_t env_offset;      /* global index of env 0 (RNG streams independent of the sharding) */
-    int32_t reserved0;
+    int32_t flags;           /* FMARL_FLAG_* */
     double world_size;
     double max_speed;
     double collision_rew;
@@ -114,6 +121,14 @@ enum {
     FMARL_F_SLOT_DELTA,        /* f64 (n, N)     formation: scenario.delta_dists            */
     FMARL_F_FORMATION_DONE,    /* f64 (n, N)     formation: world.formation_complete        */
     FMARL_F_RESET_FLAG,        /* i32 (n)        internal: envs picked by the last reset launch */
+    FMARL_F_STAGE_AGENT_POS,   /* f64 (n, N, 2)  staged next episode (FMARL_FLAG_ASYNC_RESET) ...          */
+    FMARL_F_STAGE_LANDMARK_POS,/* f64 (n, L, 2)                                                            */
+    FMARL_F_STAGE_OBSTACLE_POS,/* f64 (n, O, 2)                                                            */
+    FMARL_F_STAGE_WALL_AXIS,   /* f64 (n, W)                                                               */
+    FMARL_F_STAGE_WALL_ORIENT, /* i32 (n, W)                                                               */
+    FMARL_F_STAGE_GOAL_MATCH,  /* i32 (n, N)     ... including its fair assignment                         */
+    FMARL_F_STAGE_VALID,       /* i32 (n)        1 = the staged data belongs to episode index `episode`    */
+    FMARL_F_STAGE_NEED,        /* i32 (n)        internal: envs being staged                               */
     FMARL_NUM_FIELDS
 };
 #define FMARL_DTYPE_F64 0

@@ -97,6 +97,34 @@ def test_reset_and_rollout_vs_philox_oracle(N, O, W, n):
     check_state(eng, orc.st, 'end')
 
 
+def test_async_and_sync_reset_are_identical():
+    """FMARL_FLAG_ASYNC_RESET (next episode staged on a side stream) must not change a single bit,
+    also across masked resets and a set_state in between."""
+    cfg = fm.EnvConfig(num_agents=6, num_landmarks=6, num_obstacles=3, num_walls=1, episode_length=7)
+    n = 150
+    a_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=21, async_reset=True)
+    s_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=21, async_reset=False)
+    g = torch.Generator(device=DEV); g.manual_seed(4)
+
+    def same(msg):
+        sa, ss = a_eng.get_state(), s_eng.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], ss[k]), msg + ' ' + k
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+            assert torch.equal(getattr(a_eng, k), getattr(s_eng, k)), msg + ' ' + k
+    a_eng.reset(); s_eng.reset(); same('reset')
+    for t in range(40):
+        a = torch.randint(0, 5, (n, 6), device=DEV, generator=g, dtype=torch.int32)
+        a_eng.step(a); s_eng.step(a)
+        if t == 12:
+            mask = (torch.arange(n, device=DEV) % 3 == 0).to(torch.uint8)
+            a_eng.reset(mask); s_eng.reset(mask)
+        if t == 20:   # caller rewrites the episode counters: staged data must be rebuilt
+            st = a_eng.get_state(); st['episode'] = st['episode'] + 5
+            a_eng.set_state(st); s_eng.set_state(st)
+        same('step %d' % t)
+
+
 def test_masked_reset_and_float_actions():
     cfg = fm.EnvConfig(num_agents=5, num_landmarks=5, num_obstacles=2, num_walls=2)
     n, seed = 40, 5
