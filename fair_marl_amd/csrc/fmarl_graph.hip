@@ -32,4 +32,46 @@ __global__ __launch_bounds__(256) void update_graph_kernel(const float *adj, int
     if (lane == 0) nnz[env] = base;
 }
 
+// Policy-side edge construction, reference onpolicy/algorithms/utils/gnn.py:307-326 processAdj + the
+// PyG batching of :243-253: per graph b (graph b uses the adj of env b / graphs_per_env -- the reference
+// feeds every agent its own copy of the same matrix), edges (r, c) with 0 < adj[r][c] < max_edge_dist
+// (strict, unlike update_graph) in row-major order, node ids offset by b * E.  Two passes around a prefix
+// sum of the per-graph counts: edge_count_kernel -> offsets (caller: cumsum) -> edge_fill_kernel.
+__device__ __forceinline__ bool edge_on(float d, float thr, int strict) { return d > 0.f && (strict ? d < thr : d <= thr); }
+
+__global__ __launch_bounds__(256) void edge_count_kernel(const float *adj, int32_t *nnz, int n_envs, int E, float thr, int strict) {
+    const int lane = threadIdx.x & 63;
+    const int env = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (env >= n_envs) return;   // wave-uniform
+    const float *a = adj + (size_t)env * E * E;
+    int cnt = 0;
+    for (int q = lane; q < E * E; q += 64) cnt += edge_on(a[q], thr, strict) ? 1 : 0;
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) nnz[env] = cnt;
+}
+
+__global__ __launch_bounds__(256) void edge_fill_kernel(const float *adj, const int64_t *offsets, int64_t *edge_index,
+                                                        float *edge_attr, int64_t total, int n_graphs, int graphs_per_env,
+                                                        int E, float thr, int strict) {
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wave per graph
+    if (b >= n_graphs) return;
+    const int EE = E * E;
+    const float *a = adj + (size_t)(b / graphs_per_env) * EE;
+    int64_t *rows = edge_index, *cols = edge_index + total;
+    int64_t base = offsets[b];
+    const int64_t node0 = (int64_t)b * E;
+    for (int q0 = 0; q0 < EE; q0 += 64) {
+        const int q = q0 + lane;
+        const float d = q < EE ? a[q] : 0.f;
+        const bool on = q < EE && edge_on(d, thr, strict);
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int64_t k = base + __popcll(m & ((1ull << lane) - 1));
+            rows[k] = node0 + q / E; cols[k] = node0 + q % E; edge_attr[k] = d;
+        }
+        base += __popcll(m);
+    }
+}
+
 }  // namespace fmarl

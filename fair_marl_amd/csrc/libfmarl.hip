@@ -428,4 +428,23 @@ int fmarl_update_graph(const float *adj, int32_t *edge_index, float *edge_weight
     return FMARL_OK;
 }
 
+int fmarl_edge_count(const float *adj, int32_t *nnz, int n_envs, int num_entities, double max_edge_dist, int strict,
+                     void *stream) {
+    if (!adj || !nnz || n_envs < 1 || num_entities < 1) return fail(FMARL_EINVAL, "fmarl_edge_count: bad argument");
+    hipLaunchKernelGGL(edge_count_kernel, dim3((n_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, adj, nnz, n_envs,
+                       num_entities, (float)max_edge_dist, strict);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr, int64_t total,
+                    int n_graphs, int graphs_per_env, int num_entities, double max_edge_dist, int strict, void *stream) {
+    if (!adj || !offsets || !edge_index || !edge_attr || n_graphs < 1 || graphs_per_env < 1 || num_entities < 1 || total < 0)
+        return fail(FMARL_EINVAL, "fmarl_edge_fill: bad argument");
+    hipLaunchKernelGGL(edge_fill_kernel, dim3((n_graphs + 3) / 4), dim3(256), 0, (hipStream_t)stream, adj, offsets,
+                       edge_index, edge_attr, total, n_graphs, graphs_per_env, num_entities, (float)max_edge_dist, strict);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
 }  // extern "C"

@@ -197,6 +197,31 @@ class RolloutEngine:
                                                    float(self.cfg.max_edge_dist), self._stream()), 'fmarl_update_graph')
         return ei, ew, nnz
 
+    def process_adj(self, adj_env=None, per_agent=False, strict=True):
+        """Policy-side edge list (reference onpolicy/algorithms/utils/gnn.py:307-326 processAdj + the PyG
+        batching of :243-253): edges with 0 < adj < max_edge_dist in row-major order, node ids offset by
+        graph index * E.  ``per_agent=True`` replicates every env's graph N times like the reference batch
+        of (env, agent) graphs; the default emits each env's graph once.  Returns
+        (edge_index int64 (2, total), edge_attr f32 (total,), offsets int64 (n_graphs + 1))."""
+        adj = self.adj_env if adj_env is None else torch.as_tensor(adj_env).to(self.device, torch.float32).contiguous()
+        n, E = adj.shape[0], adj.shape[1]
+        reps = self.cfg.N if per_agent else 1
+        nnz = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_edge_count(adj.data_ptr(), nnz.data_ptr(), n, E, float(self.cfg.max_edge_dist),
+                                                 1 if strict else 0, self._stream()), 'fmarl_edge_count')
+            counts = nnz.to(torch.int64).repeat_interleave(reps)
+            offsets = torch.zeros(n * reps + 1, dtype=torch.int64, device=self.device)
+            offsets[1:] = torch.cumsum(counts, 0)
+            total = int(offsets[-1].item())
+            ei = torch.empty(2, total, dtype=torch.int64, device=self.device)
+            ea = torch.empty(total, dtype=torch.float32, device=self.device)
+            if total:
+                _lib.check(self.lib.fmarl_edge_fill(adj.data_ptr(), offsets.data_ptr(), ei.data_ptr(), ea.data_ptr(), total,
+                                                    n * reps, reps, E, float(self.cfg.max_edge_dist), 1 if strict else 0,
+                                                    self._stream()), 'fmarl_edge_fill')
+        return ei, ea, offsets
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, capacity):
         """Record a hipEvent pair around each of the next ``capacity`` step-kernel launches (0 = off)."""

@@ -198,6 +198,17 @@ int fmarl_lexifair(const double *costs, int32_t *perm, int n_envs, int num_agent
 int fmarl_update_graph(const float *adj, int32_t *edge_index, float *edge_weight, int32_t *nnz,
                        int n_envs, int num_entities, double max_edge_dist, void *stream);
 
+/* Policy-side edge construction, onpolicy/algorithms/utils/gnn.py:307-326 processAdj (strict != 0:
+ * 0 < adj < max_edge_dist; strict == 0: the <= of update_graph) with the node-id offsets of the PyG batch
+ * of :243-253.  Pass 1: nnz i32 (n) per env.  The caller builds offsets i64 (n_graphs + 1) = exclusive
+ * prefix sum of the per-graph counts (graph b uses env b / graphs_per_env; the reference replicates the
+ * matrix per agent).  Pass 2: edge_index i64 (2, total) row-major [rows | cols] with ids b * E + r,
+ * edge_attr f32 (total). */
+int fmarl_edge_count(const float *adj, int32_t *nnz, int n_envs, int num_entities, double max_edge_dist,
+                     int strict, void *stream);
+int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr, int64_t total,
+                    int n_graphs, int graphs_per_env, int num_entities, double max_edge_dist, int strict, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,6 +186,28 @@ def test_lexifair_cost_matrix_update_graph():
         assert (ei[e, :, k:] == -1).all()
 
 
+def test_process_adj_matches_reference_semantics():
+    """gnn.py:307-326 processAdj on the batch of (env, agent) graphs, restated with torch ops on the CPU."""
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=3, num_walls=1, max_edge_dist=0.8)
+    eng = fm.RolloutEngine(cfg, 11, device=DEV, seed=8)
+    eng.reset()
+    adj = eng.adj.cpu()                       # (n, N, E, E) as the policy receives it
+    batch = adj.reshape(-1, cfg.E, cfg.E)     # one graph per (env, agent)
+    mask = ((batch < cfg.max_edge_dist) * (batch > 0)).float()
+    a = batch * mask
+    idx = a.nonzero(as_tuple=True)
+    want_attr = a[idx]
+    off = idx[0] * cfg.E
+    want_index = torch.stack((off + idx[1], off + idx[2]), dim=0)
+    ei, ea, offsets = eng.process_adj(per_agent=True)
+    assert torch.equal(ei.cpu(), want_index) and torch.equal(ea.cpu(), want_attr)
+    assert offsets[-1].item() == want_attr.numel()
+    ei1, ea1, off1 = eng.process_adj(per_agent=False)
+    assert ei1.shape[1] * cfg.N == ei.shape[1]
+    ei2, ea2, _ = eng.process_adj(per_agent=False, strict=False)   # update_graph's <=
+    assert ei2.shape[1] >= ei1.shape[1]
+
+
 def test_vec_env_wrappers_api():
     """Names / arities / dtypes of the reference wrappers (env_wrappers.py:895-1026) on the HIP engine."""
     import argparse
