@@ -20,7 +20,7 @@ _TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32}
 
 class OutputSet(object):
     """obs / reward / done / info tensors of one step + the FmarlOutputs struct pointing at them."""
-    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'c')
+    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'c')
 
 
 class RolloutEngine:
@@ -65,10 +65,11 @@ class RolloutEngine:
             self._fields[name] = view.view(shapes[name])
         _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
 
-    def new_output_set(self, obs=None, reward=None, done=None):
-        """A set of per-step output buffers.  node_obs / adj are shared by all sets (large, consumed
-        before the next step); obs / reward / done / info are per set so a set can still be read
-        (e.g. by an in-flight RCCL gather, see sharding.py) while the next step writes another."""
+    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None):
+        """A set of per-step output buffers.  By default node_obs / adj are shared by all sets (large,
+        consumed before the next step) while obs / reward / done / info are per set, so a set can still
+        be read (e.g. by an in-flight RCCL gather, see sharding.py) while the next step writes another.
+        Any buffer can be supplied by the caller (e.g. a slot of a DeviceRolloutBuffer: zero-copy insert)."""
         n, N, D = self.n_envs, self.cfg.N, self.cfg.obs_dim
         with torch.cuda.device(self.device):
             mk = lambda t, shape, dt: t if t is not None else torch.zeros(shape, dtype=dt, device=self.device)
@@ -79,10 +80,14 @@ class RolloutEngine:
             # field-major planes on the device (coalesced stores); exposed as an (n, N, K) view
             o.info_planes = torch.zeros(_lib.INFO_WIDTH, n, N, dtype=torch.float32, device=self.device) if self.emit_info else None
             o.info = o.info_planes.permute(1, 2, 0) if self.emit_info else None
-        for t, shape, dt in ((o.obs, (n, N, D), torch.float32), (o.reward, (n, N), torch.float32), (o.done, (n, N), torch.uint8)):
+            o.node_obs = node_obs if node_obs is not None else self.node_obs
+            o.adj_env = adj_env if adj_env is not None else self.adj_env
+        E, F = self.cfg.E, self.cfg.node_feat
+        for t, shape, dt in ((o.obs, (n, N, D), torch.float32), (o.reward, (n, N), torch.float32), (o.done, (n, N), torch.uint8),
+                             (o.node_obs, (n, N, E, F), torch.float32), (o.adj_env, (n, E, E), torch.float32)):
             if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError('output buffer must be a contiguous %s tensor of shape %s on %s' % (dt, shape, self.device))
-        o.c = _lib.FmarlOutputs(o.obs.data_ptr(), self.node_obs.data_ptr(), self.adj_env.data_ptr(),
+        o.c = _lib.FmarlOutputs(o.obs.data_ptr(), o.node_obs.data_ptr(), o.adj_env.data_ptr(),
                                 o.reward.data_ptr(), o.done.data_ptr(),
                                 o.info_planes.data_ptr() if o.info_planes is not None else None)
         return o
@@ -91,6 +96,7 @@ class RolloutEngine:
         """Select the output set the next reset / step calls write into."""
         self.outs = out_set
         self.obs, self.reward, self.done, self.info = out_set.obs, out_set.reward, out_set.done, out_set.info
+        self.node_obs, self.adj_env = out_set.node_obs, out_set.adj_env
 
     def _field_shapes(self):
         n, c = self.n_envs, self.cfg

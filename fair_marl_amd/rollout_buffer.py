@@ -1,0 +1,89 @@
+"""Device-resident rollout buffer in the layout of the reference's ``GraphReplayBuffer``
+(reference onpolicy/utils/graph_buffer.py:84-165: ``(T + 1, n_rollout_threads, num_agents, ...)``
+float32 arrays), filled **in place** by the step kernels.
+
+The reference copies every step's NumPy outputs into the buffer on the host
+(onpolicy/runner/shared/graph_mpe_runner.py:438-488 ``insert``).  Here each time slot is an output
+set of the engine, so "insert" is free: step t writes obs / node_obs / adj straight into slot t + 1 and
+rewards into slot t.  What ``insert`` computes on the host is done with a few device ops:
+
+* ``share_obs`` (centralized critic, graph_mpe_runner.py:470-478): every agent sees the concatenation of all
+  agents' obs -> a stride-0 view ``obs.reshape(T+1, n, 1, N*D).expand(.., N, ..)``, never materialised;
+* ``adj`` is stored once per env and exposed per agent as a stride-0 view (the reference stores N copies);
+* ``masks`` = 0 where the agent was done, ``active_masks`` = 0 where an agent is done but its env is not
+  (graph_mpe_runner.py:452-465).
+
+At BASELINE config 3 (65 536 envs x 32 agents, E = 72) one slot is 8.3 GB, a 25-step episode 216 GB:
+it fits the 288 GB of one MI355X, which is the point of keeping it resident.
+"""
+import torch
+
+
+class DeviceRolloutBuffer(object):
+    def __init__(self, engine, episode_length=None):
+        self.engine = eng = engine
+        cfg = eng.cfg
+        self.T = T = int(episode_length or cfg.episode_length)
+        n, N, E, D, F = eng.n_envs, cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat
+        dev = eng.device
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        self.obs = z(T + 1, n, N, D)
+        self.node_obs = z(T + 1, n, N, E, F)
+        self.adj_env = z(T + 1, n, E, E)
+        self.rewards = z(T, n, N, 1)
+        self.dones = z(T, n, N, dtype=torch.uint8)
+        self.masks = torch.ones(T + 1, n, N, 1, dtype=torch.float32, device=dev)
+        self.active_masks = torch.ones(T + 1, n, N, 1, dtype=torch.float32, device=dev)
+        self.agent_id = torch.arange(N, dtype=torch.int32, device=dev).view(1, 1, N, 1).expand(T + 1, n, N, 1)
+        self.share_agent_id = torch.arange(N, dtype=torch.int32, device=dev).view(1, 1, 1, N).expand(T + 1, n, N, N)
+        self._scratch_reward = z(n, N)
+        self._scratch_done = z(n, N, dtype=torch.uint8)
+        # slot t receives the observation that FOLLOWS step t - 1; reward / done of step t go to index t
+        self._sets = []
+        for t in range(T + 1):
+            rew = self.rewards[t - 1].view(n, N) if t >= 1 else self._scratch_reward
+            done = self.dones[t - 1] if t >= 1 else self._scratch_done
+            self._sets.append(eng.new_output_set(obs=self.obs[t], reward=rew, done=done,
+                                                 node_obs=self.node_obs[t], adj_env=self.adj_env[t]))
+        self.step = 0
+
+    # views in the reference's shapes ---------------------------------------------------------------
+    @property
+    def adj(self):
+        T1, n, E = self.adj_env.shape[0], self.adj_env.shape[1], self.adj_env.shape[2]
+        return self.adj_env.view(T1, n, 1, E, E).expand(T1, n, self.engine.cfg.N, E, E)
+
+    @property
+    def share_obs(self):
+        T1, n, N, D = self.obs.shape
+        return self.obs.view(T1, n, 1, N * D).expand(T1, n, N, N * D)
+
+    # rollout -----------------------------------------------------------------------------------------
+    def reset(self):
+        """envs.reset() -> slot 0 (reference graph_mpe_runner.py:178-203 warmup)."""
+        self.engine.use_outputs(self._sets[0])
+        self.engine.reset()
+        self.step = 0
+        self.masks.fill_(1.0)
+        self.active_masks.fill_(1.0)
+
+    def insert_step(self, actions):
+        """envs.step(actions) + buffer.insert of the env outputs: slot step + 1, rewards[step]."""
+        t = self.step
+        if t >= self.T:
+            raise RuntimeError('buffer full: call after_update() first')
+        self.engine.use_outputs(self._sets[t + 1])
+        self.engine.step(actions, auto_reset=True)
+        done = self.dones[t].to(torch.bool)                          # (n, N)
+        done_env = done.all(dim=1, keepdim=True)                     # graph_mpe_runner.py:444
+        self.masks[t + 1] = (~done).to(torch.float32).unsqueeze(-1)  # :452-458
+        self.active_masks[t + 1] = (~(done & ~done_env)).to(torch.float32).unsqueeze(-1)  # :459-465
+        self.step = t + 1
+        return self._sets[t + 1]
+
+    def after_update(self):
+        """graph_buffer.py after_update: the last slot becomes the first of the next rollout."""
+        for name in ('obs', 'node_obs', 'adj_env', 'masks', 'active_masks'):
+            buf = getattr(self, name)
+            buf[0].copy_(buf[-1])
+        self.step = 0

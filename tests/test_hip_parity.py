@@ -208,6 +208,47 @@ def test_process_adj_matches_reference_semantics():
     assert ei2.shape[1] >= ei1.shape[1]
 
 
+def test_device_rollout_buffer_matches_reference_insert():
+    """DeviceRolloutBuffer (GraphReplayBuffer layout, filled in place) vs the reference runner's host-side
+    insert (graph_mpe_runner.py:438-488) restated with NumPy on the outputs of a twin engine."""
+    cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=2, episode_length=6)
+    n, T = 20, 6
+    a_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=3)
+    b_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=3)
+    buf = fm.DeviceRolloutBuffer(b_eng, episode_length=T)
+    obs, ids, node, adj = a_eng.reset()
+    buf.reset()
+    want = dict(obs=[obs.cpu().numpy()], node=[node.cpu().numpy()], adj=[adj.cpu().numpy()], rew=[], masks=[np.ones((n, 3, 1))],
+                active=[np.ones((n, 3, 1))])
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    for t in range(T):
+        a = torch.randint(0, 5, (n, 3), device=DEV, generator=g, dtype=torch.int32)
+        obs, ids, node, adj, rew, done, info = a_eng.step(a)
+        buf.insert_step(a)
+        dones = done.cpu().numpy().astype(bool)
+        dones_env = np.all(dones, axis=1)
+        masks = np.ones((n, 3, 1), dtype=np.float32); masks[dones] = 0
+        active = np.ones((n, 3, 1), dtype=np.float32); active[dones] = 0; active[dones_env] = 1
+        want['obs'].append(obs.cpu().numpy()); want['node'].append(node.cpu().numpy()); want['adj'].append(adj.cpu().numpy())
+        want['rew'].append(rew.cpu().numpy()[..., None]); want['masks'].append(masks); want['active'].append(active)
+    assert np.array_equal(buf.obs.cpu().numpy(), np.stack(want['obs']))
+    assert np.array_equal(buf.node_obs.cpu().numpy(), np.stack(want['node']))
+    assert np.array_equal(buf.adj.cpu().numpy(), np.stack(want['adj']))
+    assert np.array_equal(buf.rewards.cpu().numpy(), np.stack(want['rew']))
+    assert np.array_equal(buf.masks.cpu().numpy(), np.stack(want['masks']))
+    assert np.array_equal(buf.active_masks.cpu().numpy(), np.stack(want['active']))
+    so = buf.share_obs.cpu().numpy()   # graph_mpe_runner.py:470-478
+    o = np.stack(want['obs'])
+    assert np.array_equal(so, np.repeat(o.reshape(T + 1, n, 1, -1), 3, axis=2))
+    assert buf.obs.shape == (T + 1, n, 3, 7) and buf.rewards.shape == (T, n, 3, 1) and buf.adj.shape == (T + 1, n, 3, 8, 8)
+    assert (buf.masks[-1] == 0).all()   # the last step ended the episode
+    buf.after_update()
+    assert torch.equal(buf.obs[0], buf.obs[-1]) and buf.step == 0
+    with pytest.raises(RuntimeError):
+        for _ in range(T + 1):
+            buf.insert_step(a)
+
+
 def test_vec_env_wrappers_api():
     """Names / arities / dtypes of the reference wrappers (env_wrappers.py:895-1026) on the HIP engine."""
     import argparse
