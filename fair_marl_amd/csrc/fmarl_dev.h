@@ -42,7 +42,7 @@ struct Params {
     int ablate;              // measurement aid (env FMARL_ABLATE, bench only): bit mask of phases to skip
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
-    int f_slot_new, f_slot_old, f_dm_new, f_dm_old, f_hung, f_hung_bytes, f_g, f_masks, f_theta, f_words;
+    int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
     double2 *slot_pos;
     double *slot_occ, *slot_delta, *formation_done;
     // state

@@ -21,14 +21,41 @@ namespace fmarl {
 
 constexpr double kTargetRadius = 0.5;   // ff:105
 
+// Lane exchange inside a 16-lane DPP row (no LDS crossbar, a few cycles instead of a ds_bpermute round
+// trip): quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror.  For a symmetric reduction
+// (min / argmin) the mirrors do the job of xor 4 / xor 8: after the quad steps every quad is uniform.
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL> __device__ __forceinline__ void argmin_step(double &best, int &bj) {
+    const double ob = dpp_f64<CTRL>(best);
+    const int oj = dpp_i32<CTRL>(bj);
+    if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+}
+// (value, index) argmin over a group of G lanes (G = 4, 8, 16 inside one DPP row; 32 adds one shuffle)
+template <int G> __device__ __forceinline__ void group_argmin(double &best, int &bj) {
+    argmin_step<0xB1>(best, bj);                 // quad_perm [1,0,3,2]
+    argmin_step<0x4E>(best, bj);                 // quad_perm [2,3,0,1]
+    if (G >= 8) argmin_step<0x141>(best, bj);    // row_half_mirror
+    if (G >= 16) argmin_step<0x140>(best, bj);   // row_mirror
+    if (G >= 32) {
+        const double ob = __shfl_xor(best, 16, G);
+        const int oj = __shfl_xor(bj, 16, G);
+        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+}
+
 // Min-sum assignment (Kuhn-Munkres with potentials, shortest augmenting paths) by a group of G lanes
 // (G = power of two >= N, G <= 32): lane c owns column c (v, minv, way, matched row) and row c (u, in-tree
 // flag); the only cross-lane traffic is the argmin reduction and a few broadcasts (shuffles of width G).
-// a: N x N row-major costs in LDS.  ans[row] = col.  For generic real costs the optimum is unique, so it
+// Costs are |x_row - P_col| computed on the fly (x: agent positions in LDS, P: slot positions; no N x N
+// table, which would halve the envs per workgroup).  ans[row] = col.  For generic real costs the optimum is unique, so it
 // equals SciPy's linear_sum_assignment (ff:615-618).
 template <int G>
-__device__ void hungarian_group(const double *a, int N, int *ans) {
+__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *ans) {
     const int lane = threadIdx.x & (G - 1);
+    const double2 Pc = P[lane < N ? lane : 0];
     const double INF = 1e300;
     double u = 0.0, v = 0.0;
     int prow = -1;   // row matched to column `lane`
@@ -40,17 +67,12 @@ __device__ void hungarian_group(const double *a, int N, int *ans) {
             const double ui0 = __shfl(u, i0, G);
             const bool open = lane < N && !usedc;
             if (open) {
-                const double cur = a[i0 * N + lane] - ui0 - v;
+                const double cur = dist2(x[i0], Pc) - ui0 - v;
                 if (cur < minv) { minv = cur; way = j0; }
             }
             double best = open ? minv : INF;
             int bj = open ? lane : G;
-#pragma unroll
-            for (int off = G / 2; off >= 1; off >>= 1) {
-                const double ob = __shfl_xor(best, off, G);
-                const int oj = __shfl_xor(bj, off, G);
-                if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
-            }
+            group_argmin<G>(best, bj);
             const double delta = best;
             j1 = bj;
             if (in_tree) u += delta;
@@ -88,9 +110,6 @@ struct FormLds {
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
     __device__ double2 *slot_old() const { return (double2 *)(base + p.f_slot_old); }
-    __device__ double *dm_new() const { return (double *)(base + p.f_dm_new); }
-    __device__ double *dm_old() const { return (double *)(base + p.f_dm_old); }
-    __device__ double *hung(int which) const { return (double *)(base + p.f_hung + which * p.f_hung_bytes); }
     __device__ int *g_new() const { return (int *)(base + p.f_g); }
     __device__ int *g_old() const { return (int *)(base + p.f_g) + p.N; }
     __device__ int *near_new() const { return (int *)(base + p.f_g) + 2 * p.N; }
@@ -141,7 +160,7 @@ __device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_en
     for (int task = group; task < nenv * per_env; task += ngroups) {
         const int el = task / per_env, which = task - el * per_env;
         const FormLds t(p, lds, el);
-        hungarian_group<G>(which == 0 ? t.dm_new() : t.dm_old(), p.N, which == 0 ? t.g_new() : t.g_old());
+        hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old());
     }
 }
 
@@ -239,11 +258,9 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         int kb = 0, kb_old = 0;
         for (int k = 0; k < N; ++k) {
             const double d = dist2(x, t.slot_new()[k]);
-            t.dm_new()[i * N + k] = d;
             if (d < best) { best = d; kb = k; }
             if (STEP) {
                 const double d0 = dist2(x, t.slot_old()[k]);
-                t.dm_old()[i * N + k] = d0;
                 if (d0 < best_old) { best_old = d0; kb_old = k; }
             }
         }
@@ -256,7 +273,8 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (active) {
         // occupancy recomputed in reward(agent 0): any agent within thr of slot i (ff:660-661)
         bool occ = false;
-        for (int a = 0; a < N; ++a) occ |= t.dm_new()[a * N + i] < p.thr;
+        const double2 Pi = t.slot_new()[i];
+        for (int a = 0; a < N; ++a) occ |= dist2(t.pos()[a], Pi) < p.thr;
         if (occ) atomicOr(&t.words()[1], 1u << i);
     }
     __syncthreads();
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         if (STEP) {
             const bool open = Tr_old == -1.0;
             const double Dg_new = open ? pd : Dg_old;
-            const double delta = t.dm_new()[i * N + t.g_new()[i]];   // ff:665
+            const double delta = dist2(x, t.slot_new()[t.g_new()[i]]);   // ff:665
             double fairness, m, sd;   // ff:623-628, same stale/fresh rule as navigation_graph
             if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
             else mixed_stats(s_stat + 2 * N, s_stat + N, N, i, m, sd);
@@ -361,18 +379,47 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             }
         }
     }
-    // ---- emission: node_obs (one float per lane, 256 contiguous bytes per wave store) and adj
+    // ---- emission: node_obs (16 bytes per lane) and adj
     if (p.ablate & 32) return;
     if (o.node_obs) {
-        const uint32_t EF = p.E * p.F, NEF = N * EF, total = nenv * NEF;
-        float *dst = o.node_obs + (size_t)env0 * NEF;
-        for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t e_l = p.dNEF.div(q);
+        // F = 12 = three float4 chunks per (ego, entity) row: [dv dx] [goal flag dx.x] [dx.y dx type]; the
+        // workgroup streams its region front to back, one 16-byte chunk per lane (ff:896-971).
+        const uint32_t EF = p.E * p.F, NEF = N * EF, C = NEF >> 2, chunks = nenv * C, rows = p.E * 3;
+        const uint32_t first_wall = N + p.L + p.O;
+        float4 *dst = (float4 *)(o.node_obs + (size_t)env0 * NEF);
+        for (uint32_t m = tid; m < chunks; m += kThreads) {
+            const uint32_t e_l = p.dC4.div(m), r = m - e_l * C;         // dC4 = N * E * 3 chunks per env
             const FormLds te(p, lds, e_l);
             if (te.skip()) continue;
-            const uint32_t r = q - e_l * NEF, a = p.dEF.div(r), s = r - a * EF;
-            const uint32_t e = p.dF.div(s), f = s - e * p.F;
-            dst[q] = te.node_feature(a, e, f);
+            const uint32_t a = p.dEE4.div(r), s = r - a * rows;          // dEE4 = E * 3 chunks per ego
+            const uint32_t e = p.dE4.div(s), k = s - e * 3;              // dE4 = 3
+            const double2 xi = te.pos()[a], xe = te.pos()[e];
+            const float dx = (float)(xe.x - xi.x), dy = (float)(xe.y - xi.y);
+            float4 v;
+            if (k == 0) {
+                const float4 ai = te.agentf()[a];
+                float vx = 0.f, vy = 0.f;
+                if (e < (uint32_t)N) { const float4 ae = te.agentf()[e]; vx = ae.x; vy = ae.y; }
+                v = make_float4(vx - ai.x, vy - ai.y, dx, dy);
+            } else if (k == 1) {
+                float gx = dx, gy = dy, fl = 1.f, t7 = dx;
+                if (e < (uint32_t)N) {
+                    const double2 gl = te.graph_goal(a, e);
+                    gx = (float)(gl.x - xi.x); gy = (float)(gl.y - xi.y);
+                    fl = (float)((te.masks()[4 * a + 2] >> e) & 1);
+                } else if (e >= first_wall) {
+                    t7 = (float)(te.wall()[(e - first_wall) * 4 + 1] - xi.x);            // e0 - x_i
+                }
+                v = make_float4(gx, gy, fl, t7);
+            } else {
+                float t8 = dy, t9 = dx, t10 = dy;
+                if (e >= first_wall) {
+                    const double *wl = te.wall() + (e - first_wall) * 4;
+                    t8 = (float)(wl[0] + kWallWidth / 2 - xi.y); t9 = (float)(wl[2] - xi.x); t10 = (float)(wl[0] - kWallWidth / 2 - xi.y);
+                }
+                v = make_float4(t8, t9, t10, e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f)));
+            }
+            dst[m] = v;
         }
     }
     if (o.adj) {

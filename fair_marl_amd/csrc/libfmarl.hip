@@ -230,17 +230,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     int off = 0;
     p.lds_pos = off;    off = align16(off + p.E * 16);
     p.lds_agentf = off; off = align16(off + p.N * 16);
-    p.lds_ego = off;    off = align16(off + p.N * kEgoWidth * 4);
+    p.lds_ego = off;    off = align16(off + (form ? 0 : p.N * kEgoWidth * 4));
     p.lds_stat = off;   off = align16(off + 5 * p.N * 8);
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 4);
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
         p.f_slot_old = off; off = align16(off + p.N * 16);
-        p.f_dm_new = off;   off = align16(off + p.N * p.N * 8);
-        p.f_dm_old = off;   off = align16(off + p.N * p.N * 8);
-        p.f_hung_bytes = align16(3 * (p.N + 1) * 8 + 2 * (p.N + 1) * 4);
-        p.f_hung = off;     off = align16(off + 2 * p.f_hung_bytes);
         p.f_g = off;        off = align16(off + 3 * p.N * 4);
         p.f_masks = off;    off = align16(off + 4 * p.N * 4);
         p.f_theta = off;    off = align16(off + p.N * 8);
@@ -269,6 +265,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
     p.dE4.set(p.vec_adj ? p.E / 4 : 1);
+    if (form) {   // formation emission: chunks per env / per ego row block / per entity row (F = 12 = 3 float4)
+        p.vec_adj = 0;
+        p.dC4.set(p.N * p.E * 3); p.dEE4.set(p.E * 3); p.dE4.set(3);
+    }
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
