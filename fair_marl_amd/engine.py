@@ -24,7 +24,8 @@ class OutputSet(object):
 
 
 class RolloutEngine:
-    def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True):
+    def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True,
+                 emit_graph=True):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_args(cfg)
         cfg.validate()
@@ -44,10 +45,13 @@ class RolloutEngine:
         D, F = cfg.obs_dim, cfg.node_feat
         with torch.cuda.device(self.device):
             self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-            self.node_obs = torch.zeros(n, N, E, F, dtype=torch.float32, device=self.device)
-            self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device)
+            # emit_graph=False (the reference's non-graph MPEEnv, MPE_env.py:21-53): node_obs / adj are never
+            # computed -- the kernels skip the whole emission when handed NULL pointers
+            self.node_obs = torch.zeros(n, N, E, F, dtype=torch.float32, device=self.device) if emit_graph else None
+            self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device) if emit_graph else None
             self.agent_id = torch.arange(N, device=self.device).view(1, N, 1).expand(n, N, 1)
-        self.emit_info = emit_info
+        self.emit_info, self.emit_graph = emit_info, emit_graph
+        self._default_graph = (self.node_obs, self.adj_env)
         self.outs = self.new_output_set()
         self.use_outputs(self.outs)
         self._fields = {}
@@ -80,14 +84,17 @@ class RolloutEngine:
             # field-major planes on the device (coalesced stores); exposed as an (n, N, K) view
             o.info_planes = torch.zeros(_lib.INFO_WIDTH, n, N, dtype=torch.float32, device=self.device) if self.emit_info else None
             o.info = o.info_planes.permute(1, 2, 0) if self.emit_info else None
-            o.node_obs = node_obs if node_obs is not None else self.node_obs
-            o.adj_env = adj_env if adj_env is not None else self.adj_env
+            o.node_obs = node_obs if node_obs is not None else self._default_graph[0]
+            o.adj_env = adj_env if adj_env is not None else self._default_graph[1]
         E, F = self.cfg.E, self.cfg.node_feat
         for t, shape, dt in ((o.obs, (n, N, D), torch.float32), (o.reward, (n, N), torch.float32), (o.done, (n, N), torch.uint8),
                              (o.node_obs, (n, N, E, F), torch.float32), (o.adj_env, (n, E, E), torch.float32)):
+            if t is None:
+                continue
             if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError('output buffer must be a contiguous %s tensor of shape %s on %s' % (dt, shape, self.device))
-        o.c = _lib.FmarlOutputs(o.obs.data_ptr(), o.node_obs.data_ptr(), o.adj_env.data_ptr(),
+        o.c = _lib.FmarlOutputs(o.obs.data_ptr(), o.node_obs.data_ptr() if o.node_obs is not None else None,
+                                o.adj_env.data_ptr() if o.adj_env is not None else None,
                                 o.reward.data_ptr(), o.done.data_ptr(),
                                 o.info_planes.data_ptr() if o.info_planes is not None else None)
         return o
@@ -133,6 +140,8 @@ class RolloutEngine:
     @property
     def adj(self):
         """(n, N, E, E) stride-0 view of the per-env distance matrix."""
+        if self.adj_env is None:
+            return None
         n, E = self.n_envs, self.cfg.E
         return self.adj_env.view(n, 1, E, E).expand(n, self.cfg.N, E, E)
 

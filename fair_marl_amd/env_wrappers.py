@@ -65,14 +65,14 @@ class ShareVecEnv(ABC):
 
 
 class _EngineVecEnv(ShareVecEnv):
-    def __init__(self, env_fns, device='cuda:0'):
+    def __init__(self, env_fns, device='cuda:0', emit_graph=True):
         specs = [fn() for fn in env_fns]
         if not specs or not all(isinstance(s, EnvSpec) for s in specs):
             raise TypeError('env_fns must return fair_marl_amd.GraphMPEEnv / MPEEnv specs')
         spec = specs[0]
         self.spec = spec
         seed = spec.seed_value if spec.seed_value is not None else 1
-        self.engine = RolloutEngine(spec.cfg, len(specs), device=device, seed=seed)
+        self.engine = RolloutEngine(spec.cfg, len(specs), device=device, seed=seed, emit_graph=emit_graph)
         ShareVecEnv.__init__(self, len(specs), spec.observation_space, spec.share_observation_space, spec.action_space)
         self.node_observation_space = spec.node_observation_space
         self.adj_observation_space = spec.adj_observation_space
@@ -134,7 +134,7 @@ class SubprocVecEnv(_EngineVecEnv):
     """reference env_wrappers.py:242-307 (env_name == 'MPE': graph outputs dropped)."""
 
     def __init__(self, env_fns, spaces=None, device='cuda:0'):
-        _EngineVecEnv.__init__(self, env_fns, device)
+        _EngineVecEnv.__init__(self, env_fns, device, emit_graph=False)
 
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
@@ -150,4 +150,4 @@ class DummyVecEnv(SubprocVecEnv):
     """reference env_wrappers.py:686-729"""
 
     def __init__(self, env_fns, device='cuda:0'):
-        _EngineVecEnv.__init__(self, env_fns, device)
+        _EngineVecEnv.__init__(self, env_fns, device, emit_graph=False)

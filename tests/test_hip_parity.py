@@ -97,6 +97,40 @@ def test_reset_and_rollout_vs_philox_oracle(N, O, W, n):
     check_state(eng, orc.st, 'end')
 
 
+@pytest.mark.parametrize('case', range(14))
+def test_random_small_configs_vs_oracle(case):
+    """Ragged / degenerate shapes and knobs: N = 1, no obstacles, walls, n_envs = 1, episode_length = 1,
+    max_speed None, odd E (one-float-per-lane emission path), both scenarios; two episodes incl. resets."""
+    rs = np.random.RandomState(1000 + case)
+    formation = case % 3 == 2
+    N = int(rs.randint(1, 10)); O = int(rs.randint(0, 5)); W = int(rs.randint(0, 3)); n = int(rs.choice([1, 2, 7, 33]))
+    ep = int(rs.choice([1, 2, 5, 9]))
+    kw = dict(num_agents=N, num_obstacles=O, episode_length=ep, max_speed=None if case % 5 == 4 else float(rs.choice([0.7, 2.0])),
+              min_dist_thresh=float(rs.choice([0.05, 0.3])), goal_rew=float(rs.choice([5, 2.5])), collision_rew=float(rs.choice([5, 1.0])))
+    seed = 77 + case
+    if formation:
+        cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_landmarks=int(rs.randint(1, 3)), **kw)
+        ocfg = fo.Config(**{k: getattr(cfg, k) for k in fo.Config.__dataclass_fields__})
+        orc = fo.OracleFormationVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep_: PhiloxStream(seed, e, ep_))
+        check = check_form_outputs
+    else:
+        cfg = fm.EnvConfig(num_landmarks=N, num_walls=W, **kw)
+        ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+        orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep_: PhiloxStream(seed, e, ep_))
+        check = check_outputs
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, async_reset=bool(case % 2))
+    obs, ids, node, adj = eng.reset()
+    o = orc.reset()
+    np.testing.assert_allclose(obs.cpu().numpy(), o[0], **OUT)
+    np.testing.assert_allclose(node.cpu().numpy(), o[2], **OUT)
+    for t in range(2 * ep + 1):
+        a = rs.randint(0, 5, size=(n, N))
+        res = eng.step(torch.as_tensor(a, device=DEV))
+        ref = orc.step(a)
+        want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
+        check(res, want, 'case %d %s step %d' % (case, cfg, t))
+
+
 def test_async_and_sync_reset_are_identical():
     """FMARL_FLAG_ASYNC_RESET (next episode staged on a side stream) must not change a single bit,
     also across masked resets and a set_state in between."""
