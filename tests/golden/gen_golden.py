@@ -14,6 +14,7 @@ Fixture families
                        after a seeded reference reset (or a crafted one), an action tape, and
                        per-step obs / node_obs / adj / reward / done / info + the final state.
   kat_world.npz        single World.step() known answers (SURVEY.md App. B KAT 1-5).
+  fnav_<case>.npz      the same for nav_fairassign_fairrew_formation_graph.
   form_<case>.npz      the same for fair_graph_formation (BASELINE config 4), form_dummy4.npz its
                        GraphDummyVecEnv x 4 run incl. auto-resets.
 """
@@ -30,6 +31,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import refharness as rh  # noqa: E402
 from oracle.nav_oracle import INFO_KEYS, State  # noqa: E402
 from oracle import formation_oracle as fo  # noqa: E402
+from oracle import fairnav_oracle as fnv  # noqa: E402
 
 rh.install_stubs()
 
@@ -184,6 +186,48 @@ def gen_formation():
     save('form_dummy4.npz', d)
 
 
+def gen_fairnav():
+    """nav_fairassign_fairrew_formation_graph (the scenario of the shipped FA / FA+FR weights)."""
+    SC = 'nav_fairassign_fairrew_formation_graph'
+    rs = np.random.RandomState(311)
+    kw = dict(info_keys=fnv.INFO_KEYS, fields=fnv.State.FIELDS)
+    cases = [  # name, N, O, W, thr, min_obs_dist, n_envs, T
+        ('n3', 3, 3, 0, 0.05, 0.5, 3, 25), ('n10', 10, 3, 0, 0.05, 0.5, 2, 20), ('n4w2', 4, 2, 2, 0.25, 0.6, 3, 30),
+        ('n7_thr035', 7, 1, 0, 0.35, 0.4, 2, 30), ('n3_thr04', 3, 2, 0, 0.4, 0.9, 3, 30), ('n2', 2, 0, 1, 0.5, 1.5, 2, 10)]
+    for name, N, O, W, thr, mod, n, T in cases:
+        args = rh.make_args(scenario_name=SC, num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W,
+                            min_dist_thresh=thr, min_obs_dist=mod)
+        actions = rs.randint(0, 5, size=(T, n, N)).astype(np.int64)
+        save('fnav_%s.npz' % name, run_traj(args, [61 + 5 * e for e in range(n)], actions, **kw))
+    from onpolicy.envs.env_wrappers import GraphDummyVecEnv
+    from multiagent.MPE_env import GraphMPEEnv
+    n, N, seed, T = 3, 3, 1, 70
+    args = rh.make_args(scenario_name=SC, num_agents=N, num_landmarks=N, num_obstacles=2, min_dist_thresh=0.3)
+
+    def fn(r):
+        def init():
+            env = GraphMPEEnv(args)
+            env.seed(seed + r * 1000)
+            return env
+        return init
+    acts = np.eye(5)[rs.randint(0, 5, size=(T, n, N))]
+    np.random.seed(seed)
+    venv = GraphDummyVecEnv([fn(r) for r in range(n)])
+    r0 = venv.reset()
+    d = dict(reset_obs=r0[0], reset_id=r0[1], reset_node_obs=r0[2], reset_adj=r0[3][:, 0], actions=acts,
+             args=np.array(json.dumps(vars(args))), seed=np.int64(seed), info_keys=np.array(fnv.INFO_KEYS))
+    keys = ('obs', 'agent_id', 'node_obs', 'adj', 'reward', 'done')
+    rec = {k: [] for k in keys + ('info', 'reset_count')}
+    for t in range(T):
+        res = venv.step(acts[t])
+        for k, v in zip(keys, res[:6]):
+            rec[k].append(v[:, 0] if k == 'adj' else v)
+        rec['info'].append(np.stack([rh.info_array(res[6][e], fnv.INFO_KEYS) for e in range(n)]))
+        rec['reset_count'].append(res[7])
+    d.update({k: np.stack(v) for k, v in rec.items()})
+    save('fnav_dummy3.npz', d)
+
+
 def gen_cfg1():
     from onpolicy.envs.env_wrappers import GraphDummyVecEnv
     from multiagent.MPE_env import GraphMPEEnv
@@ -270,7 +314,7 @@ def gen_kat_world():
 
 if __name__ == '__main__':
     assert rh.available(), 'needs /root/reference (build container only)'
-    which = sys.argv[1:] or ['kat', 'cfg1', 'traj', 'formation']
+    which = sys.argv[1:] or ['kat', 'cfg1', 'traj', 'formation', 'fairnav']
     if 'kat' in which:
         gen_kat_world()
     if 'cfg1' in which:
@@ -279,3 +323,5 @@ if __name__ == '__main__':
         gen_traj()
     if 'formation' in which:
         gen_formation()
+    if 'fairnav' in which:
+        gen_fairnav()

@@ -77,7 +77,7 @@ def make_args(**kw):
              num_obstacles=3, collaborative=False, max_speed=2, collision_rew=5, goal_rew=5,
              min_dist_thresh=0.05, use_dones=False, episode_length=25, fair_wt=1, fair_rew=1,
              max_edge_dist=1, graph_feat_type='relative', num_landmarks=3, num_walls=0, zeroshift=5,
-             algorithm_name='rmappo', env_name='GraphMPE')
+             algorithm_name='rmappo', env_name='GraphMPE', min_obs_dist=0.5)
     d.update(kw)
     return argparse.Namespace(**d)
 
@@ -125,6 +125,11 @@ def capture_state(env):
         min_time=np.array([a.goal_min_time for a in w.agents], dtype=np.float64),
         cur_step=np.int64(env.current_step),
     )
+    if hasattr(sc, 'landmark_poses_occupied'):  # nav_fairassign_fairrew_formation_graph.py scenario-level state
+        s.update(goal_occ=np.array(sc.landmark_poses_occupied, dtype=np.float64),
+                 goal_history=np.array(sc.goal_history, dtype=np.float64),
+                 goal_reached=np.array(sc.goal_reached, dtype=np.float64),
+                 status=np.array([1.0 if a.status == True else 0.0 for a in w.agents]))  # noqa: E712
     if hasattr(sc, 'expected_poses'):  # fair_graph_formation.py scenario-level state
         s.update(slot_pos=np.array(sc.expected_poses, dtype=np.float64).reshape(N, 2),
                  slot_occ=np.array(sc.expected_poses_occupied, dtype=np.float64),
@@ -165,6 +170,13 @@ def inject_state(env, s):
     w.time_taken_stddev = np.std(w.times_required)
     env.current_step = int(s['cur_step'])
     w.current_time_step = int(s['cur_step'])
+    if 'goal_occ' in s and hasattr(sc, 'landmark_poses_occupied'):
+        sc.landmark_poses = np.array(s['landmark_pos'], dtype=np.float64)
+        sc.landmark_poses_occupied = np.array(s['goal_occ'], dtype=np.float64)
+        sc.goal_history = np.array(s['goal_history'], dtype=np.float64)
+        sc.goal_reached = np.array(s['goal_reached'], dtype=np.float64)
+        for a, v in zip(w.agents, s['status']):
+            a.status = bool(v)
     if 'slot_pos' in s and hasattr(sc, 'expected_poses'):
         sc.expected_poses = np.array(s['slot_pos'], dtype=np.float64)
         sc.expected_poses_occupied = np.array(s['slot_occ'], dtype=np.float64)

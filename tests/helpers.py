@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 
+from oracle import fairnav_oracle as fnv
 from oracle import formation_oracle as fo
 from oracle import nav_oracle as no
 
@@ -46,5 +47,21 @@ def form_state_from(fx, cfg, prefix='init_'):
     n = fx[prefix + 'agent_pos'].shape[0]
     st = fo.State(cfg, n)
     for k in fo.State.FIELDS:
+        getattr(st, k)[...] = fx[prefix + k]
+    return st
+
+
+FNAV = ['fnav_n3.npz', 'fnav_n10.npz', 'fnav_n4w2.npz', 'fnav_n7_thr035.npz', 'fnav_n3_thr04.npz', 'fnav_n2.npz']
+
+
+def fnav_cfg_of(fx):
+    args = json.loads(str(fx['args']))
+    return fnv.Config(**{k: v for k, v in args.items() if k in fnv.Config.__dataclass_fields__})
+
+
+def fnav_state_from(fx, cfg, prefix='init_'):
+    n = fx[prefix + 'agent_pos'].shape[0]
+    st = fnv.State(cfg, n)
+    for k in fnv.State.FIELDS:
         getattr(st, k)[...] = fx[prefix + k]
     return st
