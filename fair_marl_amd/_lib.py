@@ -10,17 +10,18 @@ INFO_WIDTH = 14
 (F_AGENT_POS, F_AGENT_VEL, F_P_DIST, F_LANDMARK_POS, F_OBSTACLE_POS, F_WALL_AXIS, F_WALL_E0, F_WALL_E1,
  F_WALL_ORIENT, F_WALL_LENGTH, F_GOAL_MATCH, F_DISTS_TO_GOAL, F_TIMES_REQUIRED, F_DIST_LEFT,
  F_NUM_OBST_COLL, F_NUM_AGENT_COLL, F_MIN_TIME, F_CUR_STEP, F_EPISODE, F_SLOT_POS, F_SLOT_OCC,
- F_SLOT_DELTA, F_FORMATION_DONE, F_RESET_FLAG, F_STAGE_AGENT_POS, F_STAGE_LANDMARK_POS, F_STAGE_OBSTACLE_POS,
- F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, NUM_FIELDS) = range(33)
+ F_SLOT_DELTA, F_FORMATION_DONE, F_GOAL_OCC, F_GOAL_HISTORY, F_GOAL_REACHED, F_STATUS, F_RESET_FLAG, F_STAGE_AGENT_POS, F_STAGE_LANDMARK_POS, F_STAGE_OBSTACLE_POS,
+ F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, NUM_FIELDS) = range(37)
 FLAG_ASYNC_RESET = 1
 FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_e0',
                'wall_e1', 'wall_orient', 'wall_length', 'goal_match', 'dists_to_goal', 'times_required',
                'dist_left', 'num_obst_coll', 'num_agent_coll', 'min_time', 'cur_step', 'episode',
-               'slot_pos', 'slot_occ', 'slot_delta', 'formation_done', 'reset_flag', 'stage_agent_pos',
+               'slot_pos', 'slot_occ', 'slot_delta', 'formation_done', 'goal_occ', 'goal_history', 'goal_reached', 'status',
+               'reset_flag', 'stage_agent_pos',
                'stage_landmark_pos', 'stage_obstacle_pos', 'stage_wall_axis', 'stage_wall_orient', 'stage_goal_match',
                'stage_valid', 'stage_need')
 DTYPE_F64, DTYPE_I32 = 0, 1
-SCENARIOS = {'navigation_graph': 0, 'fair_graph_formation': 1}
+SCENARIOS = {'navigation_graph': 0, 'fair_graph_formation': 1, 'nav_fairassign_fairrew_formation_graph': 2}
 
 
 class FmarlConfig(C.Structure):
@@ -29,7 +30,7 @@ class FmarlConfig(C.Structure):
                 ('episode_length', C.c_int32), ('has_max_speed', C.c_int32), ('env_offset', C.c_int32),
                 ('flags', C.c_int32), ('world_size', C.c_double), ('max_speed', C.c_double),
                 ('collision_rew', C.c_double), ('goal_rew', C.c_double), ('min_dist_thresh', C.c_double),
-                ('fair_rew', C.c_double), ('zeroshift', C.c_double), ('max_edge_dist', C.c_double),
+                ('fair_rew', C.c_double), ('zeroshift', C.c_double), ('max_edge_dist', C.c_double), ('min_obs_dist', C.c_double),
                 ('seed', C.c_uint64)]
 
 

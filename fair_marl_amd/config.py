@@ -27,6 +27,7 @@ class EnvConfig:
     use_dones: bool = False
     graph_feat_type: str = 'relative'
     num_scripted_agents: int = 0
+    min_obs_dist: float = 0.5   # nav_fairassign_fairrew_formation_graph only (onpolicy/config.py:188)
 
     def __post_init__(self):
         if self.scenario_name == 'fair_graph_formation':
@@ -55,9 +56,9 @@ class EnvConfig:
     @property
     def E(self): return self.num_agents + self.num_landmarks + self.num_obstacles + self.num_walls
     @property
-    def obs_dim(self): return 7 if self.scenario_name == 'navigation_graph' else 6
+    def obs_dim(self): return {'navigation_graph': 7, 'fair_graph_formation': 6}.get(self.scenario_name, 11)
     @property
-    def node_feat(self): return 11 if self.scenario_name == 'navigation_graph' else 12
+    def node_feat(self): return {'navigation_graph': 11, 'fair_graph_formation': 12}.get(self.scenario_name, 13)
 
     def to_c(self, n_envs, seed=0, env_offset=0, async_reset=False):
         c = _lib.FmarlConfig()
@@ -74,5 +75,6 @@ class EnvConfig:
         c.collision_rew, c.goal_rew = float(self.collision_rew), float(self.goal_rew)
         c.min_dist_thresh, c.fair_rew = float(self.min_dist_thresh), float(self.fair_rew)
         c.zeroshift, c.max_edge_dist = float(self.zeroshift), float(self.max_edge_dist)
+        c.min_obs_dist = float(self.min_obs_dist)
         c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         return c

@@ -45,6 +45,10 @@ struct Params {
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
     double2 *slot_pos;
     double *slot_occ, *slot_delta, *formation_done;
+    // fairnav scenario: extra per-env LDS tables (byte offsets), knob and state
+    int n_D, n_minprox, n_occ, n_match, n_rows, n_words;
+    double min_obs_dist;
+    double *goal_occ, *goal_history, *goal_reached, *status;
     // state
     double2 *agent_pos, *agent_vel, *landmark_pos, *obstacle_pos;
     double *p_dist, *wall_axis, *wall_e0, *wall_e1, *wall_length;

@@ -1,0 +1,360 @@
+// nav_fairassign_fairrew_formation_graph (the scenario of the shipped FA / FA+FR
+// weights) on gfx950: step + reset observation.
+//
+// Restates reference multiagent/custom_scenarios/nav_fairassign_fairrew_formation_graph.py ("nf:<line>")
+// behind the shared World.step physics (fmarl_step.hip world_step_agent):
+//   nf:691-803   reward: lexicographic-fair RE-assignment every step inside reward(agent 0) (nf:704-721),
+//                stop-on-goal `status` (velocity zeroed inside reward, done per agent: environment.py:237-247,
+//                no agent-agent force afterwards: core.py:394-398), fairness term floored at -fair_rew
+//   nf:840-1000  observation (11): nearest / second nearest goal, float-valued goal occupancy and goal
+//                history mutated in agent order
+//   nf:1222-1334 graph rows (13 features); agent rows read the occupancy / history and clear the occupancy
+//                when no goal is free
+//   nf:489-590   info_callback: leave / re-enter bookkeeping
+// The reference walks the agents sequentially (environment.py:832-864).  Everything position-only is done
+// in parallel (one thread per agent; the agent x goal distance table lives in LDS); the occupancy / history
+// vectors are walked in the reference's order: iteration i = [thread i runs observation(i)'s event] barrier
+// [every thread a evaluates its row of graph_observation(i) on that snapshot] barrier [apply the rare
+// "no free goal" clear].  The per-step assignment runs the lexifair group solver on 2^k-lane groups.
+#pragma once
+#include "fmarl_dev.h"
+#include "fmarl_kernels.h"
+#include "fmarl_lexifair.hip"
+#include "fmarl_step.hip"
+
+namespace fmarl {
+
+struct NavRow { int code; float occ, hist; int pad; };   // goal of an agent row: landmark index, -1 = own position
+
+struct FairNavLds {
+    char *base;
+    const Params &p;
+    __device__ FairNavLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
+    __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
+    __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }   // (vx, vy, newly-stopped, -)
+    __device__ double *wall() const { return (double *)(base + p.lds_wall); }
+    __device__ int *flag() const { return (int *)(base + p.lds_flag); }
+    __device__ double *D() const { return (double *)(base + p.n_D); }               // [N][L] |x_a - goal_g|
+    __device__ double *minprox() const { return (double *)(base + p.n_minprox); }   // [L] min_a |x_a - goal_g|
+    __device__ double *occ() const { return (double *)(base + p.n_occ); }           // [L] landmark_poses_occupied
+    __device__ double *hist() const { return (double *)(base + p.n_occ) + p.L; }    // [L] goal_history
+    __device__ int *match() const { return (int *)(base + p.n_match); }             // [N] goal_match_index (this step)
+    __device__ NavRow *rows() const { return (NavRow *)(base + p.n_rows); }         // [N ego][N entity]
+    __device__ int *words() const { return (int *)(base + p.n_words); }             // a*, all-done, free-empty
+    __device__ bool skip() const { return *flag() != 0; }
+
+    // feature f of entity e in the row block of ego i (nf:1222-1334), ego part included
+    __device__ float node_feature(uint32_t i, uint32_t e, uint32_t f) const {
+        const uint32_t N = p.N, first_obst = p.N + p.L, first_wall = first_obst + p.O;
+        if (f == 12) return e < N ? 0.f : (e < first_obst ? 1.f : (e < first_wall ? 2.f : 3.f));
+        const double2 xi = pos()[i];
+        if (f < 2) {   // velocities as they stand when graph_observation(i) runs: reward(a <= i) may have stopped a
+            const float4 ai = agentf()[i];
+            const float vi = ai.z != 0.f ? 0.f : (f == 0 ? ai.x : ai.y);
+            if (e >= N) return 0.f - vi;
+            const float4 ae = agentf()[e];
+            const float ve = (e <= i && ae.z != 0.f) ? 0.f : (f == 0 ? ae.x : ae.y);
+            return ve - vi;
+        }
+        if (e < N && f >= 4 && f < 8) {
+            const NavRow r = rows()[i * N + e];
+            if (f == 6) return r.occ;
+            if (f == 7) return r.hist;
+            const double2 gl = r.code >= 0 ? pos()[N + r.code] : pos()[e];
+            return (float)(f == 4 ? gl.x - xi.x : gl.y - xi.y);
+        }
+        if (e >= N && f == 6) return 1.f;
+        if (e >= N && f == 7) return e < first_obst ? (float)(e - N) : (e < first_wall ? 0.f : (float)(e - first_wall));
+        if (e >= first_wall && f >= 8) {   // corners (e0, axis + w/2), (e1, axis - w/2)
+            const double *wl = wall() + (e - first_wall) * 4;
+            const double c = f == 8 ? wl[1] : (f == 9 ? wl[0] + kWallWidth / 2 : (f == 10 ? wl[2] : wl[0] - kWallWidth / 2));
+            return (float)(c - ((f & 1) ? xi.y : xi.x));
+        }
+        const double2 xe = pos()[e];
+        return (float)((f & 1) ? xe.y - xi.y : xe.x - xi.x);   // columns 2..5, 8..11: x y pairs
+    }
+};
+
+// nf:592-613 is_obstacle_collision: obstacles at 2.0 (s + s), wall boxes padded by 1.5 s
+__device__ __forceinline__ bool wall_box_hit_pad15(double2 x, double axis, double e0, double e1, int orient) {
+    const double s = 1.5 * kEntitySize;
+    const double pperp = orient == 0 ? x.y : x.x, ppar = orient == 0 ? x.x : x.y;
+    return (axis - s <= pperp) && (pperp <= axis + s) && (e0 - s <= ppar) && (ppar <= e1 + s);
+}
+
+struct ObsGoal { int goal, second; double g_occ, g_hist, second_occ; };
+
+// observation(i)'s walk over the occupancy / history vectors (nf:845-996); Drow = distances of agent i.
+__device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *occ, double *hist, int L, int i,
+                             double thr, double mod) {
+    ObsGoal out;
+    int c = 0, s2 = 0;
+    double dmin = Drow[0], d2 = 1e300;
+    for (int g = 1; g < L; ++g) {
+        const double d = Drow[g];
+        if (d < dmin) { d2 = dmin; s2 = c; dmin = d; c = g; }
+        else if (d < d2) { d2 = d; s2 = g; }
+    }
+    out.second = s2; out.second_occ = occ[s2];
+    if (dmin < mod) {
+        int chosen = c, goal = c;
+        for (int g = 0; g < L; ++g)
+            if (Drow[g] < mod && occ[g] == 1.0 && !(minprox[g] < thr)) occ[g] = minprox[g];
+        if (dmin < thr) { occ[chosen] = 1.0; hist[chosen] = (double)i; }
+        else {
+            const double closest = minprox[chosen];
+            if (occ[chosen] == 1.0) {
+                if (closest < thr) {   // somebody sits on it: nearest goal that is not marked 1
+                    int k = 0, kk = 0, best = -1;
+                    double bd = 1e300;
+                    for (int g = 0; g < L; ++g)
+                        if (occ[g] != 1.0) { if (Drow[g] < bd) { bd = Drow[g]; best = g; k = kk; } ++kk; }
+                    if (best >= 0) { goal = best; chosen = k; }   // quirk nf:888-902: the COMPACT index is used below
+                } else occ[chosen] = 1.0 - closest;
+            } else occ[chosen] = 1.0 - closest;
+        }
+        out.goal = goal; out.g_occ = occ[chosen]; out.g_hist = hist[chosen];
+    } else {
+        int best = -1;
+        double bd = 1e300;
+        for (int g = 0; g < L; ++g)
+            if (occ[g] != 1.0 && Drow[g] < bd) { bd = Drow[g]; best = g; }
+        if (best >= 0) { out.goal = best; out.g_occ = occ[best]; out.g_hist = hist[best]; }
+        else {
+            for (int g = 0; g < L; ++g) occ[g] = 0.0;
+            out.goal = -1; out.g_occ = 0.0; out.g_hist = hist[i];
+        }
+    }
+    return out;
+}
+
+template <int G>
+__device__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv) {
+    const int group = threadIdx.x / G, ngroups = kThreads / G, lane = threadIdx.x % G;
+    for (int el = group; el < nenv; el += ngroups) {
+        const FairNavLds t(p, lds, el);
+        double c[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) c[j] = (lane < p.N && j < p.N) ? t.D()[lane * p.L + j] : 0.0;
+        const int mc = lexifair_group<G>(c, p.N);
+        if (lane < p.N) t.match()[lane] = mc;
+    }
+}
+
+template <bool STEP>
+__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                           const float *action_vec, int auto_reset) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, N = p.N, L = p.L;
+    const int env0 = blockIdx.x * p.epb;
+    const int nenv = min(p.epb, p.n_envs - env0);
+    const int el = tid / N, i = tid - el * N;
+    const bool active = el < nenv;
+    const int env = env0 + el;
+    const size_t g = (size_t)env * N + i;
+    const FairNavLds t(p, lds, el);
+    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
+
+    double2 x = make_double2(0, 0), v = make_double2(0, 0);
+    double pd = 0, status = 0;
+    int step = 0;
+    if (active) {
+        x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g]; status = p.status[g];
+        t.pos()[i] = x;
+        t.occ()[i] = p.goal_occ[g]; t.hist()[i] = p.goal_history[g];   // L == N
+        step = p.cur_step[env] + (STEP ? 1 : 0);
+        if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
+    }
+    load_statics(p, lds, env0, nenv);
+    __syncthreads();
+    if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
+    __syncthreads();   // every lane has finished reading the old positions
+    if (active) t.pos()[i] = x;
+    __syncthreads();
+
+    if (active) {   // distance table and per-goal minimum over agents
+        for (int k = 0; k < L; ++k) t.D()[i * L + k] = dist2(x, t.pos()[N + k]);
+        double m = 1e300;
+        for (int a = 0; a < N; ++a) m = fmin(m, dist2(t.pos()[a], t.pos()[N + i]));
+        t.minprox()[i] = m;
+    }
+    __syncthreads();
+    if (STEP) {   // reward(agent 0): lexicographic-fair re-assignment on the new positions (nf:704-721)
+        if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv);
+        else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv);
+        else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv);
+        else fairnav_assign_tasks<32>(p, lds, nenv);
+    } else if (active) {
+        t.match()[i] = p.goal_match[g];
+    }
+    __syncthreads();
+
+    // reward's status transition (nf:726-741) and the per-agent info bookkeeping (nf:489-573) only need
+    // positions and the agent's own previous values
+    double Dg_old = 0, Tr_old = 0, Dg_new = 0, Tr_new = 0, left = 0, gr = 0, dgoal = 0;
+    bool newly = false, done = false;
+    if (active) {
+        if (STEP) {
+            dgoal = t.D()[i * L + t.match()[i]];
+            newly = dgoal < p.thr && status == 0.0;
+            if (newly) status = 1.0;
+            done = status != 0.0 || step >= p.episode_length;   // environment.py:237-247
+            if (!done) atomicAnd(&t.words()[1], 0);
+            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left = p.dist_left[g]; gr = p.goal_reached[g];
+            int near = 0;
+            double dn = t.D()[i * L];
+            for (int k = 1; k < L; ++k) { const double d = t.D()[i * L + k]; if (d < dn) { dn = d; near = k; } }
+            Dg_new = Dg_old; Tr_new = Tr_old;
+            const double now = step * kDt;
+            if (dn < p.thr && ((double)near != gr && gr != -1.0)) { gr = near; left = dn; }
+            if (dn < p.thr && Tr_new == -1.0) { Tr_new = now; Dg_new = pd; left = dn; gr = near; }
+            if (Tr_new == -1.0) { Dg_new = pd; left = dn; }
+            if (dn > p.thr && Tr_new != -1.0) { Dg_new = pd; Tr_new = now; left = dn; }
+            if (dn < p.thr && (double)near == gr) { left = dn; gr = near; }
+            s_stat[i] = pd; s_stat[N + i] = Dg_old; s_stat[2 * N + i] = Dg_new;
+            s_stat[3 * N + i] = Tr_old; s_stat[4 * N + i] = Tr_new;
+        }
+        t.agentf()[i] = make_float4((float)v.x, (float)v.y, newly ? 1.f : 0.f, 0.f);
+    }
+    __syncthreads();
+    bool emit = false;
+    if (active) {
+        emit = STEP ? !(auto_reset && t.words()[1] != 0) : p.reset_flag[env] != 0;
+        if (i == 0) *t.flag() = emit ? 0 : 1;
+    }
+
+    // ---- the sequential part: occupancy / history walk in agent order
+    ObsGoal og;
+    og.goal = -1; og.second = 0; og.g_occ = og.g_hist = og.second_occ = 0.0;
+    for (int a = 0; a < N; ++a) {
+        if (active && i == a)
+            og = obs_event(t.D() + i * L, t.minprox(), t.occ(), t.hist(), L, i, p.thr, p.min_obs_dist);
+        __syncthreads();
+        // graph_observation(a): row of entity i on the snapshot (nf:1255-1283)
+        bool far = false, free_empty = true;
+        int c = 0, best = -1;
+        if (active) {
+            const double *Drow = t.D() + i * L;
+            double dmin = Drow[0], bd = 1e300;
+            for (int k = 0; k < L; ++k) {
+                const double d = Drow[k];
+                if (d < dmin) { dmin = d; c = k; }
+                if (t.occ()[k] != 1.0) { free_empty = false; if (d < bd) { bd = d; best = k; } }
+            }
+            far = !(dmin < p.min_obs_dist);
+            if (far && free_empty) atomicMin(&t.words()[0], i);   // first entity that triggers the clear
+        }
+        __syncthreads();
+        if (active) {
+            const int astar = t.words()[0];                        // N = nobody
+            const bool cleared = free_empty && astar < i;         // an earlier entity already cleared the flags
+            NavRow r;
+            if (!far) { r.code = c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = (float)t.hist()[c]; }
+            else if (!free_empty) { r.code = best; r.occ = (float)t.occ()[best]; r.hist = (float)t.hist()[best]; }
+            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = (float)t.hist()[i]; }
+            else { r.code = c; r.occ = 0.f; r.hist = (float)t.hist()[c]; }   // after the clear every goal is free
+            r.pad = 0;
+            t.rows()[a * N + i] = r;
+        }
+        __syncthreads();
+        if (active && free_empty && t.words()[0] == i) {   // the clear itself (nf:1278), once per graph_observation
+            for (int k = 0; k < L; ++k) t.occ()[k] = 0.0;
+        }
+        __syncthreads();
+        if (active && i == 0) t.words()[0] = N;
+        // (the next iteration's first barrier orders this reset before the next atomicMin)
+    }
+
+    if (active) {
+        const double2 goal = og.goal >= 0 ? t.pos()[N + og.goal] : x;
+        const double2 sec = t.pos()[N + og.second];
+        if (o.obs && emit) {   // nf:997-1000
+            float *ob = o.obs + g * p.D;
+            ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;
+            ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)og.g_occ; ob[7] = (float)og.g_hist;
+            ob[8] = (float)(sec.x - x.x); ob[9] = (float)(sec.y - x.y); ob[10] = (float)og.second_occ;
+        }
+        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
+        if (STEP) {
+            double fairness, m, sd;   // nf:693-698, same stale / fresh rule as navigation_graph
+            if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
+            else mixed_stats(s_stat + 2 * N, s_stat + N, N, i, m, sd);
+            fairness = m / (sd + 0.0001);
+            int ag_hits = 0;
+            for (int j = 0; j < N; ++j)
+                if (j != i && closer_than(x, t.pos()[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
+            bool ob_hit = false;
+            for (int k = 0; k < p.O; ++k)
+                ob_hit |= closer_than(t.pos()[N + L + k], x, 2.0 * (kEntitySize + kEntitySize));
+            const double *wl = t.wall();
+            for (int w = 0; w < p.W; ++w)
+                ob_hit |= wall_box_hit_pad15(x, wl[w * 4], wl[w * 4 + 1], wl[w * 4 + 2], (int)wl[w * 4 + 3]);
+            double rew = 0.0;
+            if (dgoal < p.thr) { if (newly) rew += p.goal_rew; }
+            else rew -= dgoal;
+            rew -= p.collision_rew * ag_hits;
+            if (ob_hit) rew -= p.collision_rew;
+            double fr = p.fair_rew * tanh(fairness - p.zeroshift);
+            if (fr < -p.fair_rew) fr = -p.fair_rew;
+            rew = fmin(fmax(rew + fr, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
+
+            const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
+            const double2 vout = newly ? make_double2(0.0, 0.0) : v;   // nf:736-737
+            p.agent_pos[g] = x; p.agent_vel[g] = vout; p.p_dist[g] = pd; p.status[g] = status;
+            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left; p.goal_reached[g] = gr;
+            p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac; p.goal_match[g] = t.match()[i];
+            if (i == 0) p.cur_step[env] = step;
+            if (o.reward) o.reward[g] = (float)rew;
+            if (o.done) o.done[g] = done;
+            if (o.info) {   // nf:573-590
+                double dm, ds, tm, ts;
+                mixed_stats(s_stat + 2 * N, s_stat + N, N, i + 1, dm, ds);
+                mixed_stats(s_stat + 4 * N, s_stat + 3 * N, N, i + 1, tm, ts);
+                const size_t plane = (size_t)p.n_envs * N;
+                float *inf = o.info + g;
+                inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left;
+                inf[FMARL_INFO_TIME_REQ_TO_GOAL * plane] = (float)Tr_new;
+                inf[FMARL_INFO_NUM_AGENT_COLLISIONS * plane] = (float)nac;
+                inf[FMARL_INFO_NUM_OBST_COLLISIONS * plane] = (float)noc;
+                inf[FMARL_INFO_DISTANCE_MEAN * plane] = (float)dm;
+                inf[FMARL_INFO_DISTANCE_VARIANCE * plane] = (float)ds;
+                inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)(dm / (ds + 0.0001));
+                inf[FMARL_INFO_DISTS_TRAVELED * plane] = (float)Dg_new;
+                inf[FMARL_INFO_TIME_TAKEN * plane] = (float)Tr_new;   // nf:582: times_required again
+                inf[FMARL_INFO_TIME_MEAN * plane] = (float)tm;
+                inf[FMARL_INFO_TIME_STDDEV * plane] = (float)ts;
+                inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)(tm / (ts + 0.0001));
+                inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
+                inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
+            }
+        }
+    }
+    // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
+    if (o.node_obs) {
+        const uint32_t EF = p.E * p.F, NEF = N * EF, total = nenv * NEF;
+        float *dst = o.node_obs + (size_t)env0 * NEF;
+        for (uint32_t q = tid; q < total; q += kThreads) {
+            const uint32_t e_l = p.dNEF.div(q);
+            const FairNavLds te(p, lds, e_l);
+            if (te.skip()) continue;
+            const uint32_t r = q - e_l * NEF, a = p.dEF.div(r), s = r - a * EF;
+            const uint32_t e = p.dF.div(s), f = s - e * p.F;
+            dst[q] = te.node_feature(a, e, f);
+        }
+    }
+    if (o.adj) {
+        const uint32_t EE = p.E * p.E, total = nenv * EE;
+        float *dst = o.adj + (size_t)env0 * EE;
+        for (uint32_t q = tid; q < total; q += kThreads) {
+            const uint32_t e_l = p.dEE.div(q);
+            const FairNavLds te(p, lds, e_l);
+            if (te.skip()) continue;
+            const uint32_t r = q - e_l * EE, a = p.dE.div(r), b = r - a * p.E;
+            const double2 pa = te.pos()[a], pb = te.pos()[b];
+            const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
+            dst[q] = sqrtf(dx * dx + dy * dy);
+        }
+    }
+}
+
+}  // namespace fmarl

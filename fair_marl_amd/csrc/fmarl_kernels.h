@@ -23,6 +23,10 @@ __global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal
 template <bool STEP> __global__ void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                      const float *action_vec, int auto_reset);
 
+// fmarl_fairnav.hip
+template <bool STEP> __global__ void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                   const float *action_vec, int auto_reset);
+
 // fmarl_lexifair.hip
 void launch_lexifair_costs(const double *costs, int32_t *perm, int n_envs, int N, hipStream_t stream);
 void launch_lexifair_state(const Params &p, hipStream_t stream);

@@ -34,27 +34,13 @@ __device__ __forceinline__ M group_or(M v) {
 __device__ __forceinline__ int lowest_bit(uint32_t m) { return __builtin_ctz(m); }
 __device__ __forceinline__ int lowest_bit(uint64_t m) { return __builtin_ctzll(m); }
 
+// The solve itself: lane `lane` of a G-lane group holds row `lane` of the cost matrix in c[0..G) (entries
+// beyond N are ignored).  Returns the column assigned to row `lane` (valid for lane < N).
 template <int G>
-__global__ __launch_bounds__(256) void lexifair_kernel(const double *costs, const double2 *agent_pos,
-                                                       const double2 *goal_pos, int32_t *perm,
-                                                       const int *flag, int n_envs, int N) {
+__device__ int lexifair_group(const double (&c)[G], int N) {
     using M = typename MaskOf<G>::type;   // row / column sets of one group
     const M one = 1;
     const int lane = threadIdx.x % G;
-    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int env = min(grp, n_envs - 1);          // every lane stays in the shuffles
-    const bool valid = grp < n_envs && (flag == nullptr || flag[env] != 0);
-    const bool is_row = lane < N;
-
-    double c[G];   // row `lane` of the cost matrix (navigation_graph.py:555 cdist when built from positions)
-#pragma unroll
-    for (int j = 0; j < G; ++j) {
-        double v = 0.0;
-        if (is_row && j < N)
-            v = costs ? costs[((size_t)env * N + lane) * N + j]
-                      : dist2(agent_pos[(size_t)env * N + lane], goal_pos[(size_t)env * N + j]);
-        c[j] = v;
-    }
     const M full = N >= (int)(8 * sizeof(M)) ? ~(M)0 : (M)((one << N) - 1);
 
     // initial perfect matching: rows in order take their cheapest free column (any perfect matching is a
@@ -135,6 +121,28 @@ __global__ __launch_bounds__(256) void lexifair_kernel(const double *costs, cons
             C &= ~(one << cstar);
         }
     }
+    return mc;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void lexifair_kernel(const double *costs, const double2 *agent_pos,
+                                                       const double2 *goal_pos, int32_t *perm,
+                                                       const int *flag, int n_envs, int N) {
+    const int lane = threadIdx.x % G;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int env = min(grp, n_envs - 1);          // every lane stays in the shuffles
+    const bool valid = grp < n_envs && (flag == nullptr || flag[env] != 0);
+    const bool is_row = lane < N;
+    double c[G];   // row `lane` of the cost matrix (navigation_graph.py:555 cdist when built from positions)
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        double v = 0.0;
+        if (is_row && j < N)
+            v = costs ? costs[((size_t)env * N + lane) * N + j]
+                      : dist2(agent_pos[(size_t)env * N + lane], goal_pos[(size_t)env * N + j]);
+        c[j] = v;
+    }
+    const int mc = lexifair_group<G>(c, N);
     if (valid && is_row) perm[(size_t)env * N + lane] = mc;
 }
 

@@ -63,15 +63,16 @@ struct Placed {
 // navigation_graph.py:650-684 is_obstacle_collision(pos, size = 0.05)
 template <bool LDS>
 __device__ bool obstacle_hit(const Params &p, const Placed<LDS> &pl, const double *wall, double2 x) {
-    bool hit = pl.any_closer(0, p.O, x, 1.05 * (kEntitySize + kEntitySize));
     const bool plain = p.scenario == FMARL_SCENARIO_FORMATION;   // fair_graph_formation.py:518-530: no 1.05 factors
+    const bool fairnav = p.scenario == FMARL_SCENARIO_FAIRNAV;   // nav_fairassign_...py:592-613: 2.0 (s+s), walls +-1.5 s
+    bool hit = pl.any_closer(0, p.O, x, (fairnav ? 2.0 : 1.05) * (kEntitySize + kEntitySize));
     for (int w = 0; w < p.W; ++w) {
         const double axis = wall[w * 4], e0 = wall[w * 4 + 1], e1 = wall[w * 4 + 2];
         const int orient = (int)wall[w * 4 + 3];
-        const double s = kEntitySize;
+        const double s = fairnav ? 1.5 * kEntitySize : kEntitySize / 2;
         const double pperp = orient == 0 ? x.y : x.x, ppar = orient == 0 ? x.x : x.y;
-        hit |= plain ? ((axis - s / 2 <= pperp) && (pperp <= axis + s / 2) && (e0 - s / 2 <= ppar) && (ppar <= e1 + s / 2))
-                     : wall_box_hit(x, axis, e0, e1, orient);
+        hit |= (plain || fairnav) ? ((axis - s <= pperp) && (pperp <= axis + s) && (e0 - s <= ppar) && (ppar <= e1 + s))
+                                  : wall_box_hit(x, axis, e0, e1, orient);
     }
     return hit;
 }
@@ -86,8 +87,13 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     const bool stage = mode == kResetStage;
     bool doit = true;
     if (mode == kResetMask) doit = mask[env] != 0;
-    else if (mode == kResetAuto) doit = p.cur_step[env] >= p.episode_length;   // all agents done
-    else if (stage) doit = p.stage_valid[env] == 0;
+    else if (mode == kResetAuto) {   // all agents done (environment.py:237-247: status or episode length)
+        doit = p.cur_step[env] >= p.episode_length;
+        if (!doit && p.scenario == FMARL_SCENARIO_FAIRNAV) {
+            doit = true;
+            for (int i = 0; i < p.N; ++i) doit &= p.status[(size_t)env * p.N + i] != 0.0;
+        }
+    } else if (stage) doit = p.stage_valid[env] == 0;
     if (stage) p.stage_need[env] = doit ? 1 : 0;
     else p.reset_flag[env] = doit ? 1 : 0;
     if (!doit) return;
@@ -103,10 +109,12 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         episode = p.episode[env];
     }
     PhiloxStream rng(p.seed, (uint32_t)(p.env_offset + env), (uint32_t)episode);
-    if (mode == kResetInit)   // make_world: navigation_graph.py:183-185
+    const bool formation = p.scenario == FMARL_SCENARIO_FORMATION, fairnav = p.scenario == FMARL_SCENARIO_FAIRNAV;
+    if (mode == kResetInit)   // make_world: navigation_graph.py:183-185 (fairnav draws U(0.2, 0.4) there, then redraws)
+        p.wall_length[env] = rng.uniform(0.2, fairnav ? 0.4 : 0.8) * p.world_size / 4;
+    if (fairnav)              // nav_fairassign_...py:239-241: wall_length is drawn again at every reset_world
         p.wall_length[env] = rng.uniform(0.2, 0.8) * p.world_size / 4;
     const double ws = p.world_size, wlen = p.wall_length[env];
-    const bool formation = p.scenario == FMARL_SCENARIO_FORMATION;
     const double goal_scale = formation ? 0.5 : 0.8;   // fair_graph_formation.py:363 vs navigation_graph.py:492
 
     if (!stage) {
@@ -132,6 +140,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         else { wall[4] = axis; wall[5] = -wlen; wall[6] = wlen; wall[7] = orient; }
     }
     const double thr = 1.05 * (kEntitySize + kEntitySize);
+    const double thr_goal = (fairnav ? 1.2 : 1.05) * (kEntitySize + kEntitySize);   // nav_fairassign_...py:643
     for (int k = 0, tries = 0; k < N;) {   // :389-457
         double2 x = rng.uniform_pair(-ws / 2, ws / 2);
         ++tries;
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         double2 x = make_double2(goal_scale * u.x, goal_scale * u.y);
         ++tries;
         bool bad = obstacle_hit(p, pl, wall, x);
-        bad |= pl.any_closer(2, k, x, thr);   // :707-716
+        bad |= pl.any_closer(2, k, x, thr_goal);   // :707-716
         if (!bad || tries >= kMaxTries) { pl.set_landmark(k, x); ++k; tries = 0; }
     }
     if (stage) return;   // min_time, episode counter: reset_commit_kernel
@@ -168,6 +177,11 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
             const double2 P = make_double2(L0.x + 0.5 * cos(ang), L0.y + 0.5 * sin(ang));
             p.slot_pos[a0 + i] = P; p.slot_occ[a0 + i] = 0.0; p.formation_done[a0 + i] = 0.0;
             if (p.has_max_speed) p.min_time[a0 + i] = dist2(pl.g_agent(i), P) / p.max_speed;
+        }
+    } else if (fairnav) {   // nav_fairassign_...py:233-238, :446-459: goal_match reset to arange BEFORE min_time
+        for (int i = 0; i < N; ++i) {
+            p.goal_occ[a0 + i] = 0.0; p.goal_history[a0 + i] = -1.0; p.goal_reached[a0 + i] = -1.0; p.status[a0 + i] = 0.0;
+            if (p.has_max_speed) p.min_time[a0 + i] = dist2(pl.g_agent(i), pl.g_landmark(i)) / p.max_speed;
         }
     } else if (p.has_max_speed) {   // :545-547, :719-728 -- previous episode's goal_match_index
         for (int i = 0; i < N; ++i)

@@ -216,7 +216,7 @@ __device__ __forceinline__ void mixed_stats(const double *fresh, const double *s
 // the LDS entity table (positions of the PREVIOUS step), integrate (core.py:338-356).  Updates x, v, pd.
 __device__ __forceinline__ void world_step_agent(const Params &p, const char *base, int i, size_t g,
                                                  const int32_t *action_idx, const float *action_vec,
-                                                 double2 &x, double2 &v, double &pd) {
+                                                 double2 &x, double2 &v, double &pd, bool agent_forces = true) {
     const double2 *s_pos = (const double2 *)(base + p.lds_pos);
     double ux, uy;
     if (action_idx) {
@@ -233,6 +233,7 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
     const int first_obst = p.N + p.L, first_wall = first_obst + p.O;
     for (int b = 0; b < ((p.ablate & 1) ? 0 : p.E); ++b) {
         if (b == i || (b >= p.N && b < first_obst)) continue;   // self; landmarks do not collide
+        if (b < p.N && !agent_forces) continue;                 // status == True: core.py:394-398
         const double2 q = s_pos[b];
         const double dx = x.x - q.x, dy = x.y - q.y;
         const double d2 = dx * dx + dy * dy;

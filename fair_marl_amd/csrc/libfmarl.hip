@@ -10,6 +10,7 @@
 #include "fmarl_reset.hip"
 #include "fmarl_lexifair.hip"
 #include "fmarl_formation.hip"
+#include "fmarl_fairnav.hip"
 #include "fmarl_graph.hip"
 
 using namespace fmarl;
@@ -38,7 +39,9 @@ bool config_ok(const FmarlConfig *c, const char **why) {
     *why = "";
     if (!c) { *why = "null config"; return false; }
     const bool form = c->scenario == FMARL_SCENARIO_FORMATION;
-    if (c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH && !form) { *why = "unsupported scenario"; return false; }
+    const bool fnav = c->scenario == FMARL_SCENARIO_FAIRNAV;
+    if (c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH && !form && !fnav) { *why = "unsupported scenario"; return false; }
+    if (fnav && (c->num_agents < 2 || c->num_agents > 32)) { *why = "nav_fairassign_fairrew_formation_graph needs 2..32 agents"; return false; }
     if (c->n_envs < 1) { *why = "n_envs < 1"; return false; }
     if (c->num_agents < 1 || c->num_agents > (form ? 32 : 64)) { *why = "num_agents must be in 1..64 (formation: 1..32)"; return false; }
     if (!form && c->num_landmarks != c->num_agents) { *why = "navigation_graph needs num_landmarks == num_agents"; return false; }
@@ -68,8 +71,11 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     set(FMARL_F_SLOT_OCC, form ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_SLOT_DELTA, form ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_FORMATION_DONE, form ? n * N : 0, FMARL_DTYPE_F64);
+    const bool fnav = c->scenario == FMARL_SCENARIO_FAIRNAV;
+    set(FMARL_F_GOAL_OCC, fnav ? n * N : 0, FMARL_DTYPE_F64);     set(FMARL_F_GOAL_HISTORY, fnav ? n * N : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_GOAL_REACHED, fnav ? n * N : 0, FMARL_DTYPE_F64); set(FMARL_F_STATUS, fnav ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_RESET_FLAG, n, FMARL_DTYPE_I32);
-    const bool async = (c->flags & FMARL_FLAG_ASYNC_RESET) && !form;
+    const bool async = (c->flags & FMARL_FLAG_ASYNC_RESET) && !form && !fnav;
     set(FMARL_F_STAGE_AGENT_POS, async ? n * N * 2 : 0, FMARL_DTYPE_F64);
     set(FMARL_F_STAGE_LANDMARK_POS, async ? n * L * 2 : 0, FMARL_DTYPE_F64);
     set(FMARL_F_STAGE_OBSTACLE_POS, async ? n * O * 2 : 0, FMARL_DTYPE_F64);
@@ -122,6 +128,8 @@ Params bind(const Handle *h, void *state) {
     p.episode = (int *)(s + o[FMARL_F_EPISODE]);               p.reset_flag = (int *)(s + o[FMARL_F_RESET_FLAG]);
     p.slot_pos = (double2 *)(s + o[FMARL_F_SLOT_POS]);         p.slot_occ = (double *)(s + o[FMARL_F_SLOT_OCC]);
     p.slot_delta = (double *)(s + o[FMARL_F_SLOT_DELTA]);      p.formation_done = (double *)(s + o[FMARL_F_FORMATION_DONE]);
+    p.goal_occ = (double *)(s + o[FMARL_F_GOAL_OCC]);          p.goal_history = (double *)(s + o[FMARL_F_GOAL_HISTORY]);
+    p.goal_reached = (double *)(s + o[FMARL_F_GOAL_REACHED]);  p.status = (double *)(s + o[FMARL_F_STATUS]);
     p.st_agent_pos = (double2 *)(s + o[FMARL_F_STAGE_AGENT_POS]);   p.st_landmark_pos = (double2 *)(s + o[FMARL_F_STAGE_LANDMARK_POS]);
     p.st_obstacle_pos = (double2 *)(s + o[FMARL_F_STAGE_OBSTACLE_POS]); p.st_wall_axis = (double *)(s + o[FMARL_F_STAGE_WALL_AXIS]);
     p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
@@ -172,10 +180,13 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
         if (form)
             hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
                                (const int32_t *)nullptr, (const float *)nullptr, 0);
+        else if (p.scenario == FMARL_SCENARIO_FAIRNAV)
+            hipLaunchKernelGGL(fairnav_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
+                               (const int32_t *)nullptr, (const float *)nullptr, 0);
         else
             hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
-    } else if (form && mode != kResetInit) {
-        return fail(FMARL_EINVAL, "fmarl_reset: fair_graph_formation needs output buffers (the reset observation updates the slot flags)");
+    } else if ((form || p.scenario == FMARL_SCENARIO_FAIRNAV) && mode != kResetInit) {
+        return fail(FMARL_EINVAL, "fmarl_reset: this scenario needs output buffers (its reset observation updates scenario state)");
     }
     HIP_OK(hipGetLastError());
     if (h->async) return launch_stage(h, state, st);
@@ -220,7 +231,9 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     memset(&p, 0, sizeof p);
     p.n_envs = cfg->n_envs; p.N = cfg->num_agents; p.L = cfg->num_landmarks; p.O = cfg->num_obstacles;
     const bool form = cfg->scenario == FMARL_SCENARIO_FORMATION;
-    p.W = cfg->num_walls; p.E = p.N + p.L + p.O + p.W; p.D = form ? 6 : 7; p.F = form ? 12 : 11;
+    const bool fnav = cfg->scenario == FMARL_SCENARIO_FAIRNAV;
+    p.W = cfg->num_walls; p.E = p.N + p.L + p.O + p.W; p.D = form ? 6 : (fnav ? 11 : 7); p.F = form ? 12 : (fnav ? 13 : 11);
+    p.min_obs_dist = cfg->min_obs_dist;
     p.episode_length = cfg->episode_length; p.has_max_speed = cfg->has_max_speed; p.env_offset = cfg->env_offset;
     p.scenario = cfg->scenario;
     p.world_size = cfg->world_size; p.max_speed = cfg->max_speed; p.collision_rew = cfg->collision_rew;
@@ -230,7 +243,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     int off = 0;
     p.lds_pos = off;    off = align16(off + p.E * 16);
     p.lds_agentf = off; off = align16(off + p.N * 16);
-    p.lds_ego = off;    off = align16(off + (form ? 0 : p.N * kEgoWidth * 4));
+    p.lds_ego = off;    off = align16(off + ((form || fnav) ? 0 : p.N * kEgoWidth * 4));
     p.lds_stat = off;   off = align16(off + 5 * p.N * 8);
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 4);
@@ -241,6 +254,14 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.f_masks = off;    off = align16(off + 4 * p.N * 4);
         p.f_theta = off;    off = align16(off + p.N * 8);
         p.f_words = off;    off = align16(off + 16);
+    }
+    if (fnav) {   // fmarl_fairnav.hip FairNavLds
+        p.n_D = off;       off = align16(off + p.N * p.L * 8);
+        p.n_minprox = off; off = align16(off + p.L * 8);
+        p.n_occ = off;     off = align16(off + 2 * p.L * 8);
+        p.n_match = off;   off = align16(off + p.N * 4);
+        p.n_rows = off;    off = align16(off + p.N * p.N * 16);
+        p.n_words = off;   off = align16(off + 16);
     }
     p.lds_env_bytes = off;
     int epb = kThreads / p.N;
@@ -259,7 +280,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
     p.dLO.set(p.L + p.O > 0 ? p.L + p.O : 1);
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
-    p.vec_node = !form && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
+    p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
     p.vec_adj = p.E % 4 == 0;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
@@ -274,6 +295,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)fairnav_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)fairnav_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
     }
     h->place_lds = (size_t)(p.O + p.N + p.L) * 64 * sizeof(float2);
@@ -282,7 +305,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         hipFuncSetAttribute((const void *)reset_place_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h->place_lds) != hipSuccess)
         h->place_lds = 0;
-    h->async = (cfg->flags & FMARL_FLAG_ASYNC_RESET) && !form;
+    h->async = (cfg->flags & FMARL_FLAG_ASYNC_RESET) && !form && !fnav;
     h->stage_dirty = true;   // nothing staged yet
     h->side = nullptr; h->ev_commit = h->ev_staged = nullptr;
     if (h->async) {
@@ -347,7 +370,8 @@ int fmarl_init_state(void *handle, void *state, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(hipMemsetAsync(state, 0, h->layout.total, st));
     int rc = launch_reset(h, state, kResetInit, nullptr, nullptr, st);
-    h->lockstep = true; h->host_step = 0;
+    h->lockstep = h->cfg.scenario != FMARL_SCENARIO_FAIRNAV;   // fairnav episodes end early, env by env
+    h->host_step = 0;
     return rc;
 }
 
@@ -355,7 +379,7 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlO
     Handle *h = (Handle *)handle;
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_reset: null argument");
     int rc = launch_reset(h, state, env_mask ? kResetMask : kResetAll, env_mask, outs, (hipStream_t)stream);
-    if (env_mask) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
+    if (env_mask || h->cfg.scenario == FMARL_SCENARIO_FAIRNAV) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
     return rc;
 }
 
@@ -369,7 +393,10 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     Params p = bind(h, state);
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
-    if (p.scenario == FMARL_SCENARIO_FORMATION)
+    if (p.scenario == FMARL_SCENARIO_FAIRNAV)
+        hipLaunchKernelGGL(fairnav_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
+                           action_vec, auto_reset ? 1 : 0);
+    else if (p.scenario == FMARL_SCENARIO_FORMATION)
         hipLaunchKernelGGL(formation_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
                            action_vec, auto_reset ? 1 : 0);
     else

@@ -113,7 +113,8 @@ class RolloutEngine:
                     wall_length=(n,), goal_match=(n, N), dists_to_goal=(n, N), times_required=(n, N),
                     dist_left=(n, N), num_obst_coll=(n, N), num_agent_coll=(n, N), min_time=(n, N),
                     cur_step=(n,), episode=(n,), slot_pos=(n, N, 2), slot_occ=(n, N), slot_delta=(n, N),
-                    formation_done=(n, N), reset_flag=(n,), stage_agent_pos=(n, N, 2), stage_landmark_pos=(n, L, 2),
+                    formation_done=(n, N), goal_occ=(n, N), goal_history=(n, N), goal_reached=(n, N), status=(n, N),
+                    reset_flag=(n,), stage_agent_pos=(n, N, 2), stage_landmark_pos=(n, L, 2),
                     stage_obstacle_pos=(n, O, 2), stage_wall_axis=(n, W), stage_wall_orient=(n, W),
                     stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,))
 

@@ -32,6 +32,7 @@ extern "C" {
 
 #define FMARL_SCENARIO_NAVIGATION_GRAPH 0   /* multiagent/custom_scenarios/navigation_graph.py */
 #define FMARL_SCENARIO_FORMATION 1          /* multiagent/custom_scenarios/fair_graph_formation.py */
+#define FMARL_SCENARIO_FAIRNAV 2            /* multiagent/custom_scenarios/nav_fairassign_fairrew_formation_graph.py */
 
 /* FmarlConfig.flags.  ASYNC_RESET: the next episode's placement + fair assignment (a pure function of
  * seed, env and episode index) is computed ahead of time on a library-owned side stream while the current
@@ -61,6 +62,7 @@ typedef struct FmarlConfig {
     double fair_rew;
     double zeroshift;
     double max_edge_dist;
+    double min_obs_dist;     /* FAIRNAV only (onpolicy/config.py:188) */
     uint64_t seed;           /* Philox key; env e, episode k draw from counter (i, env_offset+e, k, TAG) */
 } FmarlConfig;
 
@@ -71,8 +73,8 @@ typedef struct FmarlConfig {
  * record planes instead of per-agent dicts (navigation_graph.py:625-647).  Any pointer may be NULL
  * to skip that output. */
 typedef struct FmarlOutputs {
-    float *obs;          /* (n, N, D)        D = 7 navigation_graph / 6 formation            */
-    float *node_obs;     /* (n, N, E, F)     F = 11 / 12, E = N + L + O + W                   */
+    float *obs;          /* (n, N, D)        D = 7 navigation_graph / 6 formation / 11 fairnav */
+    float *node_obs;     /* (n, N, E, F)     F = 11 / 12 / 13, E = N + L + O + W              */
     float *adj;          /* (n, E, E)        cached_dist_mag, multiagent/core.py:204-228      */
     float *reward;       /* (n, N)                                                            */
     uint8_t *done;       /* (n, N)           environment.py:237-247                           */
@@ -120,6 +122,10 @@ enum {
     FMARL_F_SLOT_OCC,          /* f64 (n, N)     formation: scenario.expected_poses_occupied */
     FMARL_F_SLOT_DELTA,        /* f64 (n, N)     formation: scenario.delta_dists            */
     FMARL_F_FORMATION_DONE,    /* f64 (n, N)     formation: world.formation_complete        */
+    FMARL_F_GOAL_OCC,          /* f64 (n, N)     fairnav: scenario.landmark_poses_occupied  */
+    FMARL_F_GOAL_HISTORY,      /* f64 (n, N)     fairnav: scenario.goal_history             */
+    FMARL_F_GOAL_REACHED,      /* f64 (n, N)     fairnav: scenario.goal_reached             */
+    FMARL_F_STATUS,            /* f64 (n, N)     fairnav: agent.status (0 / 1)              */
     FMARL_F_RESET_FLAG,        /* i32 (n)        internal: envs picked by the last reset launch */
     FMARL_F_STAGE_AGENT_POS,   /* f64 (n, N, 2)  staged next episode (FMARL_FLAG_ASYNC_RESET) ...          */
     FMARL_F_STAGE_LANDMARK_POS,/* f64 (n, L, 2)                                                            */

@@ -478,3 +478,66 @@ def test_formation_full_size_cfg4():
     adj_env = eng.adj_env
     assert torch.equal(adj_env, adj_env.transpose(1, 2)) and (torch.diagonal(adj_env, dim1=1, dim2=2) == 0).all()
     assert torch.isfinite(eng.node_obs).all()
+
+
+# ------------------------------------------------------------------ nav_fairassign_fairrew_formation_graph
+from oracle import fairnav_oracle as fnv  # noqa: E402
+from helpers import FNAV, fnav_cfg_of, fnav_state_from  # noqa: E402
+
+
+def fnav_env_cfg(ocfg):
+    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__})
+
+
+@pytest.mark.parametrize('name', FNAV)
+def test_fairnav_golden_trajectory(name):
+    fx = load(name)
+    ocfg = fnav_cfg_of(fx)
+    st = fnav_state_from(fx, ocfg)
+    n = st.agent_pos.shape[0]
+    eng = fm.RolloutEngine(fnav_env_cfg(ocfg), n, device=DEV)
+    eng.set_state({k: getattr(st, k) for k in fnv.State.FIELDS if k != 'time'})
+    for t in range(fx['actions'].shape[0]):
+        got = eng.step(fx['actions'][t], auto_reset=False)
+        want = {k: fx[k][t] for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
+        check_outputs(got, want, '%s step %d' % (name, t))
+    final = eng.get_state()
+    for k in fnv.State.FIELDS:
+        if k != 'time':
+            np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
+
+
+@pytest.mark.parametrize('N,O,W,thr,mod,n', [(3, 3, 0, 0.05, 0.5, 150), (10, 3, 0, 0.05, 0.5, 40), (5, 2, 2, 0.3, 0.6, 64),
+                                             (7, 1, 1, 0.4, 0.3, 33), (20, 2, 0, 0.1, 0.5, 6)])
+def test_fairnav_reset_and_rollout_vs_philox_oracle(N, O, W, thr, mod, n):
+    """Device reset + 40 steps; with the larger thresholds agents reach their goals, get `status`, and envs
+    end their episodes early at different steps (per-env auto-reset)."""
+    seed = 500 + N
+    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=N, num_landmarks=N,
+                       num_obstacles=O, num_walls=W, min_dist_thresh=thr, min_obs_dist=mod)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
+    ocfg = fnv.Config(**{k: getattr(cfg, k) for k in fnv.Config.__dataclass_fields__})
+    orc = fnv.OracleFairNavVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    obs, ids, node, adj = eng.reset()
+    o = orc.reset()
+    got = eng.get_state()
+    for k in ('agent_pos', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_orient', 'wall_length', 'goal_match', 'min_time'):
+        assert np.array_equal(got[k], getattr(orc.st, k)), k
+    np.testing.assert_allclose(obs.cpu().numpy(), o[0], **OUT)
+    np.testing.assert_allclose(node.cpu().numpy(), o[2], **OUT)
+    np.testing.assert_allclose(adj.cpu().numpy(), o[3], **OUT)
+    rs = np.random.RandomState(N)
+    early = 0
+    for t in range(40):
+        a = rs.randint(0, 5, size=(n, N))
+        res = eng.step(torch.as_tensor(a, device=DEV))
+        ref = orc.step(a)
+        want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
+        check_outputs(res, want, 'fairnav N=%d step %d' % (N, t))
+        early += int((ref[5].all(axis=1) & ((t + 1) % 25 != 0)).sum())
+    got = eng.get_state()
+    for k in fnv.State.FIELDS:
+        if k != 'time':
+            np.testing.assert_allclose(got[k], getattr(orc.st, k), err_msg='end ' + k, **STATE)
+    if thr >= 0.4:
+        assert early > 0   # some envs did finish early
