@@ -20,7 +20,7 @@ DEV = 'cuda:0'
 
 
 def env_cfg(ocfg):
-    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__})
+    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__ if hasattr(ocfg, k)})
 
 
 def oracle_state_dict(st):
@@ -388,7 +388,7 @@ FORM_INFO = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13]   # record slots of fo.INFO_K
 
 
 def form_env_cfg(ocfg):
-    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__})
+    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__ if hasattr(ocfg, k)})
 
 
 def check_form_outputs(got, want, msg=''):
@@ -486,7 +486,7 @@ from helpers import FNAV, fnav_cfg_of, fnav_state_from  # noqa: E402
 
 
 def fnav_env_cfg(ocfg):
-    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__})
+    return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__ if hasattr(ocfg, k)})
 
 
 @pytest.mark.parametrize('name', FNAV)
