@@ -42,6 +42,10 @@ CONFIGS = {
     'cfg4': dict(workload='fair_graph_formation, 10 agents + 1 landmark + 3 obstacles + 2 walls (E=16), 65536 envs per GPU',
                  env=dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3),
                  n_envs=65536, cpu_envs=16, cpu_episodes=4),
+    # the shipped FA+FR weights' configuration (model_weights/FA+FR/config.yaml)
+    'fnav': dict(workload='nav_fairassign_fairrew_formation_graph, 3 agents + 3 obstacles (E=9), 65536 envs per GPU',
+                 env=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3,
+                          num_obstacles=3, goal_rew=30.0, collision_rew=30.0), n_envs=65536, cpu_envs=32, cpu_episodes=4),
     # BASELINE.json configs[1]
     'cfg2': dict(workload='navigation_graph, 3 agents + 3 obstacles (E=9), 4096 envs per GPU',
                  env=dict(num_agents=3, num_landmarks=3, num_obstacles=3), n_envs=4096, cpu_envs=512, cpu_episodes=20),
@@ -63,11 +67,15 @@ def algorithmic_bytes(cfg, emit=True):
 
 def cpu_baseline(cfg, n_envs, episodes):
     """The oracle (NumPy float64 restatement, single core) on a bounded sample of the same workload."""
+    from oracle import fairnav_oracle as fnv
     from oracle import formation_oracle as fo
     from oracle import nav_oracle as no
     from oracle.philox import PhiloxStream
     streams = lambda e, ep: PhiloxStream(1, e, ep)  # noqa: E731
-    if cfg.scenario_name == 'fair_graph_formation':
+    if cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph':
+        ocfg = fnv.Config(**{k: getattr(cfg, k) for k in fnv.Config.__dataclass_fields__})
+        env = fnv.OracleFairNavVecEnv(ocfg, n_envs, mode='subproc', streams=streams)
+    elif cfg.scenario_name == 'fair_graph_formation':
         ocfg = fo.Config(**{k: getattr(cfg, k) for k in fo.Config.__dataclass_fields__})
         env = fo.OracleFormationVecEnv(ocfg, n_envs, mode='subproc', streams=streams)
     else:
@@ -163,7 +171,7 @@ def main():
         # dominant kernel = step_kernel.  Launches on episode-end steps do not emit obs/node_obs/adj
         # (the reset path does), so their algorithmic bytes are the state + reward part only.
         ep = cfg.episode_length
-        resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)
+        resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
         bytes_per_launch = agents * (algorithmic_bytes(cfg) * (K - resets) + algorithmic_bytes(cfg, emit=False) * resets) / K
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
@@ -179,11 +187,12 @@ def main():
             'dtype': 'f64 state and contact math, f32 outputs', 'data': 'synthetic',
             'config': {'workload': spec['workload'], 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
-                       'reset': 'synchronous' if args.sync_reset else 'next episode staged on a side stream, committed at episode end',
+                       'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
+                                 else 'next episode staged on a side stream, committed at episode end'),
                        'exchange': ('RCCL gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'formation_kernel<true>' if cfg.scenario_name == 'fair_graph_formation' else 'step_kernel',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}.get(cfg.scenario_name, 'step_kernel'),
                          'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
