@@ -74,4 +74,26 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const float *adj, const 
     }
 }
 
+// Per-agent means over the envs of every info field, reference onpolicy/runner/shared/base_runner.py:197-276
+// process_infos + :291-306 log_env (np.mean of each per-agent list); Time_req_to_goal == -1 counts as
+// episode_length * dt (:212-215).  One workgroup per (field, agent); f64 tree reduction, deterministic.
+__global__ __launch_bounds__(256) void info_mean_kernel(const float *info, double *out, int n_envs, int N, double unreached_time) {
+    __shared__ double part[256];
+    const int k = blockIdx.x / N, a = blockIdx.x - k * N;
+    const float *src = info + (size_t)k * n_envs * N + a;
+    double s = 0.0;
+    for (int e = threadIdx.x; e < n_envs; e += 256) {
+        double v = (double)src[(size_t)e * N];
+        if (k == FMARL_INFO_TIME_REQ_TO_GOAL && v == -1.0) v = unreached_time;
+        s += v;
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0] / n_envs;
+}
+
 }  // namespace fmarl

@@ -474,4 +474,12 @@ int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_inde
     return FMARL_OK;
 }
 
+int fmarl_info_means(const float *info, double *means, int n_envs, int num_agents, double unreached_time, void *stream) {
+    if (!info || !means || n_envs < 1 || num_agents < 1) return fail(FMARL_EINVAL, "fmarl_info_means: bad argument");
+    hipLaunchKernelGGL(info_mean_kernel, dim3(FMARL_INFO_WIDTH * num_agents), dim3(256), 0, (hipStream_t)stream, info, means,
+                       n_envs, num_agents, unreached_time);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
 }  // extern "C"

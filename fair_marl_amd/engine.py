@@ -238,6 +238,27 @@ class RolloutEngine:
                                                     self._stream()), 'fmarl_edge_fill')
         return ei, ea, offsets
 
+    def process_infos(self, dt=0.1):
+        """Episode metrics as the reference logs them (onpolicy/runner/shared/base_runner.py:197-306
+        process_infos + log_env): dict 'agent<i>/<name>' -> mean over the envs of the last step's info,
+        with Time_req_to_goal == -1 counted as episode_length * dt.  Reduced on the device."""
+        from .infos import key_map
+        if self.outs.info_planes is None:
+            raise RuntimeError('engine was created with emit_info=False')
+        N = self.cfg.N
+        means = torch.empty(_lib.INFO_WIDTH, N, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_info_means(self.outs.info_planes.data_ptr(), means.data_ptr(), self.n_envs, N,
+                                                 float(self.cfg.episode_length * dt), self._stream()), 'fmarl_info_means')
+        m = means.cpu().numpy()
+        names = {'individual_reward': 'individual_rewards', 'Time_req_to_goal': 'time_to_goal', 'Dist_to_goal': 'dist_to_goal',
+                 'Num_agent_collisions': 'num_agent_collisions', 'Num_obst_collisions': 'num_obstacle_collisions',
+                 'Min_time_to_goal': 'min_time_to_goal', 'Distance_mean': 'distance_mean', 'Distance_variance': 'distance_variance',
+                 'Mean_by_variance': 'mean_variance', 'Dists_traveled': 'dists_traveled', 'Time_taken': 'time_taken',
+                 'Formation_dist': 'formation_dist', 'Time_mean': 'time_mean', 'Time_stddev': 'time_variance',
+                 'Time_mean_by_stddev': 'time_mn_by_stddev'}
+        return {'agent%d/%s' % (a, names[k]): float(m[slot, a]) for a in range(N) for k, slot in key_map(self.cfg.scenario_name)}
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, capacity):
         """Record a hipEvent pair around each of the next ``capacity`` step-kernel launches (0 = off)."""

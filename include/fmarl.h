@@ -215,6 +215,11 @@ int fmarl_edge_count(const float *adj, int32_t *nnz, int n_envs, int num_entitie
 int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr, int64_t total,
                     int n_graphs, int graphs_per_env, int num_entities, double max_edge_dist, int strict, void *stream);
 
+/* Per-agent means over the envs of every info field = what process_infos + log_env report
+ * (onpolicy/runner/shared/base_runner.py:197-306); Time_req_to_goal == -1 counts as unreached_time
+ * (= episode_length * dt, :212-215).  info f32 (FMARL_INFO_WIDTH, n, N) -> means f64 (FMARL_INFO_WIDTH, N). */
+int fmarl_info_means(const float *info, double *means, int n_envs, int num_agents, double unreached_time, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

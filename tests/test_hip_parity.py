@@ -283,6 +283,26 @@ def test_device_rollout_buffer_matches_reference_insert():
             buf.insert_step(a)
 
 
+def test_process_infos_matches_reference_logging():
+    """base_runner.py:197-306 process_infos + log_env restated with NumPy on the same info records."""
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=2, min_dist_thresh=0.3)
+    n = 300
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=2)
+    eng.reset()
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    for t in range(12):
+        res = eng.step(torch.randint(0, 5, (n, 4), device=DEV, generator=g, dtype=torch.int32))
+    info = res[6].cpu().numpy().astype(np.float64)    # (n, N, 14)
+    got = eng.process_infos()
+    t_req = info[..., 1].copy(); t_req[t_req == -1] = cfg.episode_length * 0.1
+    for a in range(4):
+        assert abs(got['agent%d/individual_rewards' % a] - info[:, a, 13].mean()) < 1e-9
+        assert abs(got['agent%d/time_to_goal' % a] - t_req[:, a].mean()) < 1e-9
+        assert abs(got['agent%d/mean_variance' % a] - info[:, a, 6].mean()) < 1e-6
+        assert abs(got['agent%d/num_agent_collisions' % a] - info[:, a, 2].mean()) < 1e-9
+    assert len(got) == 4 * 14 and (t_req != info[..., 1]).any()
+
+
 def test_vec_env_wrappers_api():
     """Names / arities / dtypes of the reference wrappers (env_wrappers.py:895-1026) on the HIP engine."""
     import argparse
