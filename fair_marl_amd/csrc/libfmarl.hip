@@ -278,7 +278,6 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     const uint64_t NEF = (uint64_t)p.N * p.E * p.F, maxq = (uint64_t)epb * NEF;
     if (maxq >= (1ull << 24) || maxq * NEF >= (1ull << 40)) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large"); }
     p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
-    p.dLO.set(p.L + p.O > 0 ? p.L + p.O : 1);
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
     p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
     p.vec_adj = p.E % 4 == 0;
