@@ -35,7 +35,7 @@ def counter_mean(path, kernel, counter):
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, cfg)))
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
-kname = 'formation_kernel<true>' if cfg == 'cfg4' else 'step_kernel'
+kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, 'step_kernel')
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
 w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), kname, 'WRITE_SIZE')
 traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
