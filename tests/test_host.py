@@ -63,6 +63,35 @@ def test_state_layout_and_config_validation(lib):
     assert lib.fmarl_destroy(ok) == 0
 
 
+def test_entry_points_validate_arguments_on_the_host(lib):
+    """Bad arguments are refused with FMARL_EINVAL + a message before anything is launched."""
+    import fair_marl_amd as fm
+    c = fm.EnvConfig(num_agents=3, num_landmarks=3).to_c(8)
+    h = C.c_void_p()
+    assert lib.fmarl_create(C.byref(c), C.byref(h)) == 0
+    assert lib.fmarl_step(h, None, None, None, None, 1, None) == 1 and b'null' in lib.fmarl_last_error()
+    assert lib.fmarl_reset(h, None, None, None, None) == 1
+    assert lib.fmarl_init_state(h, None, None) == 1
+    assert lib.fmarl_profile_enable(h, -1) == 1
+    assert lib.fmarl_lexifair(None, None, 4, 3, None) == 1
+    buf = (C.c_double * 8)()
+    assert lib.fmarl_lexifair(buf, buf, 1, 65, None) == 1 and b'64' in lib.fmarl_last_error()
+    assert lib.fmarl_cost_matrix(None, None, None, 1, 1, 1, None) == 1
+    assert lib.fmarl_update_graph(None, None, None, None, 1, 1, 1.0, None) == 1
+    assert lib.fmarl_edge_count(None, None, 1, 1, 1.0, 1, None) == 1
+    assert lib.fmarl_info_means(None, None, 1, 1, 2.5, None) == 1
+    assert lib.fmarl_state_changed(None) == 1
+    assert lib.fmarl_destroy(h) == 0
+    for kw, msg in ((dict(num_agents=0, num_landmarks=0), b'num_agents'), (dict(num_agents=3, num_landmarks=3, num_walls=3), b'num_walls'),
+                    (dict(num_agents=3, num_landmarks=3, episode_length=0), b'episode_length')):
+        bad = fm.EnvConfig(**kw).to_c(4)
+        assert lib.fmarl_create(C.byref(bad), C.byref(h)) == 1 and msg in lib.fmarl_last_error()
+    one = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=1, num_landmarks=1).to_c(4)
+    assert lib.fmarl_create(C.byref(one), C.byref(h)) == 1   # the scenario needs a second-nearest goal
+    form = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1).to_c(16)
+    assert form.num_walls == 2 and lib.fmarl_state_bytes(C.byref(form)) > 0
+
+
 def test_engine_refuses_to_run_without_gpu():
     import fair_marl_amd as fm
     if torch.cuda.is_available():
