@@ -159,6 +159,28 @@ def test_async_and_sync_reset_are_identical():
         same('step %d' % t)
 
 
+def test_long_horizon_n32_three_episodes():
+    """Trajectory-level parity at the dense BASELINE config-3 shape over three whole episodes (75 steps,
+    three auto-resets): f64 device state keeps following the f64 oracle (SURVEY section 7 hard part 2)."""
+    cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
+    n, seed = 6, 4242
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    eng.reset(); orc.reset()
+    rs = np.random.RandomState(9)
+    worst = 0.0
+    for t in range(75):
+        a = rs.randint(0, 5, size=(n, 32))
+        res = eng.step(torch.as_tensor(a, device=DEV))
+        ref = orc.step(a)
+        want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
+        check_outputs(res, want, 'long N=32 step %d' % t)
+        got = eng.get_state()
+        worst = max(worst, float(np.abs(got['agent_pos'] - orc.st.agent_pos).max()), float(np.abs(got['agent_vel'] - orc.st.agent_vel).max()))
+    assert worst < 1e-9, worst
+
+
 def test_masked_reset_and_float_actions():
     cfg = fm.EnvConfig(num_agents=5, num_landmarks=5, num_obstacles=2, num_walls=2)
     n, seed = 40, 5
