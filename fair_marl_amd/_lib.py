@@ -51,6 +51,8 @@ _SIGS = {
     'fmarl_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs),
                              C.c_int, C.c_void_p]),
     'fmarl_state_changed': (C.c_int, [C.c_void_p]),
+    'fmarl_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'fmarl_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fmarl_profile_enable': (C.c_int, [C.c_void_p, C.c_int]),
     'fmarl_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     'fmarl_cost_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -198,6 +198,7 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
 extern "C" {
 
 const char *fmarl_last_error(void) { return g_err; }
+int fmarl_state_changed(void *handle);
 
 size_t fmarl_state_bytes(const FmarlConfig *cfg) {
     const char *why;
@@ -413,6 +414,26 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
         }
     }
     return FMARL_OK;
+}
+
+static int copy_field(Handle *h, void *state, int field, void *host_or_dev, bool to_state, hipStream_t st, const char *who) {
+    if (!h || !state || !host_or_dev) return fail(FMARL_EINVAL, "%s: null argument", who);
+    if (field < 0 || field >= FMARL_NUM_FIELDS) return fail(FMARL_EINVAL, "%s: bad field id", who);
+    const size_t bytes = h->layout.count[field] * (h->layout.dtype[field] == FMARL_DTYPE_F64 ? 8 : 4);
+    if (bytes == 0) return FMARL_OK;
+    char *f = (char *)state + h->layout.off[field];
+    HIP_OK(hipMemcpyAsync(to_state ? (void *)f : host_or_dev, to_state ? host_or_dev : (void *)f, bytes, hipMemcpyDefault, st));
+    return FMARL_OK;
+}
+
+int fmarl_get_state(void *handle, const void *state, int field, void *dst, void *stream) {
+    return copy_field((Handle *)handle, (void *)state, field, dst, false, (hipStream_t)stream, "fmarl_get_state");
+}
+
+int fmarl_set_state(void *handle, void *state, int field, const void *src, void *stream) {
+    int rc = copy_field((Handle *)handle, state, field, (void *)src, true, (hipStream_t)stream, "fmarl_set_state");
+    if (rc == FMARL_OK) rc = fmarl_state_changed(handle);
+    return rc;
 }
 
 int fmarl_state_changed(void *handle) {

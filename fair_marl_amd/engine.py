@@ -126,15 +126,38 @@ class RolloutEngine:
         """Device tensor view of one state field (see include/fmarl.h FMARL_F_*)."""
         return self._fields[name]
 
+    _NP_DT = {torch.float64: np.float64, torch.int32: np.int32}
+
     def get_state(self):
-        return {k: v.detach().cpu().numpy().copy() for k, v in self._fields.items()
-                if k != 'reset_flag' and not k.startswith('stage_')}
+        """All scenario state fields as NumPy arrays in the reference's shapes (fmarl_get_state)."""
+        out = {}
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream(self.device).synchronize()
+            for k, t in self._fields.items():
+                if k == 'reset_flag' or k.startswith('stage_'):
+                    continue
+                a = np.empty(tuple(t.shape), dtype=self._NP_DT[t.dtype])
+                if a.size:
+                    _lib.check(self.lib.fmarl_get_state(self.handle, self.state.data_ptr(), _lib.FIELD_NAMES.index(k),
+                                                        a.ctypes.data, self._stream()), 'fmarl_get_state')
+                out[k] = a
+            torch.cuda.current_stream(self.device).synchronize()
+        return out
 
     def set_state(self, state):
-        for k, v in state.items():
-            if k in self._fields:
+        """Inject state fields (parity harness; fmarl_set_state, which also tells the handle the state changed)."""
+        with torch.cuda.device(self.device):
+            keep = []
+            for k, v in state.items():
+                if k not in self._fields:
+                    continue
                 t = self._fields[k]
-                t.copy_(torch.as_tensor(np.asarray(v)).to(t.dtype).reshape(t.shape))
+                a = np.ascontiguousarray(np.asarray(v).astype(self._NP_DT[t.dtype]).reshape(tuple(t.shape)))
+                keep.append(a)
+                if a.size:
+                    _lib.check(self.lib.fmarl_set_state(self.handle, self.state.data_ptr(), _lib.FIELD_NAMES.index(k),
+                                                        a.ctypes.data, self._stream()), 'fmarl_set_state')
+            torch.cuda.current_stream(self.device).synchronize()   # host sources must outlive the copies
         _lib.check(self.lib.fmarl_state_changed(self.handle), 'fmarl_state_changed')
 
     # ------------------------------------------------------------------ hot path

@@ -177,6 +177,13 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask,
 int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
                const FmarlOutputs *outs, int auto_reset, void *stream);
 
+/* Copy one state field (FMARL_F_*) out of / into the state buffer, in the field's own shape and dtype
+ * (= the reference's attribute layout, e.g. agent.state.p_pos as f64 (n, N, 2)).  `dst` / `src` may be host
+ * or device memory (hipMemcpyDefault).  fmarl_set_state implies fmarl_state_changed.  This is the parity
+ * harness' way to inject / read worlds (SURVEY.md App. C does the same on the reference's objects). */
+int fmarl_get_state(void *handle, const void *state, int field, void *dst, void *stream);
+int fmarl_set_state(void *handle, void *state, int field, const void *src, void *stream);
+
 /* Tell the handle the caller wrote into the state buffer (parity harness set_state): drops the
  * host-side "all envs share one step counter" shortcut used to skip the auto-reset launch. */
 int fmarl_state_changed(void *handle);
