@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 CONFIGS = {
     # BASELINE.json configs[2] (and configs[4] per GPU): the configuration the target is quoted on
     'cfg3': dict(workload='navigation_graph, 32 agents + 8 obstacles (E=72), 65536 envs per GPU',
-                 env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=64, cpu_episodes=5),
+                 env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=32, cpu_episodes=3),
     # BASELINE.json configs[3]
     'cfg4': dict(workload='fair_graph_formation, 10 agents + 1 landmark + 3 obstacles + 2 walls (E=16), 65536 envs per GPU',
                  env=dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3),
@@ -65,13 +65,15 @@ def algorithmic_bytes(cfg, emit=True):
     return 4.0 * words
 
 
-def cpu_baseline(cfg, n_envs, episodes):
-    """The oracle (NumPy float64 restatement, single core) on a bounded sample of the same workload."""
+def _cpu_worker(job):
+    """One host process = one batch of envs stepped by the oracle (the reference runs one process per env)."""
+    env_kw, n_envs, episodes, seed = job
     from oracle import fairnav_oracle as fnv
     from oracle import formation_oracle as fo
     from oracle import nav_oracle as no
     from oracle.philox import PhiloxStream
-    streams = lambda e, ep: PhiloxStream(1, e, ep)  # noqa: E731
+    cfg = fm.EnvConfig(**env_kw)
+    streams = lambda e, ep: PhiloxStream(seed, e, ep)  # noqa: E731
     if cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph':
         ocfg = fnv.Config(**{k: getattr(cfg, k) for k in fnv.Config.__dataclass_fields__})
         env = fnv.OracleFairNavVecEnv(ocfg, n_envs, mode='subproc', streams=streams)
@@ -82,15 +84,33 @@ def cpu_baseline(cfg, n_envs, episodes):
         ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
         env = no.OracleGraphVecEnv(ocfg, n_envs, mode='subproc', streams=streams)
     env.reset()
-    rs = np.random.RandomState(0)
+    rs = np.random.RandomState(seed)
     steps = episodes * cfg.episode_length
     t0 = time.perf_counter()
     for _ in range(steps):
         env.step(rs.randint(0, 5, size=(n_envs, cfg.N)))
-    dt = time.perf_counter() - t0
-    return dict(value=n_envs * cfg.N * steps / dt, unit='agent-steps/s', cores=1, kind='port',
-                sample='%d envs x %d agents x %d steps (%d episodes incl. auto-resets), NumPy f64 oracle, %.1f s'
-                       % (n_envs, cfg.N, steps, episodes, dt))
+    return n_envs * cfg.N * steps, time.perf_counter() - t0
+
+
+def cpu_baseline(env_kw, n_envs, episodes, workers):
+    """The oracle (NumPy float64 restatement) on a bounded sample of the same workload, one process per host
+    core like the reference's SubprocVecEnv (capped at 16).  Must run BEFORE this process touches the GPU: the
+    workers are spawned (exec), which is not allowed once HIP is initialised."""
+    jobs = [(env_kw, n_envs, episodes, 1 + w) for w in range(workers)]
+    t0 = time.perf_counter()
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context('spawn').Pool(workers) as pool:
+            res = pool.map_async(_cpu_worker, jobs).get(timeout=240)   # never hang the bench on the baseline
+    else:
+        res = [_cpu_worker(jobs[0])]
+    wall = time.perf_counter() - t0
+    units = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    N, ep = res[0][0] // (n_envs * episodes), episodes
+    return dict(value=units / busy, unit='agent-steps/s', cores=workers, kind='port',
+                sample='%d processes x %d envs x %d episodes incl. auto-resets (%d agent-steps), NumPy f64 oracle, '
+                       'slowest worker %.1f s, %.1f s wall incl. process start' % (workers, n_envs, ep, units, busy, wall))
 
 
 def main():
@@ -111,12 +131,20 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)'
                          % (args.gpus, world))
+    spec = CONFIGS[args.config]
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:   # first: nothing in this process has initialised the GPU yet
+        workers = max(1, min(16, os.cpu_count() or 1))
+        try:
+            cpu = cpu_baseline(spec['env'], spec['cpu_envs'], spec['cpu_episodes'], workers)
+        except Exception as exc:   # e.g. no process spawning on this host: fall back to one in-process worker
+            print('bench.py: multi-process cpu baseline failed (%s); using one process' % exc, file=sys.stderr)
+            cpu = cpu_baseline(spec['env'], spec['cpu_envs'], spec['cpu_episodes'], 1)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         dist.init_process_group('nccl', device_id=device)
 
-    spec = CONFIGS[args.config]
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
@@ -208,8 +236,8 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, spec['cpu_envs'], spec['cpu_episodes'])
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
