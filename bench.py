@@ -135,6 +135,8 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:   # first: nothing in this process has initialised the GPU yet
         workers = max(1, min(16, os.cpu_count() or 1))
+        if 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+            workers = 1   # under rocprofv3 the preloaded tool has already initialised the GPU: no exec from here
         try:
             cpu = cpu_baseline(spec['env'], spec['cpu_envs'], spec['cpu_episodes'], workers)
         except Exception as exc:   # e.g. no process spawning on this host: fall back to one in-process worker
