@@ -97,26 +97,35 @@ def test_reset_and_rollout_vs_philox_oracle(N, O, W, n):
     check_state(eng, orc.st, 'end')
 
 
-@pytest.mark.parametrize('case', range(14))
+@pytest.mark.parametrize('case', range(36))
 def test_random_small_configs_vs_oracle(case):
     """Ragged / degenerate shapes and knobs: N = 1, no obstacles, walls, n_envs = 1, episode_length = 1,
-    max_speed None, odd E (one-float-per-lane emission path), both scenarios; two episodes incl. resets."""
+    max_speed None, odd E (one-float-per-lane emission path), large thresholds (arrivals, occupied slots,
+    status / early episode end), all three scenarios; two episodes incl. resets."""
+    from oracle import fairnav_oracle as fnv
     rs = np.random.RandomState(1000 + case)
-    formation = case % 3 == 2
-    N = int(rs.randint(1, 10)); O = int(rs.randint(0, 5)); W = int(rs.randint(0, 3)); n = int(rs.choice([1, 2, 7, 33]))
+    kind = case % 3   # 0 navigation_graph, 1 nav_fairassign_fairrew_formation_graph, 2 fair_graph_formation
+    N = int(rs.randint(2 if kind == 1 else 1, 10)); O = int(rs.randint(0, 5)); W = int(rs.randint(0, 3)); n = int(rs.choice([1, 2, 7, 33]))
     ep = int(rs.choice([1, 2, 5, 9]))
     kw = dict(num_agents=N, num_obstacles=O, episode_length=ep, max_speed=None if case % 5 == 4 else float(rs.choice([0.7, 2.0])),
-              min_dist_thresh=float(rs.choice([0.05, 0.3])), goal_rew=float(rs.choice([5, 2.5])), collision_rew=float(rs.choice([5, 1.0])))
+              min_dist_thresh=float(rs.choice([0.05, 0.3, 0.6])), goal_rew=float(rs.choice([5, 2.5])), collision_rew=float(rs.choice([5, 1.0])))
     seed = 77 + case
-    if formation:
+    streams = lambda e, ep_: PhiloxStream(seed, e, ep_)  # noqa: E731
+    if kind == 2:
         cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_landmarks=int(rs.randint(1, 3)), **kw)
         ocfg = fo.Config(**{k: getattr(cfg, k) for k in fo.Config.__dataclass_fields__})
-        orc = fo.OracleFormationVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep_: PhiloxStream(seed, e, ep_))
+        orc = fo.OracleFormationVecEnv(ocfg, n, mode='subproc', streams=streams)
         check = check_form_outputs
+    elif kind == 1:
+        cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_landmarks=N, num_walls=W,
+                           min_obs_dist=float(rs.choice([0.5, 0.25, 1.2])), **kw)
+        ocfg = fnv.Config(**{k: getattr(cfg, k) for k in fnv.Config.__dataclass_fields__})
+        orc = fnv.OracleFairNavVecEnv(ocfg, n, mode='subproc', streams=streams)
+        check = check_outputs
     else:
         cfg = fm.EnvConfig(num_landmarks=N, num_walls=W, **kw)
         ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
-        orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep_: PhiloxStream(seed, e, ep_))
+        orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=streams)
         check = check_outputs
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, async_reset=bool(case % 2))
     obs, ids, node, adj = eng.reset()
