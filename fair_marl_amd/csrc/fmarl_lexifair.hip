@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void lexifair_kernel(const double *costs, cons
                                                        const int *flag, int n_envs, int N) {
     const int lane = threadIdx.x % G;
     const int grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int env = min(grp, n_envs - 1);          // every lane stays in the shuffles
-    const bool valid = grp < n_envs && (flag == nullptr || flag[env] != 0);
+    if (grp >= n_envs || (flag != nullptr && flag[grp] == 0)) return;   // group-uniform: whole groups leave
+    const int env = grp;
     const bool is_row = lane < N;
     double c[G];   // row `lane` of the cost matrix (navigation_graph.py:555 cdist when built from positions)
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void lexifair_kernel(const double *costs, cons
         c[j] = v;
     }
     const int mc = lexifair_group<G>(c, N);
-    if (valid && is_row) perm[(size_t)env * N + lane] = mc;
+    if (is_row) perm[(size_t)env * N + lane] = mc;
 }
 
 template <int G>
