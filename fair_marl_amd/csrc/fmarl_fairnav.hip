@@ -165,6 +165,8 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         step = p.cur_step[env] + (STEP ? 1 : 0);
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
+    // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
+    if (!STEP && !__syncthreads_or(active && p.reset_flag[env] != 0)) return;
     load_statics(p, lds, env0, nenv);
     __syncthreads();
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);

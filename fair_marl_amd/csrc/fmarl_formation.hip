@@ -210,6 +210,8 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         emit = STEP ? !(auto_reset && step >= p.episode_length) : p.reset_flag[env] != 0;
         if (i == 0) *t.flag() = emit ? 0 : 1;
     }
+    // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
+    if (!STEP && !__syncthreads_or(active && p.reset_flag[env] != 0)) return;
     load_statics(p, lds, env0, nenv);
     __syncthreads();
     if (active && p.slot_occ[g] != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOut
         s_stat[p.N + i] = Dg;
         if (i == 0) *(int *)(base + p.lds_flag) = flagged ? 0 : 1;   // 1 = skip
     }
+    if (!__syncthreads_or(flagged)) return;   // no freshly reset env in this workgroup (block-uniform exit)
     load_statics(p, lds, env0, nenv);
     __syncthreads();
     if (active && flagged) {
