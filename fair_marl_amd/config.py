@@ -48,8 +48,6 @@ class EnvConfig:
             raise NotImplementedError("only graph_feat_type='relative' (the reference default) is built")
         if self.num_scripted_agents:
             raise NotImplementedError('scripted agents are not part of the hot path')
-        if self.collaborative:
-            raise NotImplementedError('collaborative=True (shared reward) is not built; reference default is False')
 
     @property
     def N(self): return self.num_agents

@@ -85,9 +85,13 @@ class _EngineVecEnv(ShareVecEnv):
         self.actions = np.asarray(actions)
 
     def _step_device(self):
-        out = self.engine.step(self.actions, auto_reset=True)
+        obs, ids, node, adj, rew, done, info = self.engine.step(self.actions, auto_reset=True)
         self.actions = None
-        return out
+        if self.spec.cfg.collaborative:
+            # reference multiagent/environment.py:867-870: every agent gets [sum of the env's rewards]
+            # (a list of 1-element lists -> shape (n, N, 1)); infos keep the individual rewards
+            rew = rew.sum(dim=1, keepdim=True).expand_as(rew).unsqueeze(-1)
+        return obs, ids, node, adj, rew, done, info
 
     @staticmethod
     def _np(t, dtype):

@@ -392,6 +392,15 @@ def test_vec_env_wrappers_api():
     with pytest.raises(NotImplementedError):
         args.scenario_name = 'simple_spread'
         fm.MPEEnv(args)
+    # collaborative=True: every agent receives [sum] (environment.py:867-870), shape (n, N, 1)
+    args.scenario_name = 'navigation_graph'
+    args.collaborative = True
+    cv = fm.GraphSubprocVecEnv([get_env_fn(i) for i in range(4)], device=DEV)
+    cv.reset()
+    res = cv.step(np.eye(5)[np.ones((4, 3), dtype=int)])
+    assert res[4].shape == (4, 3, 1)
+    ind = np.array([[res[6][e][a]['individual_reward'] for a in range(3)] for e in range(4)])
+    np.testing.assert_allclose(res[4][:, :, 0], np.repeat(ind.sum(axis=1, keepdims=True), 3, axis=1), rtol=1e-6)
 
 
 def test_full_size_properties_cfg3():

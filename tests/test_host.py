@@ -117,7 +117,7 @@ def test_specs_spaces_and_unsupported_scenarios():
     with pytest.raises(NotImplementedError):
         fm.GraphMPEEnv(args)
     args.scenario_name = 'navigation_graph'
-    args.collaborative = True
+    args.graph_feat_type = 'global'
     with pytest.raises(NotImplementedError):
         fm.GraphMPEEnv(args)
 
