@@ -69,7 +69,8 @@ struct EnvLds {
 // streams the N ego rows front to back (1 KiB per store instruction, rows back to back in memory).
 template <int CG>
 __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kThreads / 64;
+    // the wave index is uniform: say so, and the env / row addressing below stays in scalar registers
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = kThreads / 64;
     const uint32_t EF = p.E * p.F, C4 = EF >> 2;
     for (uint32_t el = wave; el < (uint32_t)nenv; el += nwaves) {
         const EnvLds t(p, lds, el);
@@ -94,8 +95,32 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
             }
         }
         float4 *dst = (float4 *)(o.node_obs + ((size_t)(env0 + el) * p.N) * EF);
-        const char *ego = t.base + p.lds_ego;
-        for (int i = 0; i < p.N; ++i, ego += kEgoWidth * 4, dst += C4) {
+        // ego rows are 20 bytes apart: per block of four rows one scalar base + the lane's column offsets,
+        // the rows themselves are immediate offsets of the ds_read (keeps the address math off the VALU)
+        const uint32_t ego0 = el * p.lds_env_bytes + p.lds_ego;
+        int i = 0;
+        for (; i + 4 <= p.N; i += 4, dst += 4 * C4) {
+            const char *ego = lds + __builtin_amdgcn_readfirstlane(ego0 + i * (kEgoWidth * 4));
+            const char *e[CG][4];
+#pragma unroll
+            for (int g = 0; g < CG; ++g)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[g][k] = ego + boff[g][k];
+            // row-major store order: consecutive store instructions write consecutive KiB of the output
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ro = r * kEgoWidth * 4;
+#pragma unroll
+                for (int g = 0; g < CG; ++g) {
+                    const uint32_t c = g * 64 + lane;
+                    if (c < C4)
+                        dst[(size_t)r * C4 + c] = make_float4(a[g].x - *(const float *)(e[g][0] + ro), a[g].y - *(const float *)(e[g][1] + ro),
+                                                              a[g].z - *(const float *)(e[g][2] + ro), a[g].w - *(const float *)(e[g][3] + ro));
+                }
+            }
+        }
+        for (; i < p.N; ++i, dst += C4) {
+            const char *ego = lds + __builtin_amdgcn_readfirstlane(ego0 + i * (kEgoWidth * 4));
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
                 const uint32_t c = g * 64 + lane;
