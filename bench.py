@@ -122,6 +122,8 @@ def main():
     ap.add_argument('--n-envs', type=int, default=0, help='envs per GPU (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: skip the RCCL trajectory gather')
+    ap.add_argument('--record-path', action='store_true', help='N=1: write the step records / episode records as the '
+                    'multi-GPU run does (the gather itself is a no-op with one rank)')
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
     args = ap.parse_args()
 
@@ -151,9 +153,12 @@ def main():
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
     eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset)
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 or args.record_path) and not args.no_gather
     depth = 2
-    tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth) if gather else None
+    # navigation_graph: the learner rebuilds node_obs / adj from obs + a record gathered once per episode
+    episodes = cfg.scenario_name == 'navigation_graph'
+    tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth,
+                          episode_words=eng.episode_record_words if episodes else 0) if gather else None
     if gather:
         sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done) for r in tg.records]
     else:
@@ -173,6 +178,9 @@ def main():
             eng.step(tape[t % tape_len], auto_reset=True)
             if gather:
                 tg.submit(t)
+                if episodes and eng.episode_started:   # same steps on every rank (lockstep episodes)
+                    eng.pack_episode(out=tg.episode_record())
+                    tg.submit_episode()
         if gather:
             tg.finish()
 
@@ -232,7 +240,9 @@ def main():
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed at episode end'),
                        'exchange': ('RCCL gather of obs/reward/done to rank 0 every step, %d B per agent-step'
-                                    % StepRecord.bytes_per_agent_step(cfg.obs_dim)) if gather else 'none'},
+                                    % StepRecord.bytes_per_agent_step(cfg.obs_dim)
+                                    + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'
+                                       % (4 * eng.episode_record_words) if episodes else '')) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}.get(cfg.scenario_name, 'step_kernel'),
                          'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),

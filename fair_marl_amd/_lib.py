@@ -63,6 +63,10 @@ _SIGS = {
     'fmarl_edge_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     'fmarl_edge_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                   C.c_double, C.c_int, C.c_void_p]),
+    'fmarl_episode_record_words': (C.c_size_t, [C.POINTER(FmarlConfig)]),
+    'fmarl_episode_started': (C.c_int, [C.c_void_p]),
+    'fmarl_pack_episode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fmarl_rebuild_graph': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

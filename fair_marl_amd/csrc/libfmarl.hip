@@ -12,6 +12,7 @@
 #include "fmarl_formation.hip"
 #include "fmarl_fairnav.hip"
 #include "fmarl_graph.hip"
+#include "fmarl_rebuild.hip"
 
 using namespace fmarl;
 
@@ -101,6 +102,7 @@ struct Handle {
     int grid;
     bool lockstep;      // all envs share one step counter, known on the host
     int host_step;
+    bool episode_started;   // the last reset / step call may have started episodes (host-side knowledge, conservative)
     bool async;         // FMARL_FLAG_ASYNC_RESET: next episode staged on `side`
     bool stage_dirty;   // staged data may be stale (caller wrote the state): next reset goes the synchronous way
     hipStream_t side;
@@ -293,6 +295,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)rebuild_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)fairnav_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
@@ -318,7 +321,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
             return fail(FMARL_EHIP, "fmarl_create: cannot create the staging stream / events");
         }
     }
-    h->lockstep = false; h->host_step = 0;
+    h->lockstep = false; h->host_step = 0; h->episode_started = false;
     h->ev = nullptr; h->ev_cap = h->ev_n = 0;
     *handle = h;
     return FMARL_OK;
@@ -380,6 +383,7 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlO
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_reset: null argument");
     int rc = launch_reset(h, state, env_mask ? kResetMask : kResetAll, env_mask, outs, (hipStream_t)stream);
     if (env_mask || h->cfg.scenario == FMARL_SCENARIO_FAIRNAV) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
+    h->episode_started = true;
     return rc;
 }
 
@@ -405,12 +409,14 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
     HIP_OK(hipGetLastError());
     if (h->lockstep) ++h->host_step;
+    h->episode_started = false;
     if (auto_reset) {
         const bool may_reset = !h->lockstep || h->host_step >= h->cfg.episode_length;
         if (may_reset) {
             int rc = launch_reset(h, state, kResetAuto, nullptr, outs, st);
             if (rc) return rc;
             if (h->lockstep) h->host_step = 0;
+            h->episode_started = true;
         }
     }
     return FMARL_OK;
@@ -498,6 +504,45 @@ int fmarl_info_means(const float *info, double *means, int n_envs, int num_agent
     if (!info || !means || n_envs < 1 || num_agents < 1) return fail(FMARL_EINVAL, "fmarl_info_means: bad argument");
     hipLaunchKernelGGL(info_mean_kernel, dim3(FMARL_INFO_WIDTH * num_agents), dim3(256), 0, (hipStream_t)stream, info, means,
                        n_envs, num_agents, unreached_time);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+size_t fmarl_episode_record_words(const FmarlConfig *cfg) {
+    const char *why;
+    if (!config_ok(cfg, &why)) { fail(FMARL_EINVAL, "fmarl_episode_record_words: %s", why); return 0; }
+    return (size_t)episode_record_words(cfg->num_agents, cfg->num_landmarks, cfg->num_obstacles, cfg->num_walls);
+}
+
+int fmarl_episode_started(void *handle) {
+    Handle *h = (Handle *)handle;
+    return h && h->episode_started ? 1 : 0;
+}
+
+int fmarl_pack_episode(void *handle, const void *state, void *record, void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h || !state || !record) return fail(FMARL_EINVAL, "fmarl_pack_episode: null argument");
+    if (h->cfg.scenario != FMARL_SCENARIO_NAVIGATION_GRAPH)
+        return fail(FMARL_EINVAL, "fmarl_pack_episode: only navigation_graph has a rebuildable record");
+    Params p = bind(h, (void *)state);
+    const size_t total = (size_t)p.n_envs * (p.N + p.L + p.O + p.W);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_episode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (uint32_t *)record);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int n_envs, float *node_obs, float *adj,
+                        void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h || !obs || !record || n_envs < 1 || (!node_obs && !adj)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: bad argument");
+    if (h->cfg.scenario != FMARL_SCENARIO_NAVIGATION_GRAPH)
+        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: only navigation_graph has a rebuildable record");
+    FmarlOutputs o = {};
+    o.node_obs = node_obs; o.adj = adj;
+    const int grid = (n_envs + h->base.epb - 1) / h->base.epb;
+    hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o, obs,
+                       (const uint32_t *)record, n_envs);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

@@ -282,6 +282,47 @@ class RolloutEngine:
                  'Time_mean_by_stddev': 'time_mn_by_stddev'}
         return {'agent%d/%s' % (a, names[k]): float(m[slot, a]) for a in range(N) for k, slot in key_map(self.cfg.scenario_name)}
 
+    # ------------------------------------------------------------------ cross-GPU hand-off of the graph observation
+    @property
+    def episode_record_words(self):
+        """32-bit words per env of the episode record (goals, landmarks, obstacles, walls)."""
+        return int(self.lib.fmarl_episode_record_words(C.byref(self.c)))
+
+    @property
+    def episode_started(self):
+        """True if the last reset() / step() may have started episodes (host-side, no device access)."""
+        return bool(self.lib.fmarl_episode_started(self.handle))
+
+    def pack_episode(self, out=None):
+        """Episode record of every env, int32 (n_envs, episode_record_words): what a learner on another GPU needs
+        besides the per-step obs to rebuild node_obs / adj (navigation_graph only)."""
+        if out is None:
+            out = torch.empty(self.n_envs, self.episode_record_words, dtype=torch.int32, device=self.device)
+        assert out.is_contiguous() and out.numel() * out.element_size() == self.n_envs * self.episode_record_words * 4
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_pack_episode(self.handle, self.state.data_ptr(), out.data_ptr(), self._stream()),
+                       'fmarl_pack_episode')
+        return out
+
+    def rebuild_graph(self, obs, record, node_obs=None, adj_env=None, want_node_obs=True, want_adj=True):
+        """graph_observation (reference navigation_graph.py:941-1035) from gathered (obs (n, N, D) f32, episode record
+        (n, words)); n is the caller's.  Returns (node_obs (n, N, E, F) | None, adj_env (n, E, E) | None)."""
+        cfg = self.cfg
+        obs = torch.as_tensor(obs).to(self.device, torch.float32).contiguous()
+        n = obs.shape[0]
+        assert tuple(obs.shape[1:]) == (cfg.N, cfg.obs_dim) and record.is_contiguous() and record.device == obs.device
+        assert record.numel() * record.element_size() == n * self.episode_record_words * 4
+        if node_obs is None and want_node_obs:
+            node_obs = torch.empty(n, cfg.N, cfg.E, cfg.node_feat, dtype=torch.float32, device=self.device)
+        if adj_env is None and want_adj:
+            adj_env = torch.empty(n, cfg.E, cfg.E, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_rebuild_graph(self.handle, obs.data_ptr(), record.data_ptr(), n,
+                                                    node_obs.data_ptr() if node_obs is not None else None,
+                                                    adj_env.data_ptr() if adj_env is not None else None, self._stream()),
+                       'fmarl_rebuild_graph')
+        return node_obs, adj_env
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, capacity):
         """Record a hipEvent pair around each of the next ``capacity`` step-kernel launches (0 = off)."""

@@ -11,9 +11,11 @@ The only exchange step is the one the reference does through its worker pipes
 one ``gather`` per step to the learner rank over RCCL (backend "nccl" on ROCm; xGMI links are
 point to point, so each peer's shard moves over its own link).  The record is the compact part
 of the step output -- obs (which already carries every agent's velocity, position and goal
-offset), reward and done: 33 bytes per agent-step.  node_obs / adj are recomputable from it and
-are not sent.  Records are double-buffered: the gather of step t runs on RCCL's stream while
-the kernels of step t+1 write the other buffer.
+offset), reward and done: 33 bytes per agent-step.  node_obs / adj are not sent: for navigation_graph
+the learner rebuilds them (``RolloutEngine.rebuild_graph``) from the obs rows plus the episode record
+(goals, landmarks, obstacles, walls: ``RolloutEngine.pack_episode``), which is gathered once per
+episode because World.step never moves those entities.  Records are double-buffered: the gather of
+step t runs on RCCL's stream while the kernels of step t+1 write the other buffer.
 """
 import torch
 import torch.distributed as dist
@@ -57,7 +59,7 @@ class TrajectoryGather(object):
     All ranks must use the same n_envs per rank (equal shards) -- gather needs equal sizes.
     """
 
-    def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2):
+    def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0):
         self.group, self.dst, self.depth = group, dst, depth
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -66,6 +68,12 @@ class TrajectoryGather(object):
         self.recv = None
         if self.world > 1 and self.rank == dst:
             self.recv = [[torch.zeros_like(r.flat) for _ in range(self.world)] for r in self.records]
+        # episode records (int32 words per env), two in rotation: the one of the running episode stays readable
+        # on the learner while the next one is gathered
+        self.ep_send = [torch.zeros(int(n_envs), int(episode_words), dtype=torch.int32, device=device) for _ in range(2)]
+        self.ep_recv, self.ep_pending, self.ep_count = None, [None, None], 0
+        if self.world > 1 and self.rank == dst:
+            self.ep_recv = [[torch.zeros_like(b) for _ in range(self.world)] for b in self.ep_send]
 
     def record(self, t):
         k = t % self.depth
@@ -86,6 +94,35 @@ class TrajectoryGather(object):
             if self.pending[k] is not None:
                 self.pending[k].wait()
                 self.pending[k] = None
+        for k in range(2):
+            if self.ep_pending[k] is not None:
+                self.ep_pending[k].wait()
+                self.ep_pending[k] = None
+
+    # -- once per episode (every rank at the same steps: ``RolloutEngine.episode_started`` after reset / step)
+    def episode_record(self):
+        """Buffer for the record of the episode that starts now: fill it (``engine.pack_episode(out=...)``), then
+        ``submit_episode()``."""
+        k = self.ep_count % 2
+        if self.ep_pending[k] is not None:
+            self.ep_pending[k].wait()
+            self.ep_pending[k] = None
+        return self.ep_send[k]
+
+    def submit_episode(self):
+        k = self.ep_count % 2
+        self.ep_count += 1
+        if self.world > 1:
+            self.ep_pending[k] = dist.gather(self.ep_send[k], self.ep_recv[k] if self.rank == self.dst else None,
+                                             dst=self.dst, group=self.group, async_op=True)
+
+    def gathered_episode(self):
+        """On the learner rank: list over ranks of the most recently submitted episode record (n_envs, words)."""
+        k = (self.ep_count - 1) % 2
+        if self.ep_pending[k] is not None:
+            self.ep_pending[k].wait()
+            self.ep_pending[k] = None
+        return [self.ep_send[k]] if self.world == 1 else list(self.ep_recv[k])
 
     def gathered(self, t):
         """On the learner rank: list over ranks of (obs, reward, done) views of step t (after wait)."""

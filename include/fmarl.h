@@ -222,6 +222,27 @@ int fmarl_edge_count(const float *adj, int32_t *nnz, int n_envs, int num_entitie
 int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr, int64_t total,
                     int n_graphs, int graphs_per_env, int num_entities, double max_edge_dist, int strict, void *stream);
 
+/* Cross-GPU hand-off of the graph observation (navigation_graph only).  The reference's workers pipe node_obs /
+ * adj to the learner with every step (onpolicy/envs/env_wrappers.py:988-996).  Between GPUs only the compact
+ * record travels: the per-step obs rows, which carry every agent's velocity and position
+ * (navigation_graph.py:855-857), and once per episode the entities World.step never moves -- each agent's goal,
+ * the landmarks, obstacles and walls placed by reset_world (navigation_graph.py:264-575).
+ *   fmarl_episode_record_words: 32-bit words per env of the episode record:
+ *       goal (x, y) f32 x N | landmark, obstacle (x, y) f32 x (L + O) | wall [axis f64, e0 f32, e1 f32, orient f32, 0] x W
+ *   fmarl_episode_started: 1 if the last fmarl_reset / fmarl_step call may have started episodes (host-side
+ *       knowledge: always 1 after a reset, after a step once per episode_length steps while all envs run in
+ *       lockstep, after every auto-resetting step otherwise); no device access.
+ *   fmarl_pack_episode: record (n_envs, words) <- state.
+ *   fmarl_rebuild_graph: (obs f32 (n_envs, N, D), record (n_envs, words)) -> node_obs f32 (n_envs, N, E, F) and / or
+ *       adj f32 (n_envs, E, E) as graph_observation would give them (navigation_graph.py:941-1035, 1079-1124);
+ *       n_envs is the caller's (e.g. all ranks' envs), the handle supplies the entity counts.  node_obs equals the
+ *       sender's bit for bit; adj is computed from the f32 positions (difference < 1e-6). */
+size_t fmarl_episode_record_words(const FmarlConfig *cfg);
+int fmarl_episode_started(void *handle);
+int fmarl_pack_episode(void *handle, const void *state, void *record, void *stream);
+int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int n_envs, float *node_obs, float *adj,
+                        void *stream);
+
 /* Per-agent means over the envs of every info field = what process_infos + log_env report
  * (onpolicy/runner/shared/base_runner.py:197-306); Time_req_to_goal == -1 counts as unreached_time
  * (= episode_length * dt, :212-215).  info f32 (FMARL_INFO_WIDTH, n, N) -> means f64 (FMARL_INFO_WIDTH, N). */

@@ -168,6 +168,43 @@ def test_async_and_sync_reset_are_identical():
         same('step %d' % t)
 
 
+@pytest.mark.parametrize('N,O,W,n,async_reset', [(3, 3, 0, 257, True), (32, 8, 0, 70, True), (10, 3, 2, 100, False), (7, 0, 1, 37, True),
+                                                 (5, 2, 2, 64, True)])
+def test_learner_side_rebuild_of_node_obs_and_adj(N, O, W, n, async_reset):
+    """Multi-GPU hand-off: node_obs / adj are not sent; the learner rebuilds them from the gathered obs rows and
+    the once-per-episode record.  node_obs must equal the sender's bit for bit, adj within 1e-6 (f32 positions)."""
+    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W, episode_length=6)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=5, async_reset=async_reset)
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    assert eng.episode_record_words == 2 * N + 2 * (N + O) + 6 * W
+    eng.reset()
+    assert eng.episode_started
+    rec, started = eng.pack_episode(), 1
+    for t in range(15):
+        node, adj = eng.rebuild_graph(eng.obs, rec)
+        assert torch.equal(node, eng.node_obs), 'node_obs step %d' % t
+        np.testing.assert_allclose(adj.cpu().numpy(), eng.adj_env.cpu().numpy(), rtol=0, atol=1e-6)
+        eng.step(torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32))
+        assert eng.episode_started == ((t + 1) % 6 == 0)
+        if eng.episode_started:
+            eng.pack_episode(out=rec); started += 1
+    assert started == 3
+    # the learner holds several ranks' envs: n is the caller's, only one of the outputs may be asked for
+    obs2, rec2 = torch.cat([eng.obs, eng.obs.flip(0)]), torch.cat([rec, rec.flip(0)])
+    node2, none = eng.rebuild_graph(obs2, rec2, want_adj=False)
+    assert none is None and torch.equal(node2[:n], eng.node_obs) and torch.equal(node2[n:], eng.node_obs.flip(0))
+    none, adj2 = eng.rebuild_graph(obs2, rec2, want_node_obs=False)
+    assert none is None and torch.equal(adj2[n:], adj2[:n].flip(0))
+
+
+def test_rebuild_is_refused_for_other_scenarios():
+    cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=4, num_landmarks=1, num_obstacles=2, num_walls=2)
+    eng = fm.RolloutEngine(cfg, 8, device=DEV)
+    eng.reset()
+    with pytest.raises(RuntimeError, match='navigation_graph'):
+        eng.pack_episode()
+
+
 def test_long_horizon_n32_three_episodes():
     """Trajectory-level parity at the dense BASELINE config-3 shape over three whole episodes (75 steps,
     three auto-resets): f64 device state keeps following the f64 oracle (SURVEY section 7 hard part 2)."""

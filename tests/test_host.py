@@ -152,9 +152,12 @@ def _gather_worker(rank, world, port, q):
     from fair_marl_amd.sharding import TrajectoryGather, shard_range
     n_total, N, D, T = 12, 3, 7, 5
     lo, hi = shard_range(n_total, world, rank)
-    tg = TrajectoryGather(hi - lo, N, D, 'cpu', dst=0, depth=2)
+    tg = TrajectoryGather(hi - lo, N, D, 'cpu', dst=0, depth=2, episode_words=4)
     ok = True
     for t in range(T):
+        if t % 2 == 0:                           # a new 'episode' every second step: its record travels once
+            tg.episode_record().copy_(torch.arange(lo, hi, dtype=torch.int32).view(-1, 1) * 10 + t // 2)
+            tg.submit_episode()
         rec = tg.record(t)                       # waits for the gather that used this buffer (t - 2)
         env = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
         rec.obs.copy_((env * 100 + t).expand(hi - lo, N, D))
@@ -169,6 +172,9 @@ def _gather_worker(rank, world, port, q):
                     e = torch.arange(l2, h2, dtype=torch.float32)
                     ok &= bool((obs[:, 0, 0] == e * 100 + (t - 1)).all()) and bool((rew[:, 1] == e + 0.5 * (t - 1)).all())
                     ok &= bool((done == (t - 1) % 2).all()) and obs.shape == (h2 - l2, N, D)
+                for r, ep in enumerate(tg.gathered_episode()):     # the record of the episode step t belongs to
+                    l2, h2 = shard_range(n_total, world, r)
+                    ok &= ep.shape == (h2 - l2, 4) and bool((ep[:, 3] == torch.arange(l2, h2, dtype=torch.int32) * 10 + t // 2).all())
     tg.finish()
     if rank == 0:
         q.put(ok)
