@@ -13,6 +13,7 @@ INFO_WIDTH = 14
  F_SLOT_DELTA, F_FORMATION_DONE, F_GOAL_OCC, F_GOAL_HISTORY, F_GOAL_REACHED, F_STATUS, F_RESET_FLAG, F_STAGE_AGENT_POS, F_STAGE_LANDMARK_POS, F_STAGE_OBSTACLE_POS,
  F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, NUM_FIELDS) = range(37)
 FLAG_ASYNC_RESET = 1
+FLAG_GLOBAL_FEATURES = 2
 FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_e0',
                'wall_e1', 'wall_orient', 'wall_length', 'goal_match', 'dists_to_goal', 'times_required',
                'dist_left', 'num_obst_coll', 'num_agent_coll', 'min_time', 'cur_step', 'episode',

@@ -44,8 +44,13 @@ class EnvConfig:
         if self.scenario_name not in _lib.SCENARIOS:
             raise NotImplementedError('scenario %r is outside the MI355X hot path (supported: %s)'
                                       % (self.scenario_name, ', '.join(_lib.SCENARIOS)))
-        if self.graph_feat_type != 'relative':
-            raise NotImplementedError("only graph_feat_type='relative' (the reference default) is built")
+        if self.graph_feat_type not in ('relative', 'global'):
+            raise ValueError('graph_feat_type must be relative or global')
+        if self.graph_feat_type == 'global' and self.scenario_name != 'navigation_graph':
+            raise NotImplementedError("graph_feat_type='global' is built for navigation_graph only")
+        if self.graph_feat_type == 'global' and self.num_walls:
+            # the reference itself fails here: _get_entity_feat_global has no wall branch (navigation_graph.py:1075)
+            raise ValueError('wall not supported with graph_feat_type=global')
         if self.num_scripted_agents:
             raise NotImplementedError('scripted agents are not part of the hot path')
 
@@ -56,11 +61,14 @@ class EnvConfig:
     @property
     def obs_dim(self): return {'navigation_graph': 7, 'fair_graph_formation': 6}.get(self.scenario_name, 11)
     @property
-    def node_feat(self): return {'navigation_graph': 11, 'fair_graph_formation': 12}.get(self.scenario_name, 13)
+    def node_feat(self):
+        if self.graph_feat_type == 'global':
+            return 7
+        return {'navigation_graph': 11, 'fair_graph_formation': 12}.get(self.scenario_name, 13)
 
     def to_c(self, n_envs, seed=0, env_offset=0, async_reset=False):
         c = _lib.FmarlConfig()
-        c.flags = _lib.FLAG_ASYNC_RESET if async_reset else 0
+        c.flags = (_lib.FLAG_ASYNC_RESET if async_reset else 0) | (_lib.FLAG_GLOBAL_FEATURES if self.graph_feat_type == 'global' else 0)
         c.scenario = _lib.SCENARIOS[self.scenario_name]
         c.n_envs = int(n_envs)
         c.num_agents, c.num_landmarks = int(self.num_agents), int(self.num_landmarks)

@@ -35,6 +35,7 @@ struct Params {
     int n_envs, N, L, O, W, E, D, F;
     int episode_length, has_max_speed, env_offset, scenario;
     int epb;                 // environments per workgroup = kThreads / N
+    int feat_global;   // FMARL_FLAG_GLOBAL_FEATURES: node rows are [vel, pos, goal, type] without the ego part
     int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
     uint64_t seed;

@@ -38,6 +38,7 @@ struct EnvLds {
     // (navigation_graph.py:1079-1124): [vel, pos, goal, pos, pos, type]; walls: corners in 6..9.
     __device__ float entity_feature(uint32_t e, uint32_t f) const {
         const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
+        if (p.feat_global) f = f == 6 ? 10 : f;   // 'global' rows are the first six columns + type (navigation_graph.py:1058-1077)
         if (f == 10) return e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
         if (f < 2) {
             if (e >= N) return 0.f;
@@ -57,7 +58,7 @@ struct EnvLds {
     }
     // ego part of column f: [vx vy | x y | x y | x y | x y | 0]
     __device__ float ego_feature(uint32_t i, uint32_t f) const {
-        if (f == 10) return 0.f;
+        if (f == 10 || p.feat_global) return 0.f;
         if (f < 2) { const float4 a = agentf()[i]; return f == 0 ? a.x : a.y; }
         const double2 x = pos()[i];
         return (float)((f & 1) ? x.y : x.x);
@@ -88,7 +89,7 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     v[k] = t.entity_feature(e, f);
-                    boff[g][k] = 4 * (f == 10 ? 4 : (f < 2 ? f : 2 + (f & 1)));
+                    boff[g][k] = 4 * ((f == 10 || p.feat_global) ? 4 : (f < 2 ? f : 2 + (f & 1)));
                     if (++f == (uint32_t)p.F) { f = 0; ++e; }
                 }
                 a[g] = make_float4(v[0], v[1], v[2], v[3]);

@@ -51,6 +51,10 @@ bool config_ok(const FmarlConfig *c, const char **why) {
     if (c->num_walls < 0 || c->num_walls > 2) { *why = "num_walls must be 0..2"; return false; }
     if (form && c->num_walls != 2) { *why = "fair_graph_formation always has 2 walls"; return false; }
     if (c->episode_length < 1) { *why = "episode_length < 1"; return false; }
+    if ((c->flags & FMARL_FLAG_GLOBAL_FEATURES) && (form || fnav || c->num_walls != 0)) {
+        *why = "global node features: navigation_graph without walls only (the reference's _get_entity_feat_global knows no walls)";
+        return false;
+    }
     return true;
 }
 
@@ -236,6 +240,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     const bool form = cfg->scenario == FMARL_SCENARIO_FORMATION;
     const bool fnav = cfg->scenario == FMARL_SCENARIO_FAIRNAV;
     p.W = cfg->num_walls; p.E = p.N + p.L + p.O + p.W; p.D = form ? 6 : (fnav ? 11 : 7); p.F = form ? 12 : (fnav ? 13 : 11);
+    p.feat_global = (cfg->flags & FMARL_FLAG_GLOBAL_FEATURES) ? 1 : 0;
+    if (p.feat_global) p.F = 7;
     p.min_obs_dist = cfg->min_obs_dist;
     p.episode_length = cfg->episode_length; p.has_max_speed = cfg->has_max_speed; p.env_offset = cfg->env_offset;
     p.scenario = cfg->scenario;

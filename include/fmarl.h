@@ -40,6 +40,10 @@ extern "C" {
  * identical to the synchronous path.  Leave it off when capturing single steps into a hipGraph (the
  * side-stream work outlives the call). */
 #define FMARL_FLAG_ASYNC_RESET 1
+/* GLOBAL_FEATURES: --graph_feat_type global (navigation_graph.py:981-1009, 1058-1077): node_obs rows are the
+ * 7 absolute columns [vel, pos, goal, type], identical for every ego agent (F = 7).  navigation_graph without
+ * walls only: the reference's _get_entity_feat_global raises for walls and the other two scenarios are not built. */
+#define FMARL_FLAG_GLOBAL_FEATURES 2
 
 /* Scenario arguments: multiagent/custom_scenarios/navigation_graph.py:94-129,208
  * (defaults onpolicy/config.py:176-252, onpolicy/scripts/train_mpe.py:71-106). */

@@ -75,7 +75,7 @@ class Config:
     @property
     def obs_dim(self): return 7
     @property
-    def node_feat(self): return 11
+    def node_feat(self): return 7 if self.graph_feat_type == 'global' else 11
 
 
 class State:
@@ -246,11 +246,22 @@ def fairness_from(vec):
 
 
 def node_features(cfg, st):
-    """navigation_graph.py:941-1035 + :1079-1124 -> (n, N, E, 11) relative node features."""
+    """navigation_graph.py:941-1035 + :1079-1124 -> (n, N, E, 11) relative node features;
+    graph_feat_type 'global' (:981-1009, :1058-1077): (n, N, E, 7) [vel, pos, goal, type], the same for every ego."""
     n, N = st.agent_pos.shape[:2]
     L, O, W, E = cfg.L, cfg.O, cfg.W, cfg.E
     ep = st.entity_pos()
     ev = np.zeros((n, E, 2)); ev[:, :N] = st.agent_vel
+    if cfg.graph_feat_type == 'global':
+        if W:
+            raise ValueError('wall not supported')   # :1075: _get_entity_feat_global knows no walls
+        row = np.zeros((n, E, 7))
+        row[..., 0:2] = ev
+        row[..., 2:4] = ep
+        row[..., 4:6] = ep
+        row[:, :N, 4:6] = np.take_along_axis(st.landmark_pos, st.goal_match[..., None], axis=1)
+        row[..., 6] = np.concatenate([np.zeros(N), np.ones(L), 2 * np.ones(O)])
+        return np.broadcast_to(row[:, None], (n, N, E, 7)).copy()
     ego_p = st.agent_pos[:, :, None, :]; ego_v = st.agent_vel[:, :, None, :]
     rel_pos = ep[:, None, :, :] - ego_p
     rel_vel = ev[:, None, :, :] - ego_v

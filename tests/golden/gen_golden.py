@@ -131,6 +131,15 @@ def gen_traj():
     save('traj_crafted.npz', run_traj(args, [c0, c1], actions, crafted=True))
 
 
+def gen_global():
+    """--graph_feat_type global (navigation_graph.py:981-1009): 7-wide absolute node features."""
+    rs = np.random.RandomState(77)
+    for name, N, O, n, T in (('n3', 3, 3, 3, 12), ('n10', 10, 2, 2, 8)):
+        args = rh.make_args(num_agents=N, num_landmarks=N, num_obstacles=O, graph_feat_type='global')
+        actions = rs.randint(0, 5, size=(T, n, N)).astype(np.int64)
+        save('traj_%s_global.npz' % name, run_traj(args, [41 + 3 * e for e in range(n)], actions))
+
+
 def gen_formation():
     """fair_graph_formation (BASELINE config 4 shapes: N=10, L=1, O=3, W=2 -> E=16) + edge cases."""
     rs = np.random.RandomState(77)
@@ -314,13 +323,15 @@ def gen_kat_world():
 
 if __name__ == '__main__':
     assert rh.available(), 'needs /root/reference (build container only)'
-    which = sys.argv[1:] or ['kat', 'cfg1', 'traj', 'formation', 'fairnav']
+    which = sys.argv[1:] or ['kat', 'cfg1', 'traj', 'global', 'formation', 'fairnav']
     if 'kat' in which:
         gen_kat_world()
     if 'cfg1' in which:
         gen_cfg1()
     if 'traj' in which:
         gen_traj()
+    if 'global' in which:
+        gen_global()
     if 'formation' in which:
         gen_formation()
     if 'fairnav' in which:

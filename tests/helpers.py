@@ -29,7 +29,8 @@ def state_from(fx, cfg, prefix='init_'):
 
 
 TRAJ = ['traj_n3.npz', 'traj_n3w2.npz', 'traj_n1.npz', 'traj_n2o1w1.npz', 'traj_n10.npz', 'traj_n32.npz',
-        'traj_n3_ep5.npz', 'traj_n3_float.npz', 'traj_n4_knobs.npz', 'traj_crafted.npz']
+        'traj_n3_ep5.npz', 'traj_n3_float.npz', 'traj_n4_knobs.npz', 'traj_crafted.npz', 'traj_n3_global.npz',
+        'traj_n10_global.npz']
 
 
 FORM = ['form_n3.npz', 'form_n10.npz', 'form_n5l3.npz', 'form_n4_thr04.npz', 'form_n3_thr07.npz', 'form_n1.npz',

@@ -67,12 +67,14 @@ def test_golden_trajectory(name):
             np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
 
 
-@pytest.mark.parametrize('N,O,W,n', [(3, 3, 0, 300), (32, 8, 0, 64), (10, 3, 2, 100), (7, 0, 1, 37), (64, 4, 0, 5)])
-def test_reset_and_rollout_vs_philox_oracle(N, O, W, n):
+@pytest.mark.parametrize('N,O,W,n,feat', [(3, 3, 0, 300, 'relative'), (32, 8, 0, 64, 'relative'), (10, 3, 2, 100, 'relative'),
+                                          (7, 0, 1, 37, 'relative'), (64, 4, 0, 5, 'relative'), (32, 8, 0, 40, 'global'),
+                                          (5, 1, 0, 77, 'global')])
+def test_reset_and_rollout_vs_philox_oracle(N, O, W, n, feat):
     """Device reset (Philox stream, rejection sampling, lexifair) is bit-comparable with the oracle
     drawing from the same stream; then 30 steps incl. an auto-reset stay within tolerance."""
     seed = 1234 + N
-    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W)
+    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W, graph_feat_type=feat)
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
     ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
     orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
@@ -168,12 +170,14 @@ def test_async_and_sync_reset_are_identical():
         same('step %d' % t)
 
 
-@pytest.mark.parametrize('N,O,W,n,async_reset', [(3, 3, 0, 257, True), (32, 8, 0, 70, True), (10, 3, 2, 100, False), (7, 0, 1, 37, True),
-                                                 (5, 2, 2, 64, True)])
-def test_learner_side_rebuild_of_node_obs_and_adj(N, O, W, n, async_reset):
+@pytest.mark.parametrize('N,O,W,n,async_reset,feat', [(3, 3, 0, 257, True, 'relative'), (32, 8, 0, 70, True, 'relative'),
+                                                      (10, 3, 2, 100, False, 'relative'), (7, 0, 1, 37, True, 'relative'),
+                                                      (5, 2, 2, 64, True, 'relative'), (6, 2, 0, 90, True, 'global'),
+                                                      (32, 8, 0, 33, False, 'global')])
+def test_learner_side_rebuild_of_node_obs_and_adj(N, O, W, n, async_reset, feat):
     """Multi-GPU hand-off: node_obs / adj are not sent; the learner rebuilds them from the gathered obs rows and
     the once-per-episode record.  node_obs must equal the sender's bit for bit, adj within 1e-6 (f32 positions)."""
-    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W, episode_length=6)
+    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W, episode_length=6, graph_feat_type=feat)
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=5, async_reset=async_reset)
     g = torch.Generator(device=DEV); g.manual_seed(9)
     assert eng.episode_record_words == 2 * N + 2 * (N + O) + 6 * W

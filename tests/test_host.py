@@ -87,6 +87,10 @@ def test_entry_points_validate_arguments_on_the_host(lib):
                     (dict(num_agents=3, num_landmarks=3, episode_length=0), b'episode_length')):
         bad = fm.EnvConfig(**kw).to_c(4)
         assert lib.fmarl_create(C.byref(bad), C.byref(h)) == 1 and msg in lib.fmarl_last_error()
+    glob = fm.EnvConfig(num_agents=3, num_landmarks=3, graph_feat_type='global').to_c(4)
+    assert glob.flags & 2
+    glob.num_walls = 1   # the Python side refuses this earlier; the C side must too
+    assert lib.fmarl_create(C.byref(glob), C.byref(h)) == 1 and b'global' in lib.fmarl_last_error()
     one = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=1, num_landmarks=1).to_c(4)
     assert lib.fmarl_create(C.byref(one), C.byref(h)) == 1   # the scenario needs a second-nearest goal
     form = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1).to_c(16)
@@ -117,7 +121,12 @@ def test_specs_spaces_and_unsupported_scenarios():
     with pytest.raises(NotImplementedError):
         fm.GraphMPEEnv(args)
     args.scenario_name = 'navigation_graph'
-    args.graph_feat_type = 'global'
+    args.graph_feat_type = 'global'     # navigation_graph.py:1058-1077: 7 absolute columns
+    assert fm.GraphMPEEnv(args).node_observation_space[0].shape == (72, 7)
+    args.num_walls = 1                   # the reference's global features know no walls (ValueError there too)
+    with pytest.raises(ValueError):
+        fm.GraphMPEEnv(args)
+    args.num_walls, args.scenario_name = 0, 'nav_fairassign_fairrew_formation_graph'
     with pytest.raises(NotImplementedError):
         fm.GraphMPEEnv(args)
 
