@@ -5,6 +5,13 @@
 
 #include "../../include/fmarl.h"
 
+// Phase ablation for tools/ablate.sh: compiled in only with -DFMARL_MEASURE (the shipped library has no such switch).
+#ifdef FMARL_MEASURE
+#define FMARL_SKIP(p, bit) (((p).ablate & (bit)) != 0)
+#else
+#define FMARL_SKIP(p, bit) false
+#endif
+
 namespace fmarl {
 
 // World constants: reference multiagent/core.py:153-161, :68, :38; environment.py:307.
@@ -40,7 +47,7 @@ struct Params {
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
     uint64_t seed;
     FastDiv dNEF, dEF, dF, dEE, dE, dC4, dNC4, dEE4, dE4;
-    int ablate;              // measurement aid (env FMARL_ABLATE, bench only): bit mask of phases to skip
+    int ablate;              // -DFMARL_MEASURE builds only (tools/ablate.sh): bit mask of phases to skip
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;

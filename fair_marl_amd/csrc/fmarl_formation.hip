@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     }
     __syncthreads();
     {   // the matchings (current slots; on a step also the previous slots for observation(0))
-        const int per_env = (p.ablate & 64) ? 0 : (STEP ? 2 : 1);
+        const int per_env = FMARL_SKIP(p, 64) ? 0 : (STEP ? 2 : 1);
         if (N <= 4) hungarian_tasks<4>(p, lds, nenv, per_env);
         else if (N <= 8) hungarian_tasks<8>(p, lds, nenv, per_env);
         else if (N <= 16) hungarian_tasks<16>(p, lds, nenv, per_env);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     }
     __syncthreads();
 
-    if (active && i == 0 && !(p.ablate & 128)) {   // sequential walk of the occupancy mask (one lane per env)
+    if (active && i == 0 && !FMARL_SKIP(p, 128)) {   // sequential walk of the occupancy mask (one lane per env)
         uint32_t occ = t.words()[0];
         uint32_t *m = t.masks();
         const int *gn = t.g_new(), *nr = t.near_new();
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         }
     }
     // ---- emission: node_obs (16 bytes per lane) and adj
-    if (p.ablate & 32) return;
+    if (FMARL_SKIP(p, 32)) return;
     if (o.node_obs) {
         // F = 12 = three float4 chunks per (ego, entity) row: [dv dx] [goal flag dx.x] [dx.y dx type]; the
         // workgroup streams its region front to back, one 16-byte chunk per lane (ff:896-971).

@@ -257,7 +257,7 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
     double Fx = ux, Fy = uy;   // core.py:277-298, mass 1
     // core.py:301-316 + :370-404: agent-agent, agent-obstacle, agent-wall-entity pairs
     const int first_obst = p.N + p.L, first_wall = first_obst + p.O;
-    for (int b = 0; b < ((p.ablate & 1) ? 0 : p.E); ++b) {
+    for (int b = 0; b < (FMARL_SKIP(p, 1) ? 0 : p.E); ++b) {
         if (b == i || (b >= p.N && b < first_obst)) continue;   // self; landmarks do not collide
         if (b < p.N && !agent_forces) continue;                 // status == True: core.py:394-398
         const double2 q = s_pos[b];
@@ -379,14 +379,14 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         // fairness scalar of obs_i / reward_i (:764-769, :849-854): p_dist statistics while this
         // agent's dists_to_goal is still -1, otherwise the statistics info_{i-1} left behind.
         double fairness, m, sd;
-        if (p.ablate & 2) { m = 1.0; sd = 1.0; }
+        if (FMARL_SKIP(p, 2)) { m = 1.0; sd = 1.0; }
         else if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd);
         fairness = m / (sd + 0.0001);
 
         // collisions (:701-705, :650-684)
         int ag_hits = 0;
-        for (int j = 0; j < ((p.ablate & 4) ? 0 : p.N); ++j)
+        for (int j = 0; j < (FMARL_SKIP(p, 4) ? 0 : p.N); ++j)
             if (j != i && closer_than(x, s_pos[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
         bool ob_hit = false;
         for (int k = 0; k < p.O; ++k)
@@ -410,14 +410,14 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left_new;
         p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
         if (i == 0) p.cur_step[env] = step;
-        if (o.reward && !(p.ablate & 16)) o.reward[g] = (float)rew;
+        if (o.reward && !FMARL_SKIP(p, 16)) o.reward[g] = (float)rew;
         if (o.done) o.done[g] = step >= p.episode_length;            // environment.py:237-247
-        if (o.obs && !will_reset && !(p.ablate & 16)) {               // :845-857
+        if (o.obs && !will_reset && !FMARL_SKIP(p, 16)) {               // :845-857
             float *ob = o.obs + g * p.D;
             ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;
             ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)fairness;
         }
-        if (o.info && !(p.ablate & 8)) {
+        if (o.info && !FMARL_SKIP(p, 8)) {
             // info_callback (:577-647): statistics after this agent's own update (entries <= i fresh).
             // Field-major records: info[k][env][agent], every store is lane-contiguous.
             double dm, ds, tm, ts;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         }
     }
     // emission only reads pos / agentf / wall / flag, all final since the barrier above
-    if (!(p.ablate & 32)) emit_graph(p, o, lds, env0, nenv);
+    if (!FMARL_SKIP(p, 32)) emit_graph(p, o, lds, env0, nenv);
 }
 
 }  // namespace fmarl

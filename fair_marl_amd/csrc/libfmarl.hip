@@ -282,12 +282,16 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     h->lds_bytes = (size_t)epb * p.lds_env_bytes;
-    if (const char *pad = getenv("FMARL_LDS_PAD")) h->lds_bytes += atoi(pad);   // measurement aid: lower occupancy
+#ifdef FMARL_MEASURE
+    if (const char *pad = getenv("FMARL_LDS_PAD")) h->lds_bytes += atoi(pad);   // lower occupancy
+#endif
     h->grid = (p.n_envs + epb - 1) / epb;
     const uint64_t NEF = (uint64_t)p.N * p.E * p.F, maxq = (uint64_t)epb * NEF;
     if (maxq >= (1ull << 24) || maxq * NEF >= (1ull << 40)) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large"); }
     p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
+#ifdef FMARL_MEASURE
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
+#endif
     p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
     p.vec_adj = p.E % 4 == 0;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
