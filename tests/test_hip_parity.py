@@ -375,6 +375,38 @@ def test_process_infos_matches_reference_logging():
     assert len(got) == 4 * 14 and (t_req != info[..., 1]).any()
 
 
+def test_c_abi_client_without_python_matches_the_engine():
+    """examples/rollout_capi.cpp drives libfmarl.so through include/fmarl.h alone (HIP runtime, no torch);
+    the same rollout through RolloutEngine must give the same bytes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, 'examples', 'rollout_capi')
+    assert os.path.exists(exe), 'build it: python -c "import __graft_entry__ as g; g.build()"'
+    n, N, steps, seed = 300, 5, 60, 9
+    out = subprocess.run([exe, str(n), str(N), str(steps), str(seed)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    words = out.stdout.split()
+    got = dict(zip(words[0::2], words[1::2]))
+
+    def fnv1a(t):
+        h = 1469598103934665603
+        for b in t.cpu().contiguous().view(torch.uint8).flatten().tolist():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return '%016x' % h
+    x, tape = 0x9E3779B97F4A7C15 ^ seed, []
+    for _ in range(steps * n * N):
+        x = (x * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        tape.append((x >> 33) % 5)
+    tape = torch.tensor(tape, dtype=torch.int32, device=DEV).view(steps, n, N)
+    eng = fm.RolloutEngine(fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=3), n, device=DEV, seed=seed)
+    eng.reset()
+    for t in range(steps):
+        eng.step(tape[t])
+    want = dict(obs=fnv1a(eng.obs), node_obs=fnv1a(eng.node_obs), adj=fnv1a(eng.adj_env), reward=fnv1a(eng.reward), done=fnv1a(eng.done))
+    assert got == want
+
+
 def test_vec_env_wrappers_api():
     """Names / arities / dtypes of the reference wrappers (env_wrappers.py:895-1026) on the HIP engine."""
     import argparse
