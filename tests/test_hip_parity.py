@@ -375,6 +375,36 @@ def test_process_infos_matches_reference_logging():
     assert len(got) == 4 * 14 and (t_req != info[..., 1]).any()
 
 
+def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
+    """The entry points only enqueue work on the caller's stream (no synchronisation, no host reads), so a whole
+    episode -- 25 steps and the auto-reset that ends it -- can be captured once and replayed (synchronous reset
+    mode; the staged mode owns a side stream).  Replays must equal the eager engine bit for bit."""
+    cfg = fm.EnvConfig(num_agents=5, num_landmarks=5, num_obstacles=2, num_walls=1, episode_length=8)
+    n, T = 200, 8
+    eager = fm.RolloutEngine(cfg, n, device=DEV, seed=3, async_reset=False)
+    graph = fm.RolloutEngine(cfg, n, device=DEV, seed=3, async_reset=False)
+    gen = torch.Generator(device=DEV); gen.manual_seed(2)
+    tape = torch.randint(0, 5, (T, n, 5), device=DEV, generator=gen, dtype=torch.int32)
+    eager.reset(); graph.reset()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in range(T):
+            graph.step(tape[t])
+    for ep in range(3):
+        tape.copy_(torch.randint(0, 5, (T, n, 5), device=DEV, generator=gen, dtype=torch.int32))
+        g.replay()
+        for t in range(T):
+            eager.step(tape[t])
+        torch.cuda.synchronize()
+        sa, sb = eager.get_state(), graph.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), 'episode %d %s' % (ep, k)
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+            assert torch.equal(getattr(eager, k), getattr(graph, k)), 'episode %d %s' % (ep, k)
+    assert int(eager.get_state()['episode'].min()) >= 3   # three auto-resets happened inside the replays
+
+
 def test_c_abi_client_without_python_matches_the_engine():
     """examples/rollout_capi.cpp drives libfmarl.so through include/fmarl.h alone (HIP runtime, no torch);
     the same rollout through RolloutEngine must give the same bytes."""
