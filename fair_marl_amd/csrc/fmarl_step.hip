@@ -77,19 +77,19 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
         const EnvLds t(p, lds, el);
         if (t.skip()) continue;
         float4 a[CG];
-        uint32_t boff[CG][4];   // byte offset of each element's ego value inside an ego row [vx vy x y 0]
+        uint32_t boff[CG];   // per chunk: byte offsets of the four elements' ego values inside an ego row [vx vy x y 0], 8 bits each
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
             const uint32_t c = g * 64 + lane;
             a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            boff[g][0] = boff[g][1] = boff[g][2] = boff[g][3] = 0;
+            boff[g] = 0;
             if (c < C4) {
                 uint32_t e = p.dF.div(c * 4), f = c * 4 - e * p.F;
                 float v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     v[k] = t.entity_feature(e, f);
-                    boff[g][k] = 4 * ((f == 10 || p.feat_global) ? 4 : (f < 2 ? f : 2 + (f & 1)));
+                    boff[g] |= (4 * ((f == 10 || p.feat_global) ? 4 : (f < 2 ? f : 2 + (f & 1)))) << (8 * k);
                     if (++f == (uint32_t)p.F) { f = 0; ++e; }
                 }
                 a[g] = make_float4(v[0], v[1], v[2], v[3]);
@@ -102,11 +102,6 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
         int i = 0;
         for (; i + 4 <= p.N; i += 4, dst += 4 * C4) {
             const char *ego = lds + __builtin_amdgcn_readfirstlane(ego0 + i * (kEgoWidth * 4));
-            const char *e[CG][4];
-#pragma unroll
-            for (int g = 0; g < CG; ++g)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) e[g][k] = ego + boff[g][k];
             // row-major store order: consecutive store instructions write consecutive KiB of the output
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -114,9 +109,12 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
 #pragma unroll
                 for (int g = 0; g < CG; ++g) {
                     const uint32_t c = g * 64 + lane;
-                    if (c < C4)
-                        dst[(size_t)r * C4 + c] = make_float4(a[g].x - *(const float *)(e[g][0] + ro), a[g].y - *(const float *)(e[g][1] + ro),
-                                                              a[g].z - *(const float *)(e[g][2] + ro), a[g].w - *(const float *)(e[g][3] + ro));
+                    if (c < C4) {
+                        const char *e0 = ego + (boff[g] & 255), *e1 = ego + ((boff[g] >> 8) & 255);
+                        const char *e2 = ego + ((boff[g] >> 16) & 255), *e3 = ego + (boff[g] >> 24);
+                        dst[(size_t)r * C4 + c] = make_float4(a[g].x - *(const float *)(e0 + ro), a[g].y - *(const float *)(e1 + ro),
+                                                              a[g].z - *(const float *)(e2 + ro), a[g].w - *(const float *)(e3 + ro));
+                    }
                 }
             }
         }
@@ -125,12 +123,9 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
                 const uint32_t c = g * 64 + lane;
-                if (c < C4) {
-                    float b[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) b[k] = *(const float *)(ego + boff[g][k]);
-                    dst[c] = make_float4(a[g].x - b[0], a[g].y - b[1], a[g].z - b[2], a[g].w - b[3]);
-                }
+                if (c < C4)
+                    dst[c] = make_float4(a[g].x - *(const float *)(ego + (boff[g] & 255)), a[g].y - *(const float *)(ego + ((boff[g] >> 8) & 255)),
+                                         a[g].z - *(const float *)(ego + ((boff[g] >> 16) & 255)), a[g].w - *(const float *)(ego + (boff[g] >> 24)));
             }
         }
     }
@@ -237,12 +232,13 @@ __device__ __forceinline__ void mixed_stats(const double *fresh, const double *s
     sd = sqrt(q / n);
 }
 
-// World.step (core.py:250-274) for agent i of one env: action force (core.py:277-298 with the
-// decode of environment.py:265-311), entity and wall collision forces (core.py:301-335, :370-462) out of
-// the LDS entity table (positions of the PREVIOUS step), integrate (core.py:338-356).  Updates x, v, pd.
-__device__ __forceinline__ void world_step_agent(const Params &p, const char *base, int i, size_t g,
-                                                 const int32_t *action_idx, const float *action_vec,
-                                                 double2 &x, double2 &v, double &pd, bool agent_forces = true) {
+// First half of World.step (core.py:250-274) for agent i of one env: action force (core.py:277-298 with the
+// decode of environment.py:265-311) + entity and wall collision forces (core.py:301-335, :370-462) out of
+// the LDS entity table (positions of the PREVIOUS step).  Only the position is needed here, so callers
+// can leave velocity / path length in memory until integrate_agent (fewer live registers across the pair loop).
+__device__ __forceinline__ double2 agent_force(const Params &p, const char *base, int i, size_t g,
+                                               const int32_t *action_idx, const float *action_vec,
+                                               const double2 x, bool agent_forces = true) {
     const double2 *s_pos = (const double2 *)(base + p.lds_pos);
     double ux, uy;
     if (action_idx) {
@@ -306,9 +302,13 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
         Fx += horiz ? fpar : fperp;
         Fy += horiz ? fperp : fpar;
     }
-    // core.py:338-356 integrate
-    v.x = v.x * (1 - kDamping) + Fx * kDt;
-    v.y = v.y * (1 - kDamping) + Fy * kDt;
+    return make_double2(Fx, Fy);
+}
+
+// core.py:338-356 integrate_state: updates x, v, pd
+__device__ __forceinline__ void integrate_agent(const Params &p, const double2 F, double2 &x, double2 &v, double &pd) {
+    v.x = v.x * (1 - kDamping) + F.x * kDt;
+    v.y = v.y * (1 - kDamping) + F.y * kDt;
     if (p.has_max_speed) {
         double speed = sqrt(v.x * v.x + v.y * v.y);
         if (speed > p.max_speed) { v.x = v.x / speed * p.max_speed; v.y = v.y / speed * p.max_speed; }
@@ -316,6 +316,14 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
     x.x += v.x * kDt; x.y += v.y * kDt;
     double sx = v.x * kDt, sy = v.y * kDt;
     pd += sqrt(sx * sx + sy * sy);
+}
+
+// World.step for agent i: both halves.
+__device__ __forceinline__ void world_step_agent(const Params &p, const char *base, int i, size_t g,
+                                                 const int32_t *action_idx, const float *action_vec,
+                                                 double2 &x, double2 &v, double &pd, bool agent_forces = true) {
+    const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x, agent_forces);
+    integrate_agent(p, F, x, v, pd);
 }
 
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
@@ -336,10 +344,8 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     double pd = 0;
     int step = 0, match = 0;
     if (active) {
-        x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
-        match = p.goal_match[g];
+        x = p.agent_pos[g];
         s_pos[i] = x;
-        step = p.cur_step[env] + 1;   // environment.py:819, :823
     }
     load_statics(p, lds, env0, nenv);
     __syncthreads();
@@ -347,8 +353,13 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     // ---- World.step (core.py:250-274) ---------------------------------------------------------
     double2 goal = make_double2(0, 0);
     if (active) {
+        const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x);
+        // everything else of the agent's state is first needed here: loaded after the pair loop, not carried through it
+        v = p.agent_vel[g]; pd = p.p_dist[g];
+        match = p.goal_match[g];
+        step = p.cur_step[env] + 1;   // environment.py:819, :823
         goal = s_pos[p.N + match];
-        world_step_agent(p, base, i, g, action_idx, action_vec, x, v, pd);
+        integrate_agent(p, F, x, v, pd);
     }
     __syncthreads();   // every lane has finished reading the old positions
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # measurement aid: step time with phases of the step kernel skipped (FMARL_ABLATE bit mask).
 # Runs on the GPU box with a -DFMARL_MEASURE build of the library (the shipped build has no such switch); restores it after.
-cd "$(dirname "$0")/../fair_marl_amd/csrc" && cp libfmarl.so libfmarl_ship.so && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFMARL_MEASURE -shared -fPIC -o libfmarl.so libfmarl.hip && cd ../..
+cd "$(dirname "$0")/../fair_marl_amd/csrc" && cp libfmarl.so libfmarl_ship.so && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -DFMARL_MEASURE -shared -fPIC -o libfmarl.so libfmarl.hip && cd ../..
 for m in 0 1 2 4 8 16 31 32 33 35 39 47 63; do
   FMARL_ABLATE=$m python bench.py --steps 50 --warmup 25 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ablate=%3s  ms_per_step=%.3f  kernel_avg_ms=%.3f' % ('$m', d['ms_per_step'], d['roofline']['kernel_avg_ms']))"
 done
