@@ -17,6 +17,7 @@ the host each step, which only makes sense for small ``n_rollout_threads``.
 from abc import ABC, abstractmethod
 
 import numpy as np
+import torch
 
 from .engine import RolloutEngine
 from .infos import LazyInfos
@@ -80,9 +81,18 @@ class _EngineVecEnv(ShareVecEnv):
         self.agent_id_observation_space = spec.agent_id_observation_space
         self.share_agent_id_observation_space = spec.share_agent_id_observation_space
         self.actions = None
+        self._staging = None
+        self._act_pin = None
 
     def step_async(self, actions):
-        self.actions = np.asarray(actions)
+        # (n, N, 5) one-hot / continuous floats or (n, N) indices; through a pinned buffer (pageable copies stall)
+        a = np.asarray(actions)
+        a = a.astype(np.float32 if a.ndim == 3 else np.int32, copy=False)
+        if self._act_pin is None or tuple(self._act_pin.shape) != a.shape or self._act_pin.numpy().dtype != a.dtype:
+            self._act_pin = torch.empty(a.shape, dtype=torch.float32 if a.ndim == 3 else torch.int32, pin_memory=True)
+        self._act_pin.numpy()[...] = a
+        # safe to reuse next step: step_wait ends with a stream synchronisation
+        self.actions = self._act_pin.to(self.engine.device, non_blocking=True)
 
     def _step_device(self):
         obs, ids, node, adj, rew, done, info = self.engine.step(self.actions, auto_reset=True)
@@ -93,9 +103,25 @@ class _EngineVecEnv(ShareVecEnv):
             rew = rew.sum(dim=1, keepdim=True).expand_as(rew).unsqueeze(-1)
         return obs, ids, node, adj, rew, done, info
 
-    @staticmethod
-    def _np(t, dtype):
-        return t.detach().cpu().numpy().astype(dtype)
+    def _fetch(self, *tensors):
+        """Device tensors -> fresh float64 NumPy arrays of the same shapes (what the reference's workers pipe back).
+        The widening and the materialisation of stride-0 views (the per-agent adj) happen on the device; everything
+        crosses PCIe in ONE copy into a pinned staging buffer, from which the caller-owned arrays are cut."""
+        flat = torch.cat([t.detach().to(torch.float64).reshape(-1) for t in tensors])
+        if self._staging is None or self._staging.numel() < flat.numel():
+            self._staging = torch.empty(flat.numel(), dtype=torch.float64, pin_memory=True)
+        host = self._staging[:flat.numel()]
+        host.copy_(flat, non_blocking=True)
+        torch.cuda.current_stream(self.engine.device).synchronize()
+        arr, out, o = host.numpy(), [], 0
+        for t in tensors:
+            out.append(arr[o:o + t.numel()].reshape(tuple(t.shape)).copy())
+            o += t.numel()
+        return out
+
+    def _agent_ids(self):
+        n, N = self.engine.n_envs, self.spec.cfg.N
+        return np.broadcast_to(np.arange(N, dtype=np.int64).reshape(1, N, 1), (n, N, 1)).copy()
 
     def close_extras(self):
         self.engine.close()
@@ -112,14 +138,13 @@ class GraphSubprocVecEnv(_EngineVecEnv):
 
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
-        return (self._np(obs, np.float64), self._np(ids, np.int64), self._np(node, np.float64),
-                self._np(adj, np.float64), self._np(rew, np.float64), self._np(done, bool),
-                LazyInfos(self._np(info, np.float64), self.spec.cfg.scenario_name))
+        obs, node, adj, rew, done, info = self._fetch(obs, node, adj, rew, done, info)
+        return obs, self._agent_ids(), node, adj, rew, done != 0, LazyInfos(info, self.spec.cfg.scenario_name)
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()
-        return (self._np(obs, np.float64), self._np(ids, np.int64), self._np(node, np.float64),
-                self._np(adj, np.float64))
+        obs, node, adj = self._fetch(obs, node, adj)
+        return obs, self._agent_ids(), node, adj
 
 
 class GraphDummyVecEnv(GraphSubprocVecEnv):
@@ -142,12 +167,12 @@ class SubprocVecEnv(_EngineVecEnv):
 
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
-        return (self._np(obs, np.float64), self._np(rew, np.float64), self._np(done, bool),
-                LazyInfos(self._np(info, np.float64), self.spec.cfg.scenario_name))
+        obs, rew, done, info = self._fetch(obs, rew, done, info)
+        return obs, rew, done != 0, LazyInfos(info, self.spec.cfg.scenario_name)
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()
-        return self._np(obs, np.float64)
+        return self._fetch(obs)[0]
 
 
 class DummyVecEnv(SubprocVecEnv):
