@@ -209,6 +209,59 @@ def test_rebuild_is_refused_for_other_scenarios():
         eng.pack_episode()
 
 
+SHARD_CASES = [dict(num_agents=6, num_landmarks=6, num_obstacles=3, num_walls=1, episode_length=9),
+               dict(scenario_name='fair_graph_formation', num_agents=5, num_landmarks=1, num_obstacles=2, episode_length=9),
+               dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=4, num_landmarks=4, num_obstacles=2,
+                    episode_length=9)]
+
+
+@pytest.mark.parametrize('kw', SHARD_CASES, ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
+def test_shards_reproduce_the_unsharded_rollout(kw):
+    """Multi-GPU sharding: random streams are keyed by the GLOBAL env index (FmarlConfig.env_offset), so two
+    shards stepping their slices give the very bytes of the unsharded engine -- resets, auto-resets included."""
+    cfg = fm.EnvConfig(**kw)
+    n, cut, N = 96, 40, cfg.N
+    whole = fm.RolloutEngine(cfg, n, device=DEV, seed=17)
+    parts = [fm.RolloutEngine(cfg, cut, device=DEV, seed=17, env_offset=0),
+             fm.RolloutEngine(cfg, n - cut, device=DEV, seed=17, env_offset=cut)]
+    g = torch.Generator(device=DEV); g.manual_seed(6)
+
+    def same(msg):
+        sw = whole.get_state()
+        sp = [e.get_state() for e in parts]
+        for k in sw:
+            assert np.array_equal(sw[k], np.concatenate([sp[0][k], sp[1][k]])), msg + ' state ' + k
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+            assert torch.equal(getattr(whole, k), torch.cat([getattr(e, k) for e in parts])), msg + ' ' + k
+    whole.reset(); parts[0].reset(); parts[1].reset()
+    same('reset')
+    for t in range(22):
+        a = torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32)
+        whole.step(a); parts[0].step(a[:cut].contiguous()); parts[1].step(a[cut:].contiguous())
+        same('step %d' % t)
+
+
+def test_index_math_beyond_2_to_the_32_elements():
+    """300 000 envs of the cfg 3 shape on one GPU: node_obs has 7.6e9 elements (> 2^32).  The first and the last
+    envs must equal small engines placed at the same global env indices."""
+    cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
+    n, k = 300000, 48
+    big = fm.RolloutEngine(cfg, n, device=DEV, seed=4, emit_info=False)
+    assert big.node_obs.numel() > 2 ** 32
+    lo = fm.RolloutEngine(cfg, k, device=DEV, seed=4, env_offset=0, emit_info=False)
+    hi = fm.RolloutEngine(cfg, k, device=DEV, seed=4, env_offset=n - k, emit_info=False)
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    big.reset(); lo.reset(); hi.reset()
+    for t in range(3):
+        a = torch.randint(0, 5, (n, 32), device=DEV, generator=g, dtype=torch.int32)
+        big.step(a); lo.step(a[:k].contiguous()); hi.step(a[n - k:].contiguous())
+        for name in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+            assert torch.equal(getattr(big, name)[:k], getattr(lo, name)), 'first envs, step %d %s' % (t, name)
+            assert torch.equal(getattr(big, name)[n - k:], getattr(hi, name)), 'last envs, step %d %s' % (t, name)
+    del big
+    torch.cuda.empty_cache()
+
+
 def test_long_horizon_n32_three_episodes():
     """Trajectory-level parity at the dense BASELINE config-3 shape over three whole episodes (75 steps,
     three auto-resets): f64 device state keeps following the f64 oracle (SURVEY section 7 hard part 2)."""
