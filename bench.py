@@ -130,6 +130,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started by hand: launch one rank per GPU as a child job (nothing here has touched the GPU yet)
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        raise SystemExit(subprocess.call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                          '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+                                          '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]))
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)'
                          % (args.gpus, world))
