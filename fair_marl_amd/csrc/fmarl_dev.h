@@ -144,4 +144,58 @@ __device__ __forceinline__ bool wall_box_hit(double2 p, double axis, double e0, 
            (1.05 * (e0 - s / 2) <= ppar) && (ppar <= 1.05 * (e1 + s / 2));
 }
 
+// Lane exchange inside a 16-lane DPP row (no LDS crossbar, a few cycles instead of a ds_bpermute round
+// trip): quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror.  For a symmetric reduction
+// (min / argmin) the mirrors do the job of xor 4 / xor 8: after the quad steps every quad is uniform.
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL> __device__ __forceinline__ void argmin_step(double &best, int &bj) {
+    const double ob = dpp_f64<CTRL>(best);
+    const int oj = dpp_i32<CTRL>(bj);
+    if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+}
+// (value, index) argmin over a group of G lanes (G = 4, 8, 16 inside one DPP row; 32 adds one shuffle)
+template <int G> __device__ __forceinline__ void group_argmin(double &best, int &bj) {
+    argmin_step<0xB1>(best, bj);                 // quad_perm [1,0,3,2]
+    argmin_step<0x4E>(best, bj);                 // quad_perm [2,3,0,1]
+    if (G >= 8) argmin_step<0x141>(best, bj);    // row_half_mirror
+    if (G >= 16) argmin_step<0x140>(best, bj);   // row_mirror
+    if (G >= 32) {
+        const double ob = __shfl_xor(best, 16, G);
+        const int oj = __shfl_xor(bj, 16, G);
+        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+}
+
+template <int CTRL> __device__ __forceinline__ void argmax_step(double &best, int &bj) {
+    const double ob = dpp_f64<CTRL>(best);
+    const int oj = dpp_i32<CTRL>(bj);
+    if (ob > best || (ob == best && oj > bj)) { best = ob; bj = oj; }
+}
+// (value, index) argmax over a group of G lanes, largest (value, index) pair wins
+template <int G> __device__ __forceinline__ void group_argmax(double &best, int &bj) {
+    argmax_step<0xB1>(best, bj);
+    argmax_step<0x4E>(best, bj);
+    if (G >= 8) argmax_step<0x141>(best, bj);
+    if (G >= 16) argmax_step<0x140>(best, bj);
+#pragma unroll
+    for (int off = 16; off < G; off <<= 1) {
+        const double ob = __shfl_xor(best, off, G);
+        const int oj = __shfl_xor(bj, off, G);
+        if (ob > best || (ob == best && oj > bj)) { best = ob; bj = oj; }
+    }
+}
+// bitwise OR over a group of G lanes, result in every lane
+template <int G> __device__ __forceinline__ uint32_t group_or32(uint32_t v) {
+    v |= (uint32_t)dpp_i32<0xB1>((int)v);
+    v |= (uint32_t)dpp_i32<0x4E>((int)v);
+    if (G >= 8) v |= (uint32_t)dpp_i32<0x141>((int)v);
+    if (G >= 16) v |= (uint32_t)dpp_i32<0x140>((int)v);
+#pragma unroll
+    for (int off = 16; off < G; off <<= 1) v |= (uint32_t)__shfl_xor((int)v, off, G);
+    return v;
+}
+
 }  // namespace fmarl

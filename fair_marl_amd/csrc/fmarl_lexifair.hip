@@ -25,11 +25,10 @@ template <> struct MaskOf<8> { using type = uint32_t; };
 template <> struct MaskOf<16> { using type = uint32_t; };
 template <> struct MaskOf<32> { using type = uint32_t; };
 
-template <int G, typename M>
-__device__ __forceinline__ M group_or(M v) {
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1) v |= __shfl_xor(v, off, G);
-    return v;
+// row / column sets: OR over the group, by DPP inside 16-lane rows + one shuffle per doubling beyond (fmarl_dev.h)
+template <int G> __device__ __forceinline__ uint32_t group_or(uint32_t v) { return group_or32<G>(v); }
+template <int G> __device__ __forceinline__ uint64_t group_or(uint64_t v) {
+    return ((uint64_t)group_or32<G>((uint32_t)(v >> 32)) << 32) | group_or32<G>((uint32_t)v);
 }
 __device__ __forceinline__ int lowest_bit(uint32_t m) { return __builtin_ctz(m); }
 __device__ __forceinline__ int lowest_bit(uint64_t m) { return __builtin_ctzll(m); }
@@ -68,12 +67,7 @@ __device__ int lexifair_group(const double (&c)[G], int N) {
         const bool arow = (R >> lane) & 1;
         double kc = arow ? mycost : -__builtin_huge_val();
         int kidx = arow ? lane * G + mc : -1;
-#pragma unroll
-        for (int off = G / 2; off >= 1; off >>= 1) {
-            double oc = __shfl_xor(kc, off, G);
-            int oi = __shfl_xor(kidx, off, G);
-            if (oc > kc || (oc == kc && oi > kidx)) { kc = oc; kidx = oi; }
-        }
+        group_argmax<G>(kc, kidx);
         const int rstar = kidx / G, cstar = kidx - rstar * G;
         // 2. edges of this row with a strictly smaller key, restricted to the free columns
         M adj = 0;
@@ -85,29 +79,27 @@ __device__ int lexifair_group(const double (&c)[G], int N) {
             }
             adj &= C;
         }
-        // 3. alternating BFS from the freed row r* to the freed column c*
+        // 3. alternating BFS from the freed row r* to the freed column c*; rows and columns remember the level
+        //    they were reached at, the path itself is only traced when there is one
         M F = one << rstar, VC = 0;
-        int parent = -1;
+        int rlvl = lane == rstar ? 0 : -1, clvl = -1;
         bool found = false;
         for (int lvl = 0; lvl < N; ++lvl) {
-            const M nc = group_or<G, M>(((F >> lane) & 1) ? adj : (M)0) & ~VC;
+            const M nc = group_or<G>(((F >> lane) & 1) ? adj : (M)0) & ~VC;
             if (nc == 0) break;
             const bool newcol = (nc >> lane) & 1;
-            int pr = -1;
-            for (M Fi = F; Fi != 0; Fi &= Fi - 1) {
-                const int r = lowest_bit(Fi);
-                const M ar = __shfl(adj, r, G);
-                if (newcol && pr < 0 && ((ar >> lane) & 1)) pr = r;
-            }
-            if (newcol) parent = pr;
+            if (newcol) clvl = lvl;
             VC |= nc;
             if ((nc >> cstar) & 1) { found = true; break; }
-            F = group_or<G, M>(newcol ? (M)(one << mr) : (M)0);
+            F = group_or<G>(newcol ? (M)(one << mr) : (M)0);
+            if ((F >> lane) & 1) rlvl = lvl + 1;
         }
-        if (found) {   // flip the path: every matched key is now smaller than the old maximum
+        if (found) {   // flip a shortest path back from c*: every matched key is now smaller than the old maximum
             int ccur = cstar;
             for (int hop = 0; hop < N; ++hop) {
-                const int r = __shfl(parent, ccur, G);
+                const int lc = __shfl(clvl, ccur, G);   // ccur was reached from some row of level lc
+                const M cand = group_or<G>((rlvl == lc && ((adj >> ccur) & 1)) ? (M)(one << lane) : (M)0);
+                const int r = lowest_bit(cand);
                 const int cprev = __shfl(mc, r, G);
                 if (lane == r) mc = ccur;
                 if (lane == ccur) mr = r;
