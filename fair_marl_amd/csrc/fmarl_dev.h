@@ -172,7 +172,9 @@ template <int G> __device__ __forceinline__ void group_argmin(double &best, int 
 template <int CTRL> __device__ __forceinline__ void argmax_step(double &best, int &bj) {
     const double ob = dpp_f64<CTRL>(best);
     const int oj = dpp_i32<CTRL>(bj);
-    if (ob > best || (ob == best && oj > bj)) { best = ob; bj = oj; }
+    const bool take = (ob > best) | ((ob == best) & (oj > bj));   // selects, not branches
+    best = take ? ob : best;
+    bj = take ? oj : bj;
 }
 // (value, index) argmax over a group of G lanes, largest (value, index) pair wins
 template <int G> __device__ __forceinline__ void group_argmax(double &best, int &bj) {
@@ -184,7 +186,9 @@ template <int G> __device__ __forceinline__ void group_argmax(double &best, int 
     for (int off = 16; off < G; off <<= 1) {
         const double ob = __shfl_xor(best, off, G);
         const int oj = __shfl_xor(bj, off, G);
-        if (ob > best || (ob == best && oj > bj)) { best = ob; bj = oj; }
+        const bool take = (ob > best) | ((ob == best) & (oj > bj));
+        best = take ? ob : best;
+        bj = take ? oj : bj;
     }
 }
 // bitwise OR over a group of G lanes, result in every lane

@@ -52,8 +52,11 @@ __device__ int lexifair_group(const double (&c)[G], int N) {
             double best = __builtin_huge_val();
             int bj = 0;
 #pragma unroll
-            for (int j = 0; j < G; ++j)
-                if (((freec >> j) & 1) && c[j] < best) { best = c[j]; bj = j; }
+            for (int j = 0; j < G; ++j) {   // branch-free: selects, no exec-mask games per column
+                const bool take = (bool)((freec >> j) & 1) & (c[j] < best);
+                best = take ? c[j] : best;
+                bj = take ? j : bj;
+            }
             const int pick = __shfl(bj, r, G);
             if (lane == r) { mc = bj; mycost = best; }
             if (lane == pick) mr = r;
@@ -70,15 +73,17 @@ __device__ int lexifair_group(const double (&c)[G], int N) {
         group_argmax<G>(kc, kidx);
         const int rstar = kidx / G, cstar = kidx - rstar * G;
         // 2. edges of this row with a strictly smaller key, restricted to the free columns
-        M adj = 0;
-        if (arow) {
+        //    (branch-free: one mask of the cheaper entries, one of the equally expensive ones, of which
+        //    those with a smaller column index than thr = kidx - lane * G count)
+        M lt = 0, eq = 0;
 #pragma unroll
-            for (int j = 0; j < G; ++j) {
-                bool lt = c[j] < kc || (c[j] == kc && lane * G + j < kidx);
-                if (lt) adj |= one << j;
-            }
-            adj &= C;
+        for (int j = 0; j < G; ++j) {
+            lt |= (M)(c[j] < kc) << j;
+            eq |= (M)(c[j] == kc) << j;
         }
+        const int thr = kidx - lane * G;
+        const M below = thr <= 0 ? (M)0 : (thr >= G ? ~(M)0 : (M)((one << (thr & (G - 1))) - 1));
+        const M adj = arow ? (lt | (eq & below)) & C : (M)0;
         // 3. alternating BFS from the freed row r* to the freed column c*; rows and columns remember the level
         //    they were reached at, the path itself is only traced when there is one
         M F = one << rstar, VC = 0;
