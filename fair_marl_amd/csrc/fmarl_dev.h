@@ -154,7 +154,9 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
 template <int CTRL> __device__ __forceinline__ void argmin_step(double &best, int &bj) {
     const double ob = dpp_f64<CTRL>(best);
     const int oj = dpp_i32<CTRL>(bj);
-    if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    const bool take = (ob < best) | ((ob == best) & (oj < bj));   // selects, not branches
+    best = take ? ob : best;
+    bj = take ? oj : bj;
 }
 // (value, index) argmin over a group of G lanes (G = 4, 8, 16 inside one DPP row; 32 adds one shuffle)
 template <int G> __device__ __forceinline__ void group_argmin(double &best, int &bj) {
@@ -165,7 +167,9 @@ template <int G> __device__ __forceinline__ void group_argmin(double &best, int 
     if (G >= 32) {
         const double ob = __shfl_xor(best, 16, G);
         const int oj = __shfl_xor(bj, 16, G);
-        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        const bool take = (ob < best) | ((ob == best) & (oj < bj));
+        best = take ? ob : best;
+        bj = take ? oj : bj;
     }
 }
 
