@@ -151,49 +151,36 @@ template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __bui
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
 }
-template <int CTRL> __device__ __forceinline__ void argmin_step(double &best, int &bj) {
-    const double ob = dpp_f64<CTRL>(best);
-    const int oj = dpp_i32<CTRL>(bj);
-    const bool take = (ob < best) | ((ob == best) & (oj < bj));   // selects, not branches
-    best = take ? ob : best;
-    bj = take ? oj : bj;
-}
-// (value, index) argmin over a group of G lanes (G = 4, 8, 16 inside one DPP row; 32 adds one shuffle)
-template <int G> __device__ __forceinline__ void group_argmin(double &best, int &bj) {
-    argmin_step<0xB1>(best, bj);                 // quad_perm [1,0,3,2]
-    argmin_step<0x4E>(best, bj);                 // quad_perm [2,3,0,1]
-    if (G >= 8) argmin_step<0x141>(best, bj);    // row_half_mirror
-    if (G >= 16) argmin_step<0x140>(best, bj);   // row_mirror
-    if (G >= 32) {
-        const double ob = __shfl_xor(best, 16, G);
-        const int oj = __shfl_xor(bj, 16, G);
-        const bool take = (ob < best) | ((ob == best) & (oj < bj));
-        best = take ? ob : best;
-        bj = take ? oj : bj;
-    }
-}
-
-template <int CTRL> __device__ __forceinline__ void argmax_step(double &best, int &bj) {
-    const double ob = dpp_f64<CTRL>(best);
-    const int oj = dpp_i32<CTRL>(bj);
-    const bool take = (ob > best) | ((ob == best) & (oj > bj));   // selects, not branches
-    best = take ? ob : best;
-    bj = take ? oj : bj;
-}
-// (value, index) argmax over a group of G lanes, largest (value, index) pair wins
-template <int G> __device__ __forceinline__ void group_argmax(double &best, int &bj) {
-    argmax_step<0xB1>(best, bj);
-    argmax_step<0x4E>(best, bj);
-    if (G >= 8) argmax_step<0x141>(best, bj);
-    if (G >= 16) argmax_step<0x140>(best, bj);
+// min / max of a double over a group of G lanes, result in every lane
+template <int G, bool MAX> __device__ __forceinline__ double group_extreme(double v) {
+#define FMARL_EXT_STEP(o) { const double o_ = (o); v = (MAX ? o_ > v : o_ < v) ? o_ : v; }
+    FMARL_EXT_STEP(dpp_f64<0xB1>(v))                 // quad_perm [1,0,3,2]
+    FMARL_EXT_STEP(dpp_f64<0x4E>(v))                 // quad_perm [2,3,0,1]
+    if (G >= 8) FMARL_EXT_STEP(dpp_f64<0x141>(v))    // row_half_mirror
+    if (G >= 16) FMARL_EXT_STEP(dpp_f64<0x140>(v))   // row_mirror
 #pragma unroll
-    for (int off = 16; off < G; off <<= 1) {
-        const double ob = __shfl_xor(best, off, G);
-        const int oj = __shfl_xor(bj, off, G);
-        const bool take = (ob > best) | ((ob == best) & (oj > bj));
-        best = take ? ob : best;
-        bj = take ? oj : bj;
-    }
+    for (int off = 16; off < G; off <<= 1) FMARL_EXT_STEP(__shfl_xor(v, off, G))
+#undef FMARL_EXT_STEP
+    return v;
+}
+// lowest (LAST = false) or highest lane index inside the group whose predicate holds; G if none
+template <int G, bool LAST> __device__ __forceinline__ int group_pick_lane(bool pred) {
+    const unsigned long long m = __ballot(pred);
+    const int base = (threadIdx.x & 63) & ~(G - 1);
+    const unsigned long long g = G == 64 ? m : (m >> base) & ((1ull << (G & 63)) - 1);
+    if (g == 0) return G;
+    return LAST ? 63 - __builtin_clzll(g) : __builtin_ctzll(g);
+}
+// (value, lane) argmin over a group: smallest value, ties to the lowest lane; lanes with valid = false do not
+// take part.  One value reduction + one ballot instead of reducing (value, index) pairs.
+template <int G> __device__ __forceinline__ void group_argmin(double v, bool valid, double &best, int &lane_out) {
+    best = group_extreme<G, false>(valid ? v : __builtin_huge_val());
+    lane_out = group_pick_lane<G, false>(valid & (v == best));
+}
+// (value, lane) argmax: largest value, ties to the highest lane
+template <int G> __device__ __forceinline__ void group_argmax(double v, bool valid, double &best, int &lane_out) {
+    best = group_extreme<G, true>(valid ? v : -__builtin_huge_val());
+    lane_out = group_pick_lane<G, true>(valid & (v == best));
 }
 // bitwise OR over a group of G lanes, result in every lane
 template <int G> __device__ __forceinline__ uint32_t group_or32(uint32_t v) {

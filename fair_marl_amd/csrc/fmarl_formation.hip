@@ -45,11 +45,8 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *
                 const double cur = dist2(x[i0], Pc) - ui0 - v;
                 if (cur < minv) { minv = cur; way = j0; }
             }
-            double best = open ? minv : INF;
-            int bj = open ? lane : G;
-            group_argmin<G>(best, bj);
-            const double delta = best;
-            j1 = bj;
+            double delta;
+            group_argmin<G>(minv, open, delta, j1);   // ties to the lowest column
             if (in_tree) u += delta;
             if (usedc) v -= delta; else if (lane < N) minv -= delta;
             if (lane == j1) usedc = true;

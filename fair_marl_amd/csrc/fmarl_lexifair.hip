@@ -67,11 +67,12 @@ __device__ int lexifair_group(const double (&c)[G], int N) {
 
     for (int iter = 0; R != 0 && iter < N * N + N + 8; ++iter) {
         // 1. matched edge with the largest key (cost, row * G + col) among the free rows
+        //    (equal costs: the highest row wins, which is the largest row * G + col)
         const bool arow = (R >> lane) & 1;
-        double kc = arow ? mycost : -__builtin_huge_val();
-        int kidx = arow ? lane * G + mc : -1;
-        group_argmax<G>(kc, kidx);
-        const int rstar = kidx / G, cstar = kidx - rstar * G;
+        double kc;
+        int rstar;
+        group_argmax<G>(mycost, arow, kc, rstar);
+        const int cstar = __shfl(mc, rstar, G), kidx = rstar * G + cstar;
         // 2. edges of this row with a strictly smaller key, restricted to the free columns
         //    (branch-free: one mask of the cheaper entries, one of the equally expensive ones, of which
         //    those with a smaller column index than thr = kidx - lane * G count)
