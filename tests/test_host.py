@@ -81,6 +81,9 @@ def test_entry_points_validate_arguments_on_the_host(lib):
     assert lib.fmarl_edge_count(None, None, 1, 1, 1.0, 1, None) == 1
     assert lib.fmarl_info_means(None, None, 1, 1, 2.5, None) == 1
     assert lib.fmarl_state_changed(None) == 1
+    assert lib.fmarl_pack_episode(h, None, None, None) == 1 and lib.fmarl_rebuild_graph(h, None, None, 4, None, None, None) == 1
+    assert lib.fmarl_episode_started(None) == 0 and lib.fmarl_episode_started(h) == 0
+    assert lib.fmarl_episode_record_words(C.byref(c)) == 2 * 3 + 2 * (3 + 3) + 0
     assert lib.fmarl_get_state(h, None, 0, None, None) == 1 and lib.fmarl_set_state(h, None, 99, None, None) == 1
     assert lib.fmarl_destroy(h) == 0
     for kw, msg in ((dict(num_agents=0, num_landmarks=0), b'num_agents'), (dict(num_agents=3, num_landmarks=3, num_walls=3), b'num_walls'),
