@@ -46,7 +46,7 @@ struct Params {
     int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
     uint64_t seed;
-    FastDiv dNEF, dEF, dF, dEE, dE, dC4, dNC4, dEE4, dE4;
+    FastDiv dNEF, dEF, dF, dEE, dE, dNE, dC4, dNC4, dEE4, dE4;
     int ablate;              // -DFMARL_MEASURE builds only (tools/ablate.sh): bit mask of phases to skip
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
     // formation scenario: extra per-env LDS tables (byte offsets) and state

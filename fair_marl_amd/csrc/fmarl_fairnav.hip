@@ -43,35 +43,39 @@ struct FairNavLds {
     __device__ int *words() const { return (int *)(base + p.n_words); }             // a*, all-done, free-empty
     __device__ bool skip() const { return *flag() != 0; }
 
-    // feature f of entity e in the row block of ego i (nf:1222-1334), ego part included
-    __device__ float node_feature(uint32_t i, uint32_t e, uint32_t f) const {
+    // the 13 features of entity e in the row block of ego i (nf:1222-1334), ego part included:
+    // [dv (2) | dx (2) | goal or dx (2) | occupancy, history / 1, index | dx or wall corners (4) | type]
+    __device__ void node_row(uint32_t i, uint32_t e, float (&o)[13]) const {
         const uint32_t N = p.N, first_obst = p.N + p.L, first_wall = first_obst + p.O;
-        if (f == 12) return e < N ? 0.f : (e < first_obst ? 1.f : (e < first_wall ? 2.f : 3.f));
-        const double2 xi = pos()[i];
-        if (f < 2) {   // velocities as they stand when graph_observation(i) runs: reward(a <= i) may have stopped a
-            const float4 ai = agentf()[i];
-            const float vi = ai.z != 0.f ? 0.f : (f == 0 ? ai.x : ai.y);
-            if (e >= N) return 0.f - vi;
+        const double2 xi = pos()[i], xe = pos()[e];
+        const float dx = (float)(xe.x - xi.x), dy = (float)(xe.y - xi.y);
+        // velocities as they stand when graph_observation(i) runs: reward(a <= i) may have stopped a
+        const float4 ai = agentf()[i];
+        const float vix = ai.z != 0.f ? 0.f : ai.x, viy = ai.z != 0.f ? 0.f : ai.y;
+        float vex = 0.f, vey = 0.f;
+        if (e < N) {
             const float4 ae = agentf()[e];
-            const float ve = (e <= i && ae.z != 0.f) ? 0.f : (f == 0 ? ae.x : ae.y);
-            return ve - vi;
+            const bool stopped = e <= i && ae.z != 0.f;
+            vex = stopped ? 0.f : ae.x; vey = stopped ? 0.f : ae.y;
         }
-        if (e < N && f >= 4 && f < 8) {
+        o[0] = vex - vix; o[1] = vey - viy;
+        o[2] = dx; o[3] = dy; o[4] = dx; o[5] = dy; o[8] = dx; o[9] = dy; o[10] = dx; o[11] = dy;
+        if (e < N) {
             const NavRow r = rows()[i * N + e];
-            if (f == 6) return r.occ;
-            if (f == 7) return r.hist;
-            const double2 gl = r.code >= 0 ? pos()[N + r.code] : pos()[e];
-            return (float)(f == 4 ? gl.x - xi.x : gl.y - xi.y);
+            const double2 gl = r.code >= 0 ? pos()[N + r.code] : xe;
+            o[4] = (float)(gl.x - xi.x); o[5] = (float)(gl.y - xi.y);
+            o[6] = r.occ; o[7] = r.hist;
+            o[12] = 0.f;
+        } else {
+            o[6] = 1.f;
+            o[7] = e < first_obst ? (float)(e - N) : (e < first_wall ? 0.f : (float)(e - first_wall));
+            o[12] = e < first_obst ? 1.f : (e < first_wall ? 2.f : 3.f);
         }
-        if (e >= N && f == 6) return 1.f;
-        if (e >= N && f == 7) return e < first_obst ? (float)(e - N) : (e < first_wall ? 0.f : (float)(e - first_wall));
-        if (e >= first_wall && f >= 8) {   // corners (e0, axis + w/2), (e1, axis - w/2)
+        if (e >= first_wall) {   // corners (e0, axis + w/2), (e1, axis - w/2)
             const double *wl = wall() + (e - first_wall) * 4;
-            const double c = f == 8 ? wl[1] : (f == 9 ? wl[0] + kWallWidth / 2 : (f == 10 ? wl[2] : wl[0] - kWallWidth / 2));
-            return (float)(c - ((f & 1) ? xi.y : xi.x));
+            o[8] = (float)(wl[1] - xi.x); o[9] = (float)(wl[0] + kWallWidth / 2 - xi.y);
+            o[10] = (float)(wl[2] - xi.x); o[11] = (float)(wl[0] - kWallWidth / 2 - xi.y);
         }
-        const double2 xe = pos()[e];
-        return (float)((f & 1) ? xe.y - xi.y : xe.x - xi.x);   // columns 2..5, 8..11: x y pairs
     }
 };
 
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         t.minprox()[i] = m;
     }
     __syncthreads();
-    if (STEP) {   // reward(agent 0): lexicographic-fair re-assignment on the new positions (nf:704-721)
+    if (STEP && !FMARL_SKIP(p, 64)) {   // reward(agent 0): lexicographic-fair re-assignment on the new positions (nf:704-721)
         if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv);
         else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv);
         else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv);
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
     // ---- the sequential part: occupancy / history walk in agent order
     ObsGoal og;
     og.goal = -1; og.second = 0; og.g_occ = og.g_hist = og.second_occ = 0.0;
-    for (int a = 0; a < N; ++a) {
+    for (int a = 0; a < (FMARL_SKIP(p, 128) ? 0 : N); ++a) {
         if (active && i == a)
             og = obs_event(t.D() + i * L, t.minprox(), t.occ(), t.hist(), L, i, p.thr, p.min_obs_dist);
         __syncthreads();
@@ -332,16 +336,20 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         }
     }
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
+    if (FMARL_SKIP(p, 32)) return;
     if (o.node_obs) {
-        const uint32_t EF = p.E * p.F, NEF = N * EF, total = nenv * NEF;
-        float *dst = o.node_obs + (size_t)env0 * NEF;
+        // one lane per (ego, entity) row: the 13 features share their loads; consecutive lanes write consecutive rows
+        const uint32_t NE = N * p.E, total = nenv * NE;
+        float *dst = o.node_obs + (size_t)env0 * NE * 13;
         for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t e_l = p.dNEF.div(q);
+            const uint32_t e_l = p.dC4.div(q);                 // dC4 = N * E rows per env
             const FairNavLds te(p, lds, e_l);
             if (te.skip()) continue;
-            const uint32_t r = q - e_l * NEF, a = p.dEF.div(r), s = r - a * EF;
-            const uint32_t e = p.dF.div(s), f = s - e * p.F;
-            dst[q] = te.node_feature(a, e, f);
+            const uint32_t r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;
+            float row[13];
+            te.node_row(a, e, row);
+#pragma unroll
+            for (int f = 0; f < 13; ++f) dst[(size_t)q * 13 + f] = row[f];
         }
     }
     if (o.adj) {

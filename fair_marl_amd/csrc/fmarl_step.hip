@@ -56,12 +56,29 @@ struct EnvLds {
         const double2 x = pos()[e];
         return (float)((f & 1) ? x.y : x.x);
     }
-    // ego part of column f: [vx vy | x y | x y | x y | x y | 0]
-    __device__ float ego_feature(uint32_t i, uint32_t f) const {
-        if (f == 10 || p.feat_global) return 0.f;
-        if (f < 2) { const float4 a = agentf()[i]; return f == 0 ? a.x : a.y; }
-        const double2 x = pos()[i];
-        return (float)((f & 1) ? x.y : x.x);
+    // whole row of entity e in the block of ego i: feat(e) - ego(i), both sides rounded to f32 first; returns F
+    __device__ int node_row(uint32_t i, uint32_t e, float (&o)[11]) const {
+        const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
+        const double2 xe = pos()[e];
+        const float pex = (float)xe.x, pey = (float)xe.y;
+        float vex = 0.f, vey = 0.f, gex = pex, gey = pey;
+        if (e < N) { const float4 ae = agentf()[e]; vex = ae.x; vey = ae.y; gex = ae.z; gey = ae.w; }
+        const float type = e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
+        if (p.feat_global) {   // navigation_graph.py:1058-1077
+            o[0] = vex; o[1] = vey; o[2] = pex; o[3] = pey; o[4] = gex; o[5] = gey; o[6] = type;
+            return 7;
+        }
+        const float4 ai = agentf()[i];
+        const double2 xi = pos()[i];
+        const float vix = ai.x, viy = ai.y, xix = (float)xi.x, xiy = (float)xi.y;
+        float c0 = pex, c1 = pey, c2 = pex, c3 = pey;
+        if (e >= first_wall) {   // (e0, axis + w/2), (e1, axis - w/2): navigation_graph.py:1115-1116
+            const double *wl = wall() + (e - first_wall) * 4;
+            c0 = (float)wl[1]; c1 = (float)(wl[0] + kWallWidth / 2); c2 = (float)wl[2]; c3 = (float)(wl[0] - kWallWidth / 2);
+        }
+        o[0] = vex - vix; o[1] = vey - viy; o[2] = pex - xix; o[3] = pey - xiy; o[4] = gex - xix; o[5] = gey - xiy;
+        o[6] = c0 - xix; o[7] = c1 - xiy; o[8] = c2 - xix; o[9] = c3 - xiy; o[10] = type - 0.f;
+        return 11;
     }
 };
 
@@ -140,16 +157,22 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, const char *l
         if (groups <= 1) emit_node_rows<1>(p, o, lds, env0, nenv);
         else if (groups <= 2) emit_node_rows<2>(p, o, lds, env0, nenv);
         else emit_node_rows<4>(p, o, lds, env0, nenv);
-    } else if (o.node_obs) {   // any shape: one float per lane, 256 contiguous bytes per wave store
+    } else if (o.node_obs) {
+        // any shape: one lane per (ego, entity) row -- the features of a row share their loads; consecutive lanes
+        // write consecutive rows
+        const uint32_t NE = p.N * p.E, total = nenv * NE;
         float *dst = o.node_obs + (size_t)env0 * NEF;
-        const uint32_t total = nenv * NEF;
         for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t el = p.dNEF.div(q);
+            const uint32_t el = p.dNE.div(q);
             const EnvLds t(p, lds, el);
             if (t.skip()) continue;
-            const uint32_t r = q - el * NEF, i = p.dEF.div(r), s = r - i * EF;
-            const uint32_t e = p.dF.div(s), f = s - e * p.F;
-            dst[q] = t.entity_feature(e, f) - t.ego_feature(i, f);
+            const uint32_t r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
+            float row[11];
+            const int F = t.node_row(i, e, row);
+            float *d = dst + (size_t)q * F;
+#pragma unroll
+            for (int f = 0; f < 11; ++f)
+                if (f < F) d[f] = row[f];
         }
     }
     if (o.adj && p.vec_adj) {

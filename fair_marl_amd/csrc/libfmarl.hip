@@ -288,7 +288,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     h->grid = (p.n_envs + epb - 1) / epb;
     const uint64_t NEF = (uint64_t)p.N * p.E * p.F, maxq = (uint64_t)epb * NEF;
     if (maxq >= (1ull << 24) || maxq * NEF >= (1ull << 40)) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large"); }
-    p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E);
+    p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E); p.dNE.set(p.N * p.E);
 #ifdef FMARL_MEASURE
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
 #endif
@@ -302,6 +302,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.vec_adj = 0;
         p.dC4.set(p.N * p.E * 3); p.dEE4.set(p.E * 3); p.dE4.set(3);
     }
+    if (fnav) p.dC4.set(p.N * p.E);   // fairnav emission: (ego, entity) rows per env
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
