@@ -356,44 +356,35 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     // ---- emission: node_obs (16 bytes per lane) and adj
     if (FMARL_SKIP(p, 32)) return;
     if (o.node_obs) {
-        // F = 12 = three float4 chunks per (ego, entity) row: [dv dx] [goal flag dx.x] [dx.y dx type]; the
-        // workgroup streams its region front to back, one 16-byte chunk per lane (ff:896-971).
-        const uint32_t EF = p.E * p.F, NEF = N * EF, C = NEF >> 2, chunks = nenv * C, rows = p.E * 3;
-        const uint32_t first_wall = N + p.L + p.O;
-        float4 *dst = (float4 *)(o.node_obs + (size_t)env0 * NEF);
-        for (uint32_t m = tid; m < chunks; m += kThreads) {
-            const uint32_t e_l = p.dC4.div(m), r = m - e_l * C;         // dC4 = N * E * 3 chunks per env
+        // one lane per (ego, entity) row of F = 12 floats = three 16-byte stores: [dv dx] [goal flag dx.x] [dx.y dx type];
+        // the three chunks share the position loads and the index math; consecutive lanes write consecutive rows (ff:896-971)
+        const uint32_t NE = N * p.E, total = nenv * NE, first_wall = N + p.L + p.O;
+        float4 *dst = (float4 *)(o.node_obs + (size_t)env0 * NE * 12);
+        for (uint32_t q = tid; q < total; q += kThreads) {
+            const uint32_t e_l = p.dNE.div(q), r = q - e_l * NE;
             const FormLds te(p, lds, e_l);
             if (te.skip()) continue;
-            const uint32_t a = p.dEE4.div(r), s = r - a * rows;          // dEE4 = E * 3 chunks per ego
-            const uint32_t e = p.dE4.div(s), k = s - e * 3;              // dE4 = 3
+            const uint32_t a = p.dE.div(r), e = r - a * p.E;
             const double2 xi = te.pos()[a], xe = te.pos()[e];
             const float dx = (float)(xe.x - xi.x), dy = (float)(xe.y - xi.y);
-            float4 v;
-            if (k == 0) {
-                const float4 ai = te.agentf()[a];
-                float vx = 0.f, vy = 0.f;
-                if (e < (uint32_t)N) { const float4 ae = te.agentf()[e]; vx = ae.x; vy = ae.y; }
-                v = make_float4(vx - ai.x, vy - ai.y, dx, dy);
-            } else if (k == 1) {
-                float gx = dx, gy = dy, fl = 1.f, t7 = dx;
-                if (e < (uint32_t)N) {
-                    const double2 gl = te.graph_goal(a, e);
-                    gx = (float)(gl.x - xi.x); gy = (float)(gl.y - xi.y);
-                    fl = (float)((te.masks()[4 * a + 2] >> e) & 1);
-                } else if (e >= first_wall) {
-                    t7 = (float)(te.wall()[(e - first_wall) * 4 + 1] - xi.x);            // e0 - x_i
-                }
-                v = make_float4(gx, gy, fl, t7);
-            } else {
-                float t8 = dy, t9 = dx, t10 = dy;
-                if (e >= first_wall) {
-                    const double *wl = te.wall() + (e - first_wall) * 4;
-                    t8 = (float)(wl[0] + kWallWidth / 2 - xi.y); t9 = (float)(wl[2] - xi.x); t10 = (float)(wl[0] - kWallWidth / 2 - xi.y);
-                }
-                v = make_float4(t8, t9, t10, e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f)));
+            const float4 ai = te.agentf()[a];
+            float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
+            if (e < (uint32_t)N) {
+                const float4 ae = te.agentf()[e];
+                vx = ae.x; vy = ae.y;
+                const double2 gl = te.graph_goal(a, e);
+                gx = (float)(gl.x - xi.x); gy = (float)(gl.y - xi.y);
+                fl = (float)((te.masks()[4 * a + 2] >> e) & 1);
+            } else if (e >= first_wall) {
+                const double *wl = te.wall() + (e - first_wall) * 4;
+                t7 = (float)(wl[1] - xi.x);                                             // e0 - x_i
+                t8 = (float)(wl[0] + kWallWidth / 2 - xi.y); t9 = (float)(wl[2] - xi.x); t10 = (float)(wl[0] - kWallWidth / 2 - xi.y);
             }
-            dst[m] = v;
+            const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
+            float4 *d = dst + (size_t)q * 3;
+            d[0] = make_float4(vx - ai.x, vy - ai.y, dx, dy);
+            d[1] = make_float4(gx, gy, fl, t7);
+            d[2] = make_float4(t8, t9, t10, type);
         }
     }
     if (o.adj) {

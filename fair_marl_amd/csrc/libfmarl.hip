@@ -298,10 +298,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
     p.dE4.set(p.vec_adj ? p.E / 4 : 1);
-    if (form) {   // formation emission: chunks per env / per ego row block / per entity row (F = 12 = 3 float4)
-        p.vec_adj = 0;
-        p.dC4.set(p.N * p.E * 3); p.dEE4.set(p.E * 3); p.dE4.set(3);
-    }
+    if (form) p.vec_adj = 0;
     if (fnav) p.dC4.set(p.N * p.E);   // fairnav emission: (ego, entity) rows per env
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
