@@ -46,6 +46,9 @@ CONFIGS = {
     'fnav': dict(workload='nav_fairassign_fairrew_formation_graph, 3 agents + 3 obstacles (E=9), 65536 envs per GPU',
                  env=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3,
                           num_obstacles=3, goal_rew=30.0, collision_rew=30.0), n_envs=65536, cpu_envs=32, cpu_episodes=4),
+    # the reference's own experiment scale (10 agents): odd E, so the generic (row-per-lane) emission path
+    'n10': dict(workload='navigation_graph, 10 agents + 3 obstacles (E=23), 65536 envs per GPU',
+                env=dict(num_agents=10, num_landmarks=10, num_obstacles=3), n_envs=65536, cpu_envs=64, cpu_episodes=3),
     # BASELINE.json configs[1]
     'cfg2': dict(workload='navigation_graph, 3 agents + 3 obstacles (E=9), 4096 envs per GPU',
                  env=dict(num_agents=3, num_landmarks=3, num_obstacles=3), n_envs=4096, cpu_envs=512, cpu_episodes=20),

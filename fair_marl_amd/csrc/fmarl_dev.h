@@ -27,6 +27,7 @@ constexpr double kSensitivity = 5.0;
 constexpr int kThreads = 256;       // workgroup size of the step / emit kernels (4 waves)
 constexpr int kMaxTries = 10000;    // bound on the reference's unbounded rejection loops
 constexpr int kEgoWidth = 5;         // LDS ego row: vx, vy, x, y, 0
+constexpr int kStageRows = 64;      // rows per wave and window of the generic emission (one row per lane)
 constexpr int kStepWavesPerSimd = 4; // register budget of step_kernel (128 VGPRs); measured best of 3..6 on MI355X
 
 // floor(q / d) for q * d < 2^40, q < 2^24 (block-local flat indices): one 64-bit multiply.
@@ -49,6 +50,7 @@ struct Params {
     FastDiv dNEF, dEF, dF, dEE, dE, dNE, dC4, dNC4, dEE4, dE4;
     int ablate;              // -DFMARL_MEASURE builds only (tools/ablate.sh): bit mask of phases to skip
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
+    int lds_stage, stage_wave_bytes;   // generic shapes: per-wave LDS window the rows go through (offset from the LDS base, bytes per wave)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
     double2 *slot_pos;

@@ -338,33 +338,35 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
     if (FMARL_SKIP(p, 32)) return;
     if (o.node_obs) {
-        // one lane per (ego, entity) row: the 13 features share their loads; consecutive lanes write consecutive rows
+        // one lane per (ego, entity) row: the 13 features share their loads; the rows leave through the waves' LDS
+        // windows (fmarl_step.hip flush_rows) unless some env of the workgroup keeps its previous rows
         const uint32_t NE = N * p.E, total = nenv * NE;
         float *dst = o.node_obs + (size_t)env0 * NE * 13;
-        for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t e_l = p.dC4.div(q);                 // dC4 = N * E rows per env
-            const FairNavLds te(p, lds, e_l);
-            if (te.skip()) continue;
-            const uint32_t r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;
-            float row[13];
-            te.node_row(a, e, row);
+        const bool some_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
+        if (!some_skip) {
+            for (uint32_t base = 0; base < total; base += kThreads) {
+                const uint32_t q = base + tid, w0 = base + (tid & ~63u);
+                float row[13];
+                if (q < total) {
+                    const uint32_t e_l = p.dC4.div(q), r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;   // dC4 = N * E
+                    FairNavLds(p, lds, e_l).node_row(a, e, row);
+                }
+                flush_rows<13>(p, lds, row, 13, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
+            }
+        } else {
+            for (uint32_t q = tid; q < total; q += kThreads) {
+                const uint32_t e_l = p.dC4.div(q);
+                const FairNavLds te(p, lds, e_l);
+                if (te.skip()) continue;
+                const uint32_t r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;
+                float row[13];
+                te.node_row(a, e, row);
 #pragma unroll
-            for (int f = 0; f < 13; ++f) dst[(size_t)q * 13 + f] = row[f];
+                for (int f = 0; f < 13; ++f) dst[(size_t)q * 13 + f] = row[f];
+            }
         }
     }
-    if (o.adj) {
-        const uint32_t EE = p.E * p.E, total = nenv * EE;
-        float *dst = o.adj + (size_t)env0 * EE;
-        for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t e_l = p.dEE.div(q);
-            const FairNavLds te(p, lds, e_l);
-            if (te.skip()) continue;
-            const uint32_t r = q - e_l * EE, a = p.dE.div(r), b = r - a * p.E;
-            const double2 pa = te.pos()[a], pb = te.pos()[b];
-            const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
-            dst[q] = sqrtf(dx * dx + dy * dy);
-        }
-    }
+    if (o.adj) emit_adj_generic(p, o, lds, env0, nenv);
 }
 
 }  // namespace fmarl

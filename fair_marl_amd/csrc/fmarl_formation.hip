@@ -387,19 +387,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             d[2] = make_float4(t8, t9, t10, type);
         }
     }
-    if (o.adj) {
-        const uint32_t EE = p.E * p.E, total = nenv * EE;
-        float *dst = o.adj + (size_t)env0 * EE;
-        for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t e_l = p.dEE.div(q);
-            const FormLds te(p, lds, e_l);
-            if (te.skip()) continue;
-            const uint32_t r = q - e_l * EE, a = p.dE.div(r), b = r - a * p.E;
-            const double2 pa = te.pos()[a], pb = te.pos()[b];
-            const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
-            dst[q] = sqrtf(dx * dx + dy * dy);
-        }
-    }
+    if (o.adj) emit_adj_generic(p, o, lds, env0, nenv);
 }
 
 }  // namespace fmarl

@@ -148,8 +148,74 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
     }
 }
 
+// Generic row widths: lane l of a wave holds row l of the wave's window (F floats, valid for l < nrows).  The rows
+// go through the wave's LDS window so that global memory sees 16 bytes per lane at 16-byte aligned addresses
+// whatever F and the alignment of gdst are (row-per-lane stores at a 4 F byte stride reach about half the
+// store bandwidth).  The window is private to the wave: LDS executes a wave's instructions in order, so a
+// wavefront-scope fence (no workgroup barrier) is all that separates the writes from the reads.
+template <int FMAX>
+__device__ __forceinline__ void flush_rows(const Params &p, char *lds, const float (&row)[FMAX], int F, int nrows, float *gdst) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *buf = (float *)(lds + p.lds_stage + wave * p.stage_wave_bytes);
+    const uint32_t shift = (uint32_t)(((uintptr_t)gdst >> 2) & 3);   // dwords past the previous 16-byte boundary
+    if ((int)lane < nrows) {
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f)
+            if (f < F) buf[shift + lane * F + f] = row[f];   // stride F dwords: conflict-free for odd F
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t end = shift + nrows * F, first4 = (shift + 3) >> 2, last4 = end >> 2;
+    float *gal = gdst - shift;   // 16-byte aligned frame: dword k of the frame is buf[k]
+    for (uint32_t k = first4 + lane; k < last4; k += 64) ((float4 *)gal)[k] = ((const float4 *)buf)[k];
+    if (lane < 3) {            // at most 3 dwords before the first full chunk ...
+        const uint32_t idx = shift + lane;
+        if (idx < min(first4 * 4, end)) gal[idx] = buf[idx];
+    } else if (lane < 6) {     // ... and 3 after the last one
+        const uint32_t idx = max(last4, first4) * 4 + (lane - 3);
+        if (idx < end) gal[idx] = buf[idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next window's writes stay behind these reads
+    __builtin_amdgcn_wave_barrier();
+}
+
+// adj for any E: a lane owns one 16-byte aligned chunk of the workgroup's region (4 entries, possibly of two rows
+// or envs), computes |x_a - x_b| for each and stores 16 bytes; the ragged ends and chunks that touch an env which
+// keeps its previous matrix fall back to 4-byte stores.  Shared by the three scenarios (same LDS tables).
+__device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
+    const uint32_t EE = p.E * p.E, total = nenv * EE;
+    float *dst = o.adj + (size_t)env0 * EE;
+    const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 3), end = shift + total;
+    float *gal = dst - shift;
+    for (uint32_t k = threadIdx.x; k < ((end + 3) >> 2); k += kThreads) {
+        float v[4];
+        bool ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t idx = 4 * k + j;
+            ok[j] = idx >= shift && idx < end;
+            v[j] = 0.f;
+            if (ok[j]) {
+                const uint32_t q = idx - shift, el = p.dEE.div(q);
+                const EnvLds t(p, lds, el);
+                if (t.skip()) { ok[j] = false; continue; }
+                const uint32_t r = q - el * EE, a = p.dE.div(r), b = r - a * p.E;
+                const double2 pa = t.pos()[a], pb = t.pos()[b];
+                const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
+                v[j] = sqrtf(dx * dx + dy * dy);
+            }
+        }
+        if (ok[0] & ok[1] & ok[2] & ok[3]) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) gal[4 * k + j] = v[j];
+        }
+    }
+}
+
 // Emission of the graph outputs of the workgroup's envs.
-__device__ void emit_graph(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
+__device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x;
     const uint32_t NEF = p.N * p.E * p.F, EF = p.E * p.F, EE = p.E * p.E;
     if (o.node_obs && p.vec_node) {
@@ -158,21 +224,34 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, const char *l
         else if (groups <= 2) emit_node_rows<2>(p, o, lds, env0, nenv);
         else emit_node_rows<4>(p, o, lds, env0, nenv);
     } else if (o.node_obs) {
-        // any shape: one lane per (ego, entity) row -- the features of a row share their loads; consecutive lanes
-        // write consecutive rows
+        // any shape: one lane per (ego, entity) row -- the features of a row share their loads
         const uint32_t NE = p.N * p.E, total = nenv * NE;
         float *dst = o.node_obs + (size_t)env0 * NEF;
-        for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t el = p.dNE.div(q);
-            const EnvLds t(p, lds, el);
-            if (t.skip()) continue;
-            const uint32_t r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
-            float row[11];
-            const int F = t.node_row(i, e, row);
-            float *d = dst + (size_t)q * F;
+        const bool some_skip = __syncthreads_or(tid < nenv && EnvLds(p, lds, tid).skip());
+        if (!some_skip) {   // every env of the workgroup emits: rows leave through the LDS windows, 16 bytes per lane
+            for (uint32_t base = 0; base < total; base += kThreads) {
+                const uint32_t q = base + tid, w0 = base + (tid & ~63u);
+                float row[11];
+                int F = p.F;
+                if (q < total) {
+                    const uint32_t el = p.dNE.div(q), r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
+                    F = EnvLds(p, lds, el).node_row(i, e, row);
+                }
+                flush_rows<11>(p, lds, row, F, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * F);
+            }
+        } else {            // some envs keep their previous rows (reset in flight): per-lane stores of the rest
+            for (uint32_t q = tid; q < total; q += kThreads) {
+                const uint32_t el = p.dNE.div(q);
+                const EnvLds t(p, lds, el);
+                if (t.skip()) continue;
+                const uint32_t r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
+                float row[11];
+                const int F = t.node_row(i, e, row);
+                float *d = dst + (size_t)q * F;
 #pragma unroll
-            for (int f = 0; f < 11; ++f)
-                if (f < F) d[f] = row[f];
+                for (int f = 0; f < 11; ++f)
+                    if (f < F) d[f] = row[f];
+            }
         }
     }
     if (o.adj && p.vec_adj) {
@@ -196,17 +275,7 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, const char *l
             dst[m] = make_float4(v[0], v[1], v[2], v[3]);
         }
     } else if (o.adj) {
-        float *dst = o.adj + (size_t)env0 * EE;
-        const uint32_t total = nenv * EE;
-        for (uint32_t q = tid; q < total; q += kThreads) {
-            const uint32_t el = p.dEE.div(q);
-            const EnvLds t(p, lds, el);
-            if (t.skip()) continue;
-            const uint32_t r = q - el * EE, a = p.dE.div(r), b = r - a * p.E;
-            const double2 pa = t.pos()[a], pb = t.pos()[b];
-            const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
-            dst[q] = sqrtf(dx * dx + dy * dy);
-        }
+        emit_adj_generic(p, o, lds, env0, nenv);
     }
 }
 

@@ -273,15 +273,20 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.n_words = off;   off = align16(off + 16);
     }
     p.lds_env_bytes = off;
+    // generic row widths (everything but navigation_graph with E * F % 4 == 0 and the formation scenario's 48-byte
+    // rows) leave through one LDS window per wave: fmarl_step.hip flush_rows
+    const bool staged = fnav || (!form && (p.E * p.F) % 4 != 0) || (!form && !fnav && p.E * p.F / 4 > 64 * 4);
+    p.stage_wave_bytes = staged ? align16(kStageRows * p.F * 4 + 16) : 0;
     int epb = kThreads / p.N;
-    const int budget = 48 * 1024;
+    const int budget = 48 * 1024 - (kThreads / 64) * p.stage_wave_bytes;
     if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
     if (epb < 1) epb = 1;
     // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
     if ((p.n_envs + epb - 1) / epb < 512) { int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb); }
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
-    h->lds_bytes = (size_t)epb * p.lds_env_bytes;
+    p.lds_stage = align16(epb * p.lds_env_bytes);
+    h->lds_bytes = (size_t)p.lds_stage + (kThreads / 64) * p.stage_wave_bytes;
 #ifdef FMARL_MEASURE
     if (const char *pad = getenv("FMARL_LDS_PAD")) h->lds_bytes += atoi(pad);   // lower occupancy
 #endif
