@@ -30,6 +30,16 @@ int fail(int code, const char *fmt, const char *a = "") {
         if (e_ != hipSuccess) return fail(FMARL_EHIP, #call ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// node_obs rows of 16-byte multiples (navigation_graph with E * F % 4 == 0, the formation scenario) and adj with
+// E % 4 == 0 are written with 16-byte stores straight from registers: those buffers must be 16-byte aligned
+// (hipMalloc and torch allocations are).  Every other shape goes through aligned frames and takes any float pointer.
+bool outputs_aligned(const fmarl::Params &p, const FmarlOutputs *o) {
+    const bool form = p.scenario == FMARL_SCENARIO_FORMATION;
+    if (o->node_obs && (p.vec_node || form) && ((uintptr_t)o->node_obs & 15)) return false;
+    if (o->adj && p.vec_adj && ((uintptr_t)o->adj & 15)) return false;
+    return true;
+}
+
 struct Layout {
     size_t off[FMARL_NUM_FIELDS], count[FMARL_NUM_FIELDS];
     int dtype[FMARL_NUM_FIELDS];
@@ -394,6 +404,7 @@ int fmarl_init_state(void *handle, void *state, void *stream) {
 int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlOutputs *outs, void *stream) {
     Handle *h = (Handle *)handle;
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_reset: null argument");
+    if (outs && !outputs_aligned(h->base, outs)) return fail(FMARL_EINVAL, "fmarl_reset: node_obs / adj must be 16-byte aligned for this shape");
     int rc = launch_reset(h, state, env_mask ? kResetMask : kResetAll, env_mask, outs, (hipStream_t)stream);
     if (env_mask || h->cfg.scenario == FMARL_SCENARIO_FAIRNAV) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
     h->episode_started = true;
@@ -408,6 +419,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
         return fail(FMARL_EINVAL, "fmarl_step: pass exactly one of action_idx / action_vec");
     hipStream_t st = (hipStream_t)stream;
     Params p = bind(h, state);
+    if (!outputs_aligned(p, outs)) return fail(FMARL_EINVAL, "fmarl_step: node_obs / adj must be 16-byte aligned for this shape");
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     if (p.scenario == FMARL_SCENARIO_FAIRNAV)
@@ -553,6 +565,7 @@ int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int 
         return fail(FMARL_EINVAL, "fmarl_rebuild_graph: only navigation_graph has a rebuildable record");
     FmarlOutputs o = {};
     o.node_obs = node_obs; o.adj = adj;
+    if (!outputs_aligned(h->base, &o)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: node_obs / adj must be 16-byte aligned for this shape");
     const int grid = (n_envs + h->base.epb - 1) / h->base.epb;
     hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o, obs,
                        (const uint32_t *)record, n_envs);

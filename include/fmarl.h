@@ -75,7 +75,9 @@ typedef struct FmarlConfig {
  * layer undoes in its NumPy-compat mode: adj is stored once per env (the reference returns
   * the same E x E matrix N times, navigation_graph.py:1033) and infos are dense field-major
  * record planes instead of per-agent dicts (navigation_graph.py:625-647).  Any pointer may be NULL
- * to skip that output. */
+ * to skip that output.  node_obs and adj must be 16-byte aligned when their rows are multiples of 16 bytes
+ * (E * F % 4 == 0 resp. E % 4 == 0: written with 16-byte stores; hipMalloc'd memory always is); other shapes
+ * take any float pointer.  Misaligned buffers are refused with FMARL_EINVAL. */
 typedef struct FmarlOutputs {
     float *obs;          /* (n, N, D)        D = 7 navigation_graph / 6 formation / 11 fairnav */
     float *node_obs;     /* (n, N, E, F)     F = 11 / 12 / 13, E = N + L + O + W              */

@@ -458,6 +458,29 @@ def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
     assert int(eager.get_state()['episode'].min()) >= 3   # three auto-resets happened inside the replays
 
 
+def test_misaligned_output_buffers():
+    """16-byte row shapes need 16-byte aligned node_obs / adj (refused otherwise); generic shapes take any float
+    pointer and still produce the same values (aligned frames inside the kernels)."""
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=4)          # E = 12, E * F = 132: 16-byte rows
+    eng = fm.RolloutEngine(cfg, 16, device=DEV, seed=2)
+    pad = torch.zeros(16 * 4 * 12 * 11 + 1, device=DEV)
+    with pytest.raises(RuntimeError, match='16-byte aligned'):
+        eng.use_outputs(eng.new_output_set(node_obs=pad[1:].view(16, 4, 12, 11)))
+        eng.reset()
+    cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=3)          # E = 9, F = 11: generic paths
+    n = 301
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=2)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=2)
+    for off in (1, 2, 3):
+        node = torch.zeros(n * 3 * 9 * 11 + off, device=DEV)[off:].view(n, 3, 9, 11)
+        adj = torch.zeros(n * 81 + off, device=DEV)[off:].view(n, 9, 9)
+        b.use_outputs(b.new_output_set(node_obs=node, adj_env=adj))
+        a.reset(); b.reset()
+        act = torch.randint(0, 5, (n, 3), device=DEV, dtype=torch.int32)
+        a.step(act); b.step(act)
+        assert torch.equal(a.node_obs, node) and torch.equal(a.adj_env, adj), off
+
+
 def test_c_abi_client_without_python_matches_the_engine():
     """examples/rollout_capi.cpp drives libfmarl.so through include/fmarl.h alone (HIP runtime, no torch);
     the same rollout through RolloutEngine must give the same bytes."""
