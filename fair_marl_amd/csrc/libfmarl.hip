@@ -420,6 +420,11 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     hipStream_t st = (hipStream_t)stream;
     Params p = bind(h, state);
     if (!outputs_aligned(p, outs)) return fail(FMARL_EINVAL, "fmarl_step: node_obs / adj must be 16-byte aligned for this shape");
+    if (h->async) {   // the staging stream and its events are not part of the caller's graph
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(FMARL_EINVAL, "fmarl_step: stream capture needs a handle created without FMARL_FLAG_ASYNC_RESET");
+    }
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     if (p.scenario == FMARL_SCENARIO_FAIRNAV)

@@ -37,8 +37,8 @@ extern "C" {
 /* FmarlConfig.flags.  ASYNC_RESET: the next episode's placement + fair assignment (a pure function of
  * seed, env and episode index) is computed ahead of time on a library-owned side stream while the current
  * episode runs; a reset then only commits the staged state and emits the observation.  Results are
- * identical to the synchronous path.  Leave it off when capturing single steps into a hipGraph (the
- * side-stream work outlives the call). */
+ * identical to the synchronous path.  Leave it off when capturing steps into a hipGraph (the side-stream
+ * work outlives the call): fmarl_step refuses a capturing stream on a handle that has it. */
 #define FMARL_FLAG_ASYNC_RESET 1
 /* GLOBAL_FEATURES: --graph_feat_type global (navigation_graph.py:981-1009, 1058-1077): node_obs rows are the
  * 7 absolute columns [vel, pos, goal, type], identical for every ego agent (F = 7).  navigation_graph without

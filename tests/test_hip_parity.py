@@ -456,6 +456,14 @@ def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
         for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
             assert torch.equal(getattr(eager, k), getattr(graph, k)), 'episode %d %s' % (ep, k)
     assert int(eager.get_state()['episode'].min()) >= 3   # three auto-resets happened inside the replays
+    # the staged-reset mode owns a side stream and events: capturing it is refused, not silently mis-captured
+    staged = fm.RolloutEngine(cfg, n, device=DEV, seed=3, async_reset=True)
+    staged.reset()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='FMARL_FLAG_ASYNC_RESET'):
+        with torch.cuda.graph(g2):
+            staged.step(tape[0])
 
 
 def test_misaligned_output_buffers():
