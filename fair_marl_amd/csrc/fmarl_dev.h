@@ -45,11 +45,13 @@ struct Params {
     int epb;                 // environments per workgroup = kThreads / N
     int feat_global;   // FMARL_FLAG_GLOBAL_FEATURES: node rows are [vel, pos, goal, type] without the ego part
     int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
+    int lds_posf, has_posf;  // navigation_graph: f32 copy of the entity positions (adj is computed from it)
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
     uint64_t seed;
     FastDiv dNEF, dEF, dF, dEE, dE, dNE, dC4, dNC4, dEE4, dE4;
     int ablate;              // -DFMARL_MEASURE builds only (tools/ablate.sh): bit mask of phases to skip
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
+    int scan_stats;          // N is a power of two <= 64: the agent-loop statistics run as wave scans (seg_mixed_stats)
     int lds_stage, stage_wave_bytes;   // generic shapes: per-wave LDS window the rows go through (offset from the LDS base, bytes per wave)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
@@ -129,6 +131,10 @@ __device__ __forceinline__ double dist2(double2 a, double2 b) {
     return sqrt(dx * dx + dy * dy);
 }
 
+// |(dx, dy)| for the f32 outputs: one v_sqrt_f32 (1 ulp; sqrtf's correctly rounded sequence is 17 instructions,
+// and the adj emission evaluates 5 184 of these per env and step at E = 72)
+__device__ __forceinline__ float dist_f32(float dx, float dy) { return __builtin_amdgcn_sqrtf(fmaf(dy, dy, dx * dx)); }
+
 // sqrt(|a-b|^2) < c, decided on the squared distance unless it is within a few ulp of c^2
 // (navigation_graph.py:659, :695, :705 compare np.linalg.norm(delta) < dist_min)
 __device__ __forceinline__ bool closer_than(double2 a, double2 b, double c) {
@@ -193,6 +199,89 @@ template <int G> __device__ __forceinline__ uint32_t group_or32(uint32_t v) {
 #pragma unroll
     for (int off = 16; off < G; off <<= 1) v |= (uint32_t)__shfl_xor((int)v, off, G);
     return v;
+}
+
+// ---------------------------------------------------------------- run statistics by wave scans
+// (mean, M2 = sum of squared deviations from the mean) of runs of consecutive lanes, joined pairwise
+// (Chan, Golub, LeVeque): no cancellation, and a run of equal values keeps M2 = 0 exactly -- np.std of a constant
+// vector is exactly 0 and the fairness scalar divides by std + 1e-4 (navigation_graph.py:766, :769).
+// Segments are the N lanes of one env, N a power of two (N | 64), li = lane index inside the segment.
+__device__ __forceinline__ double rcp_small(double n) {   // 1 / n for the small integer counts (two Newton steps)
+    double r = __builtin_amdgcn_rcp(n);
+    r = fma(fma(-n, r, 1.0), r, r);
+    return fma(fma(-n, r, 1.0), r, r);
+}
+// run A (ca values) joined with run B (cb values), both counts >= 1
+__device__ __forceinline__ void run_join(double ma, double qa, double ca, double mb, double qb, double cb, double &m, double &q) {
+    const double w = cb * rcp_small(ca + cb), d = mb - ma;
+    m = ma + d * w;
+    q = qa + qb + d * d * (ca * w);
+}
+// One scan step: lanes with take join the run (pm, pq) of cp values fetched from the partner lane with their own of co values.
+#define FMARL_RUN_STEP(pm_, pq_, take_, cp_, co_) {                                                                  \
+        const double pm = (pm_), pq = (pq_);                                                                         \
+        const bool take = (take_);                                                                                   \
+        double jm, jq;                                                                                               \
+        run_join(pm, pq, take ? (double)(cp_) : 1.0, m, q, take ? (double)(co_) : 1.0, jm, jq);                      \
+        m = take ? jm : m; q = take ? jq : q; }
+// inclusive prefix: on return (m, q) of lane li describe the values of lanes [0, li] of its segment
+__device__ __forceinline__ void seg_prefix_runs(int N, int li, double v, double &m, double &q) {
+    m = v; q = 0.0;
+    const int s = li & 15;   // DPP rows are 16 lanes: row_shr inside them, row_bcast across
+    if (N > 1) FMARL_RUN_STEP(dpp_f64<0x111>(m), dpp_f64<0x111>(q), s >= 1, 1, 1)
+    if (N > 2) FMARL_RUN_STEP(dpp_f64<0x112>(m), dpp_f64<0x112>(q), s >= 2, min(s - 1, 2), min(s + 1, 2))
+    if (N > 4) FMARL_RUN_STEP(dpp_f64<0x114>(m), dpp_f64<0x114>(q), s >= 4, min(s - 3, 4), min(s + 1, 4))
+    if (N > 8) FMARL_RUN_STEP(dpp_f64<0x118>(m), dpp_f64<0x118>(q), s >= 8, min(s - 7, 8), min(s + 1, 8))
+    if (N > 16) FMARL_RUN_STEP(dpp_f64<0x142>(m), dpp_f64<0x142>(q), (li & 16) != 0, 16, s + 1)          // row_bcast:15
+    if (N > 32) FMARL_RUN_STEP(dpp_f64<0x143>(m), dpp_f64<0x143>(q), (li & 32) != 0, 32, (li & 31) + 1)  // row_bcast:31
+}
+// inclusive suffix: on return (m, q) of lane li describe the values of lanes [li, N - 1] of its segment
+__device__ __forceinline__ void seg_suffix_runs(int N, int li, double v, double &m, double &q) {
+    m = v; q = 0.0;
+    const int R = N < 16 ? N : 16, t = R - 1 - (li & (R - 1));   // lanes of the segment after this one inside its DPP row
+    if (N > 1) FMARL_RUN_STEP(dpp_f64<0x101>(m), dpp_f64<0x101>(q), t >= 1, 1, 1)
+    if (N > 2) FMARL_RUN_STEP(dpp_f64<0x102>(m), dpp_f64<0x102>(q), t >= 2, min(t - 1, 2), min(t + 1, 2))
+    if (N > 4) FMARL_RUN_STEP(dpp_f64<0x104>(m), dpp_f64<0x104>(q), t >= 4, min(t - 3, 4), min(t + 1, 4))
+    if (N > 8) FMARL_RUN_STEP(dpp_f64<0x108>(m), dpp_f64<0x108>(q), t >= 8, min(t - 7, 8), min(t + 1, 8))
+    const int lane = threadIdx.x & 63;
+    if (N > 16) {   // first lane of the next row holds that row's total
+        const int src = (lane & ~31) | 16;
+        FMARL_RUN_STEP(__shfl(m, src, 64), __shfl(q, src, 64), (li & 16) == 0, 16, t + 1)
+    }
+    if (N > 32) FMARL_RUN_STEP(__shfl(m, 32, 64), __shfl(q, 32, 64), li < 32, 32, 32 - (li & 31))
+}
+// all lanes of the segment: mean and M2 of the segment's N values (butterfly of equal-sized runs, symmetric in the
+// two partners, so every lane ends with the same bits)
+__device__ __forceinline__ void seg_all_runs(int N, double v, double &m, double &q) {
+    m = v; q = 0.0;
+#define FMARL_ALL_STEP(pm_, pq_, half_) { const double pm = (pm_), pq = (pq_), d = m - pm; \
+        m = 0.5 * (m + pm); q = (q + pq) + d * d * (half_); }
+    if (N > 1) FMARL_ALL_STEP(dpp_f64<0xB1>(m), dpp_f64<0xB1>(q), 0.5)      // quad_perm [1,0,3,2]
+    if (N > 2) FMARL_ALL_STEP(dpp_f64<0x4E>(m), dpp_f64<0x4E>(q), 1.0)      // quad_perm [2,3,0,1]
+    if (N > 4) FMARL_ALL_STEP(dpp_f64<0x141>(m), dpp_f64<0x141>(q), 2.0)    // row_half_mirror (quads are uniform by now)
+    if (N > 8) FMARL_ALL_STEP(dpp_f64<0x140>(m), dpp_f64<0x140>(q), 4.0)    // row_mirror
+    if (N > 16) FMARL_ALL_STEP(__shfl_xor(m, 16, 64), __shfl_xor(q, 16, 64), 8.0)
+    if (N > 32) FMARL_ALL_STEP(__shfl_xor(m, 32, 64), __shfl_xor(q, 32, 64), 16.0)
+#undef FMARL_ALL_STEP
+}
+// Statistics of the reference's sequential agent loop for lane li (navigation_graph.py:617-618, :769, :854):
+// `info`  = mean / population std of [fresh_0 .. fresh_li, stale_li+1 .. stale_N-1]   (after info_callback(li))
+// `before` = the same with fresh_li not yet in (what observation(li) / reward(li) see): info of lane li - 1, all stale for li = 0.
+// Every lane of the wave must call this (no divergence around it).
+__device__ __forceinline__ void seg_mixed_stats(int N, int li, double fresh, double stale, double &info_m, double &info_sd,
+                                                double &before_m, double &before_sd) {
+    double pm, pq, sm, sq;
+    seg_prefix_runs(N, li, fresh, pm, pq);
+    seg_suffix_runs(N, li, stale, sm, sq);
+    const double nm = dpp_f64<0x130>(sm), nq = dpp_f64<0x130>(sq);   // wave_shl:1 -> suffix run starting at li + 1
+    const bool last = li == N - 1;
+    double jm, jq;
+    run_join(pm, pq, (double)(li + 1), nm, nq, last ? 1.0 : (double)(N - 1 - li), jm, jq);
+    info_m = last ? pm : jm;
+    info_sd = sqrt((last ? pq : jq) / N);
+    const double bm = dpp_f64<0x138>(info_m), bs = dpp_f64<0x138>(info_sd);   // wave_shr:1
+    before_m = li == 0 ? sm : bm;
+    before_sd = li == 0 ? sqrt(sq / N) : bs;
 }
 
 }  // namespace fmarl

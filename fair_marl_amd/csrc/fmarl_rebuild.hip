@@ -8,7 +8,7 @@
 // learner rank rebuilds what graph_observation / _get_entity_feat_relative would have produced
 // (navigation_graph.py:941-1035, 1079-1124): the same f32 tables go into LDS, the same emission runs.
 // node_obs is bit-identical to the sender's (the sender's emission starts from the same f32 roundings);
-// adj is computed from f32 instead of f64 positions (absolute difference below 1e-6).
+// adj likewise: the sender computes it from the same f32 position table.
 //
 // Episode record, 32-bit words per env:  goal (gx, gy) f32 x N | landmark, obstacle (x, y) f32 x (L + O) |
 // wall [axis f64 (2 words), e0 f32, e1 f32, orient f32, 0] x W.
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kThreads) void rebuild_graph_kernel(Params p, Fmarl
         const int e_l = t / LO, k = t - e_l * LO;
         const float *s = (const float *)(rec + (size_t)(env0 + e_l) * words) + 2 * (p.N + k);
         ((double2 *)(lds + (size_t)e_l * p.lds_env_bytes + p.lds_pos))[p.N + k] = make_double2((double)s[0], (double)s[1]);
+        ((float2 *)(lds + (size_t)e_l * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2(s[0], s[1]);
     }
     for (int t = tid; t < nenv * p.W; t += kThreads) {
         const int e_l = t / p.W, w = t - e_l * p.W;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(kThreads) void rebuild_graph_kernel(Params p, Fmarl
         double *wl = (double *)(base + p.lds_wall) + w * 4;
         wl[0] = axis; wl[1] = (double)qf[2]; wl[2] = (double)qf[3]; wl[3] = (double)qf[4];
         ((double2 *)(base + p.lds_pos))[p.N + LO + w] = qf[4] == 0.f ? make_double2(0.0, axis) : make_double2(axis, 0.0);
+        ((float2 *)(base + p.lds_posf))[p.N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
     }
     __syncthreads();
     emit_graph(p, o, lds, env0, nenv);

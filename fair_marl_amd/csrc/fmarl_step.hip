@@ -31,6 +31,7 @@ struct EnvLds {
     __device__ EnvLds(const Params &p_, const char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
     __device__ const double2 *pos() const { return (const double2 *)(base + p.lds_pos); }
     __device__ const float4 *agentf() const { return (const float4 *)(base + p.lds_agentf); }
+    __device__ const float2 *posf() const { return (const float2 *)(base + p.lds_posf); }   // (float)pos, navigation_graph only
     __device__ const double *wall() const { return (const double *)(base + p.lds_wall); }
     __device__ bool skip() const { return *(const int *)(base + p.lds_flag) != 0; }
 
@@ -201,8 +202,7 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
                 if (t.skip()) { ok[j] = false; continue; }
                 const uint32_t r = q - el * EE, a = p.dE.div(r), b = r - a * p.E;
                 const double2 pa = t.pos()[a], pb = t.pos()[b];
-                const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
-                v[j] = sqrtf(dx * dx + dy * dy);
+                v[j] = dist_f32((float)(pa.x - pb.x), (float)(pa.y - pb.y));
             }
         }
         if (ok[0] & ok[1] & ok[2] & ok[3]) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
@@ -256,7 +256,8 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, in
     }
     if (o.adj && p.vec_adj) {
         // 16-byte path (E % 4 == 0): the workgroup streams its region front to back (chunk m = tid + 256 k:
-        // its four waves write one 4 KiB window at a time); a lane computes |x_a - x_b| for four b.
+        // its four waves write one 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32
+        // position table (the roundings node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
         const uint32_t E4 = p.E >> 2, per_env = p.E * E4, chunks = nenv * per_env;
         float4 *dst = (float4 *)(o.adj + (size_t)env0 * EE);
         for (uint32_t m = tid; m < chunks; m += kThreads) {
@@ -264,15 +265,10 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, in
             const EnvLds t(p, lds, el);
             if (t.skip()) continue;
             const uint32_t a = p.dE4.div(r), b4 = r - a * E4;
-            const double2 pa = t.pos()[a];
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double2 pb = t.pos()[b4 * 4 + k];
-                const float dx = (float)(pa.x - pb.x), dy = (float)(pa.y - pb.y);
-                v[k] = sqrtf(dx * dx + dy * dy);
-            }
-            dst[m] = make_float4(v[0], v[1], v[2], v[3]);
+            const float2 pa = t.posf()[a];
+            const float4 q0 = ((const float4 *)t.posf())[b4 * 2], q1 = ((const float4 *)t.posf())[b4 * 2 + 1];
+            dst[m] = make_float4(dist_f32(pa.x - q0.x, pa.y - q0.y), dist_f32(pa.x - q0.z, pa.y - q0.w),
+                                 dist_f32(pa.x - q1.x, pa.y - q1.y), dist_f32(pa.x - q1.z, pa.y - q1.w));
         }
     } else if (o.adj) {
         emit_adj_generic(p, o, lds, env0, nenv);
@@ -284,6 +280,7 @@ __device__ __forceinline__ void store_agent_rows(const Params &p, char *base, in
     ((float4 *)(base + p.lds_agentf))[i] = make_float4((float)v.x, (float)v.y, (float)goal.x, (float)goal.y);
     float *ego = (float *)(base + p.lds_ego) + i * kEgoWidth;
     ego[0] = (float)v.x; ego[1] = (float)v.y; ego[2] = (float)x.x; ego[3] = (float)x.y; ego[4] = 0.f;
+    ((float2 *)(base + p.lds_posf))[i] = make_float2((float)x.x, (float)x.y);
 }
 
 // Loads landmarks / obstacles / walls of the workgroup's envs into the LDS entity table.
@@ -293,8 +290,9 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         int el = t / LO, k = t - el * LO;
         double2 *pos = (double2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_pos);
         int env = env0 + el;
-        pos[p.N + k] = k < p.L ? p.landmark_pos[(size_t)env * p.L + k]
-                               : p.obstacle_pos[(size_t)env * p.O + (k - p.L)];
+        const double2 x = k < p.L ? p.landmark_pos[(size_t)env * p.L + k] : p.obstacle_pos[(size_t)env * p.O + (k - p.L)];
+        pos[p.N + k] = x;
+        if (p.has_posf) ((float2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)x.x, (float)x.y);
     }
     for (int t = threadIdx.x; t < nenv * p.W; t += kThreads) {
         int el = t / p.W, w = t - el * p.W;
@@ -305,7 +303,9 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         double *wl = (double *)(base + p.lds_wall) + w * 4;
         wl[0] = axis; wl[1] = p.wall_e0[g]; wl[2] = p.wall_e1[g]; wl[3] = (double)orient;
         // wall "sphere" centre: (0, axis) for 'H', (axis, 0) for 'V' (navigation_graph.py:309-324)
-        ((double2 *)(base + p.lds_pos))[p.N + LO + w] = orient == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
+        const double2 c = orient == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
+        ((double2 *)(base + p.lds_pos))[p.N + LO + w] = c;
+        if (p.has_posf) ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
     }
 }
 
@@ -343,35 +343,58 @@ __device__ __forceinline__ double2 agent_force(const Params &p, const char *base
         uy = ((double)a[3] - (double)a[4]) * kSensitivity;
     }
     double Fx = ux, Fy = uy;   // core.py:277-298, mass 1
-    // core.py:301-316 + :370-404: agent-agent, agent-obstacle, agent-wall-entity pairs
-    const int first_obst = p.N + p.L, first_wall = first_obst + p.O;
-    for (int b = 0; b < (FMARL_SKIP(p, 1) ? 0 : p.E); ++b) {
-        if (b == i || (b >= p.N && b < first_obst)) continue;   // self; landmarks do not collide
-        if (b < p.N && !agent_forces) continue;                 // status == True: core.py:394-398
-        const double2 q = s_pos[b];
-        const double dx = x.x - q.x, dy = x.y - q.y;
-        const double d2 = dx * dx + dy * dy;
-        const double dmin = b < first_wall ? 2 * kEntitySize : kEntitySize + kWallWidth;
-        // z = -(d - dmin) / margin.  Three regimes by distance (all exact to ~1e-16 in the force):
-        //   z < -37      : softplus tail < 1e-16 * margin, below f64 resolution of the sum -> skip
-        //   -37 <= z < -24: force < 2.3e-10, evaluated in f32 (relative 1e-6 -> absolute 2e-16)
-        //   otherwise    : f64
-        const double far = dmin + 37.0 * kContactMargin, mid = dmin + 24.0 * kContactMargin;
-        if (d2 > far * far) continue;
-        if (d2 > mid * mid) {
-            const float fdx = (float)dx, fdy = (float)dy;
+    // core.py:301-316 + :370-404: agent-agent, agent-obstacle, agent-wall-entity pairs (landmarks do not collide).
+    // z = -(d - dmin) / margin.  Three regimes by distance (all exact to ~1e-16 in the force):
+    //   z < -37      : softplus tail < 1e-16 * margin, below f64 resolution of the sum -> skip
+    //   -37 <= z < -24: force < 2.3e-10, evaluated in f32 (relative 1e-6 -> absolute 2e-16)
+    //   otherwise    : f64
+    // The lanes of a wave differ in WHICH partners are near, hardly in HOW MANY: a cheap pass classifies 32 partners
+    // into two bit masks, then each regime walks its set bits only (a loop over all partners with the regimes as
+    // branches runs every regime for nearly every partner: 2.6e8 of the step kernel's 5.7e8 VALU instructions at cfg 3).
+    const int first_obst = p.N + p.L, first_wall = first_obst + p.O, partners = p.N + p.O + p.W;
+    const double dmin_e = 2 * kEntitySize, dmin_w = kEntitySize + kWallWidth;
+    const double far_e = (dmin_e + 37.0 * kContactMargin) * (dmin_e + 37.0 * kContactMargin);
+    const double mid_e = (dmin_e + 24.0 * kContactMargin) * (dmin_e + 24.0 * kContactMargin);
+    const double far_w = (dmin_w + 37.0 * kContactMargin) * (dmin_w + 37.0 * kContactMargin);
+    const double mid_w = (dmin_w + 24.0 * kContactMargin) * (dmin_w + 24.0 * kContactMargin);
+    for (int p0 = 0; p0 < (FMARL_SKIP(p, 1) ? 0 : partners); p0 += 32) {
+        uint32_t near = 0, midm = 0;
+        const int cnt = min(32, partners - p0);
+        for (int k = 0; k < cnt; ++k) {
+            const int b = p0 + k < p.N ? p0 + k : p0 + k + p.L;       // partner index -> entity index
+            const double2 q = s_pos[b];
+            const double dx = x.x - q.x, dy = x.y - q.y, d2 = dx * dx + dy * dy;
+            const bool wall = b >= first_wall;
+            const bool ok = b != i && (b >= p.N || agent_forces);     // self; status == True: core.py:394-398
+            const bool in_far = !(d2 > (wall ? far_w : far_e)), in_mid = !(d2 > (wall ? mid_w : mid_e));
+            near |= (uint32_t)(ok & in_mid) << k;
+            midm |= (uint32_t)(ok & in_far & !in_mid) << k;
+        }
+        while (near) {
+            const int k = __builtin_ctz(near);
+            near &= near - 1;
+            const int b = p0 + k < p.N ? p0 + k : p0 + k + p.L;
+            const double2 q = s_pos[b];
+            const double dx = x.x - q.x, dy = x.y - q.y;
+            const double d = sqrt(dx * dx + dy * dy);
+            const double dmin = b < first_wall ? dmin_e : dmin_w;
+            const double c = kContactForce * softplus_pen(-(d - dmin) / kContactMargin, kContactMargin) / d;
+            Fx += c * dx;
+            Fy += c * dy;
+        }
+        while (midm) {
+            const int k = __builtin_ctz(midm);
+            midm &= midm - 1;
+            const int b = p0 + k < p.N ? p0 + k : p0 + k + p.L;
+            const double2 q = s_pos[b];
+            const float fdx = (float)(x.x - q.x), fdy = (float)(x.y - q.y);
             const float r = rsqrtf(fdx * fdx + fdy * fdy), d = 1.0f / r;
-            const float e = __expf(((float)dmin - d) * (float)(1.0 / kContactMargin));
+            const float dmin = b < first_wall ? (float)dmin_e : (float)dmin_w;
+            const float e = __expf((dmin - d) * (float)(1.0 / kContactMargin));
             const float c = (float)(kContactForce * kContactMargin) * e * r;
             Fx += (double)(c * fdx);
             Fy += (double)(c * fdy);
-            continue;
         }
-        const double d = sqrt(d2);
-        const double z = -(d - dmin) / kContactMargin;
-        const double c = kContactForce * softplus_pen(z, kContactMargin) / d;
-        Fx += c * dx;
-        Fy += c * dy;
     }
     // core.py:317-326 + :407-462 walls proper
     const double *wl = (const double *)(base + p.lds_wall);
@@ -464,15 +487,31 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         const bool open = Tr_old == -1.0;
         dg = dist2(x, goal);                                          // navigation_graph.py:583, :774
         Tr_new = (dg < p.thr && open) ? step * kDt : Tr_old;          // :587-589
-        s_stat[i] = pd;
-        s_stat[p.N + i] = Dg_old;
-        s_stat[2 * p.N + i] = open ? pd : Dg_old;                     // :590, :597
-        s_stat[3 * p.N + i] = Tr_old;
-        s_stat[4 * p.N + i] = Tr_new;
+        if (!p.scan_stats) {
+            s_stat[i] = pd;
+            s_stat[p.N + i] = Dg_old;
+            s_stat[2 * p.N + i] = open ? pd : Dg_old;                 // :590, :597
+            s_stat[3 * p.N + i] = Tr_old;
+            s_stat[4 * p.N + i] = Tr_new;
+        }
         will_reset = auto_reset && step >= p.episode_length;          // env_wrappers.py:859-864
         if (i == 0) *(int *)(base + p.lds_flag) = will_reset ? 1 : 0;
     }
     __syncthreads();
+
+    // Statistics of the sequential agent loop.  N a power of two (an env = an aligned run of lanes of one wave):
+    // wave scans of (mean, M2) runs, every lane taking part (idle lanes carry zeros); otherwise loops over LDS below.
+    double f_m = 1.0, f_sd = 1.0, dm = 0.0, ds = 0.0, tm = 0.0, ts = 0.0;
+    if (p.scan_stats && !FMARL_SKIP(p, 2)) {
+        const bool open = Tr_old == -1.0;
+        double bm, bs, am, aq;
+        seg_mixed_stats(p.N, i, open ? pd : Dg_old, Dg_old, dm, ds, bm, bs);
+        seg_all_runs(p.N, pd, am, aq);
+        const bool unset = Dg_old == -1.0;                            // :764-766, :849-851: p_dist statistics
+        f_m = unset ? am : bm;
+        f_sd = unset ? sqrt(aq / p.N) : bs;
+        if (o.info && !FMARL_SKIP(p, 8)) seg_mixed_stats(p.N, i, Tr_new, Tr_old, tm, ts, bm, bs);
+    }
 
     if (active) {
         const bool open = Tr_old == -1.0;
@@ -483,6 +522,7 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         // agent's dists_to_goal is still -1, otherwise the statistics info_{i-1} left behind.
         double fairness, m, sd;
         if (FMARL_SKIP(p, 2)) { m = 1.0; sd = 1.0; }
+        else if (p.scan_stats) { m = f_m; sd = f_sd; }
         else if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd);
         fairness = m / (sd + 0.0001);
@@ -523,9 +563,10 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         if (o.info && !FMARL_SKIP(p, 8)) {
             // info_callback (:577-647): statistics after this agent's own update (entries <= i fresh).
             // Field-major records: info[k][env][agent], every store is lane-contiguous.
-            double dm, ds, tm, ts;
-            mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
-            mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
+            if (!p.scan_stats) {
+                mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
+                mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
+            }
             const size_t plane = (size_t)p.n_envs * p.N;
             float *inf = o.info + g;
             inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left_new;

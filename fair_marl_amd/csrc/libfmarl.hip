@@ -266,6 +266,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_stat = off;   off = align16(off + 5 * p.N * 8);
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 4);
+    p.has_posf = !form && !fnav;
+    p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
         p.f_slot_old = off; off = align16(off + p.N * 16);
@@ -309,6 +311,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 #endif
     p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
     p.vec_adj = p.E % 4 == 0;
+    p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
