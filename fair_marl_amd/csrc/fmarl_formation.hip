@@ -24,17 +24,34 @@ constexpr double kTargetRadius = 0.5;   // ff:105
 // Min-sum assignment (Kuhn-Munkres with potentials, shortest augmenting paths) by a group of G lanes
 // (G = power of two >= N, G <= 32): lane c owns column c (v, minv, way, matched row) and row c (u, in-tree
 // flag); the only cross-lane traffic is the argmin reduction and a few broadcasts (shuffles of width G).
-// Costs are |x_row - P_col| computed on the fly (x: agent positions in LDS, P: slot positions; no N x N
-// table, which would halve the envs per workgroup).  ans[row] = col.  For generic real costs the optimum is unique, so it
+// Costs are |x_row - P_col| computed on the fly (x: agent positions in LDS, P: slot positions; an N x N table per
+// group of lanes costs a workgroup per CU and was measured slower: 0.46 vs 0.42 ms at cfg 4).  ans[row] = col.  For generic real costs the optimum is unique, so it
 // equals SciPy's linear_sum_assignment (ff:615-618).
 template <int G>
-__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *ans) {
+__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *ans, const double *rowmin) {
     const int lane = threadIdx.x & (G - 1);
-    const double2 Pc = P[lane < N ? lane : 0];
     const double INF = 1e300;
     double u = 0.0, v = 0.0;
     int prow = -1;   // row matched to column `lane`
-    for (int i = 0; i < N; ++i) {
+    const double2 Pc = P[lane < N ? lane : 0];
+    // Start: u = row minima, v = 0 (feasible potentials), every row claims its cheapest column, the lowest row wins a
+    // contested one (those edges are tight).  Only the rows left without a column go through the augmenting search;
+    // the optimum does not depend on the start.
+    // (row minima and their columns come from the kernel's agent x slot distance pass: rowmin[], ans[] on entry)
+    int mine = 0;
+    {
+        if (lane < N) { u = rowmin[lane]; mine = ans[lane]; }
+        for (int r = 0; r < N; ++r) {
+            const int cr = __shfl(mine, r, G);
+            if (lane == cr && prow < 0) prow = r;
+        }
+    }
+    const bool unmatched = lane < N && __shfl(prow, mine, G) != lane;
+    const unsigned long long um_all = __ballot(unmatched);
+    uint32_t um = (uint32_t)(um_all >> ((threadIdx.x & 63) & ~(G - 1))) & (G == 32 ? ~0u : ((1u << G) - 1));
+    while (um) {
+        const int i = __builtin_ctz(um);
+        um &= um - 1;
         double minv = INF;
         int way = -1, j0 = -1, i0 = i, j1;
         bool usedc = false, in_tree = lane == i;
@@ -132,7 +149,8 @@ __device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_en
     for (int task = group; task < nenv * per_env; task += ngroups) {
         const int el = task / per_env, which = task - el * per_env;
         const FormLds t(p, lds, el);
-        hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old());
+        hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
+                           which == 0 ? t.theta() : (const double *)t.masks());
     }
 }
 
@@ -240,6 +258,9 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         }
         left = best;
         t.near_new()[i] = best < p.thr ? kb : -1;
+        // start of the matchings (hungarian_group): row minimum and its column, in tables that are idle until then
+        t.theta()[i] = best; t.g_new()[i] = kb;
+        if (STEP) { ((double *)t.masks())[i] = best_old; t.g_old()[i] = kb_old; }
         if (i == 0) t.words()[3] = (uint32_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
     }
     __syncthreads();

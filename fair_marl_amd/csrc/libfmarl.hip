@@ -293,6 +293,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     const int budget = 48 * 1024 - (kThreads / 64) * p.stage_wave_bytes;
     if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
     if (epb < 1) epb = 1;
+    if (form) {   // the step's 2 matchings per env are dealt to groups of G lanes: keep the last round of tasks full
+        int G = 4;
+        while (G < p.N) G *= 2;
+        const int groups = kThreads / (G < 32 ? G : 32);
+        for (int e = epb; e >= 1 && 10 * e >= 9 * epb; --e)
+            if ((2 * e) % groups == 0) { epb = e; break; }
+    }
     // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
     if ((p.n_envs + epb - 1) / epb < 512) { int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb); }
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
