@@ -81,7 +81,10 @@ __global__ __launch_bounds__(kThreads) void rebuild_graph_kernel(Params p, Fmarl
         wl[0] = axis; wl[1] = (double)qf[2]; wl[2] = (double)qf[3]; wl[3] = (double)qf[4];
         ((double2 *)(base + p.lds_pos))[p.N + LO + w] = qf[4] == 0.f ? make_double2(0.0, axis) : make_double2(axis, 0.0);
         ((float2 *)(base + p.lds_posf))[p.N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
+        ((float4 *)(base + p.lds_wallf))[w] = make_float4((float)wl[1], (float)(axis + kWallWidth / 2), (float)wl[2], (float)(axis - kWallWidth / 2));
     }
+    for (int t = tid; t < nenv; t += kThreads)
+        *(float4 *)(lds + (size_t)t * p.lds_env_bytes + p.lds_constf) = make_float4(0.f, 1.f, 2.f, 3.f);
     __syncthreads();
     emit_graph(p, o, lds, env0, nenv);
 }

@@ -35,28 +35,6 @@ struct EnvLds {
     __device__ const double *wall() const { return (const double *)(base + p.lds_wall); }
     __device__ bool skip() const { return *(const int *)(base + p.lds_flag) != 0; }
 
-    // Column f of the node-feature row of entity e before the ego part is subtracted
-    // (navigation_graph.py:1079-1124): [vel, pos, goal, pos, pos, type]; walls: corners in 6..9.
-    __device__ float entity_feature(uint32_t e, uint32_t f) const {
-        const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
-        if (p.feat_global) f = f == 6 ? 10 : f;   // 'global' rows are the first six columns + type (navigation_graph.py:1058-1077)
-        if (f == 10) return e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
-        if (f < 2) {
-            if (e >= N) return 0.f;
-            const float4 a = agentf()[e];
-            return f == 0 ? a.x : a.y;
-        }
-        if (e < N && f < 6 && f >= 4) {   // goal of agent e
-            const float4 a = agentf()[e];
-            return f == 4 ? a.z : a.w;
-        }
-        if (e >= first_wall && f >= 6) {   // (e0, axis + w/2), (e1, axis - w/2): navigation_graph.py:1115-1116
-            const double *wl = wall() + (e - first_wall) * 4;
-            return (float)(f == 6 ? wl[1] : (f == 7 ? wl[0] + kWallWidth / 2 : (f == 8 ? wl[2] : wl[0] - kWallWidth / 2)));
-        }
-        const double2 x = pos()[e];
-        return (float)((f & 1) ? x.y : x.x);
-    }
     // whole row of entity e in the block of ego i: feat(e) - ego(i), both sides rounded to f32 first; returns F
     __device__ int node_row(uint32_t i, uint32_t e, float (&o)[11]) const {
         const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
@@ -83,6 +61,20 @@ struct EnvLds {
     }
 };
 
+// Where column f of the node-feature row of entity e lives inside an env's LDS block, before the ego part is
+// subtracted (navigation_graph.py:1079-1124): [vel, pos, goal, pos, pos, type]; walls: corners in 6..9.
+// All sources are f32 tables: agentf (vx, vy, gx, gy), posf, wallf (the four corner words), constf (0, 1, 2, 3).
+__device__ __forceinline__ uint32_t feature_src(const Params &p, uint32_t e, uint32_t f) {
+    const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
+    if (p.feat_global) f = f == 6 ? 10 : f;   // 'global' rows are the first six columns + type (navigation_graph.py:1058-1077)
+    if (f == 10) return p.lds_constf + 4 * (e < N ? 0 : (e < N + p.L ? 1 : (e < first_wall ? 2 : 3)));
+    if (f < 2) return e < N ? p.lds_agentf + 16 * e + 4 * f : p.lds_constf;
+    if (f < 4) return p.lds_posf + 8 * e + 4 * (f - 2);
+    if (f < 6) return e < N ? p.lds_agentf + 16 * e + 4 * (f - 2) : p.lds_posf + 8 * e + 4 * (f - 4);
+    if (e >= first_wall) return p.lds_wallf + 16 * (e - first_wall) + 4 * (f - 6);   // (e0, axis + w/2), (e1, axis - w/2): :1115-1116
+    return p.lds_posf + 8 * e + 4 * ((f - 6) & 1);
+}
+
 // node_obs, 16-byte path (E*F % 4 == 0, at most 64 * CG <= 256 float4 chunks per ego row).  A wave owns whole
 // environments: each lane builds the entity part of its CG column chunks once per env, then the wave
 // streams the N ego rows front to back (1 KiB per store instruction, rows back to back in memory).
@@ -91,28 +83,34 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
     // the wave index is uniform: say so, and the env / row addressing below stays in scalar registers
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = kThreads / 64;
     const uint32_t EF = p.E * p.F, C4 = EF >> 2;
+    // Once per wave: where each of the lane's 4 CG elements comes from -- byte offset of the entity value inside an
+    // env's LDS block (16 bits each) and of the ego value inside an ego row [vx vy x y 0] (8 bits each).  The env
+    // loop below is then loads and subtractions only.
+    uint32_t src[CG][2], boff[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) {
+        const uint32_t c = g * 64 + lane;
+        src[g][0] = src[g][1] = (uint32_t)p.lds_constf * 0x10001u;
+        boff[g] = 0;
+        if (c < C4) {
+            uint32_t e = p.dF.div(c * 4), f = c * 4 - e * p.F;
+            src[g][0] = src[g][1] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                src[g][k >> 1] |= feature_src(p, e, f) << (16 * (k & 1));
+                boff[g] |= (4 * ((f == 10 || p.feat_global) ? 4 : (f < 2 ? f : 2 + (f & 1)))) << (8 * k);
+                if (++f == (uint32_t)p.F) { f = 0; ++e; }
+            }
+        }
+    }
     for (uint32_t el = wave; el < (uint32_t)nenv; el += nwaves) {
         const EnvLds t(p, lds, el);
         if (t.skip()) continue;
         float4 a[CG];
-        uint32_t boff[CG];   // per chunk: byte offsets of the four elements' ego values inside an ego row [vx vy x y 0], 8 bits each
 #pragma unroll
-        for (int g = 0; g < CG; ++g) {
-            const uint32_t c = g * 64 + lane;
-            a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            boff[g] = 0;
-            if (c < C4) {
-                uint32_t e = p.dF.div(c * 4), f = c * 4 - e * p.F;
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[k] = t.entity_feature(e, f);
-                    boff[g] |= (4 * ((f == 10 || p.feat_global) ? 4 : (f < 2 ? f : 2 + (f & 1)))) << (8 * k);
-                    if (++f == (uint32_t)p.F) { f = 0; ++e; }
-                }
-                a[g] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
+        for (int g = 0; g < CG; ++g)
+            a[g] = make_float4(*(const float *)(t.base + (src[g][0] & 0xffff)), *(const float *)(t.base + (src[g][0] >> 16)),
+                               *(const float *)(t.base + (src[g][1] & 0xffff)), *(const float *)(t.base + (src[g][1] >> 16)));
         float4 *dst = (float4 *)(o.node_obs + ((size_t)(env0 + el) * p.N) * EF);
         // ego rows are 20 bytes apart: per block of four rows one scalar base + the lane's column offsets,
         // the rows themselves are immediate offsets of the ds_read (keeps the address math off the VALU)
@@ -294,6 +292,9 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         pos[p.N + k] = x;
         if (p.has_posf) ((float2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)x.x, (float)x.y);
     }
+    if (p.has_posf)
+        for (int t = threadIdx.x; t < nenv; t += kThreads)
+            *(float4 *)(lds + (size_t)t * p.lds_env_bytes + p.lds_constf) = make_float4(0.f, 1.f, 2.f, 3.f);
     for (int t = threadIdx.x; t < nenv * p.W; t += kThreads) {
         int el = t / p.W, w = t - el * p.W;
         char *base = lds + (size_t)el * p.lds_env_bytes;
@@ -303,6 +304,7 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         double *wl = (double *)(base + p.lds_wall) + w * 4;
         wl[0] = axis; wl[1] = p.wall_e0[g]; wl[2] = p.wall_e1[g]; wl[3] = (double)orient;
         // wall "sphere" centre: (0, axis) for 'H', (axis, 0) for 'V' (navigation_graph.py:309-324)
+        if (p.has_posf) ((float4 *)(base + p.lds_wallf))[w] = make_float4((float)wl[1], (float)(axis + kWallWidth / 2), (float)wl[2], (float)(axis - kWallWidth / 2));
         const double2 c = orient == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
         ((double2 *)(base + p.lds_pos))[p.N + LO + w] = c;
         if (p.has_posf) ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);

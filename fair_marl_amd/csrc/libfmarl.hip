@@ -268,6 +268,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_flag = off;   off = align16(off + 4);
     p.has_posf = !form && !fnav;
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
+    p.lds_wallf = off;  off = align16(off + (p.has_posf ? p.W * 16 : 0));
+    p.lds_constf = off; off = align16(off + (p.has_posf ? 16 : 0));
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
         p.f_slot_old = off; off = align16(off + p.N * 16);
@@ -316,7 +318,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 #ifdef FMARL_MEASURE
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
 #endif
-    p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4;
+    p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4 && p.lds_env_bytes < 65536;
     p.vec_adj = p.E % 4 == 0;
     p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
