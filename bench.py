@@ -128,6 +128,9 @@ def main():
     ap.add_argument('--record-path', action='store_true', help='N=1: write the step records / episode records as the '
                     'multi-GPU run does (the gather itself is a no-op with one rank)')
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
+                         'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -157,10 +160,13 @@ def main():
         except Exception as exc:   # e.g. no process spawning on this host: fall back to one in-process worker
             print('bench.py: multi-process cpu baseline failed (%s); using one process' % exc, file=sys.stderr)
             cpu = cpu_baseline(spec['env'], spec['cpu_envs'], spec['cpu_episodes'], 1)
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank if args.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
 
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
@@ -252,7 +258,7 @@ def main():
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed at episode end'),
-                       'exchange': ('RCCL gather of obs/reward/done to rank 0 every step, %d B per agent-step'
+                       'exchange': (('RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)') + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)
                                     + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'
                                        % (4 * eng.episode_record_words) if episodes else '')) if gather else 'none'},

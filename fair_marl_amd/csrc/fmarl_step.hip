@@ -199,8 +199,13 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
                 const EnvLds t(p, lds, el);
                 if (t.skip()) { ok[j] = false; continue; }
                 const uint32_t r = q - el * EE, a = p.dE.div(r), b = r - a * p.E;
-                const double2 pa = t.pos()[a], pb = t.pos()[b];
-                v[j] = dist_f32((float)(pa.x - pb.x), (float)(pa.y - pb.y));
+                if (p.has_posf) {   // navigation_graph: the f32 position table (what a learner-side rebuild has)
+                    const float2 pa = t.posf()[a], pb = t.posf()[b];
+                    v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
+                } else {
+                    const double2 pa = t.pos()[a], pb = t.pos()[b];
+                    v[j] = dist_f32((float)(pa.x - pb.x), (float)(pa.y - pb.y));
+                }
             }
         }
         if (ok[0] & ok[1] & ok[2] & ok[3]) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);

@@ -4,6 +4,8 @@ Tolerances: device STATE is float64 and must follow the float64 reference trajec
 (rtol/atol 1e-9; the stiff soft-contact dynamics amplify last-bit differences of exp/log/sqrt
 implementations); OUTPUTS are float32 and must match within 1e-5 (north_star: "within 1e-5 fp32").
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,7 @@ pytestmark = pytest.mark.gpu
 OUT = dict(rtol=1e-5, atol=1e-5)
 STATE = dict(rtol=1e-9, atol=1e-9)
 DEV = 'cuda:0'
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def env_cfg(ocfg):
@@ -176,7 +179,7 @@ def test_async_and_sync_reset_are_identical():
                                                       (32, 8, 0, 33, False, 'global')])
 def test_learner_side_rebuild_of_node_obs_and_adj(N, O, W, n, async_reset, feat):
     """Multi-GPU hand-off: node_obs / adj are not sent; the learner rebuilds them from the gathered obs rows and
-    the once-per-episode record.  node_obs must equal the sender's bit for bit, adj within 1e-6 (f32 positions)."""
+    the once-per-episode record.  Both must equal the sender's bit for bit."""
     cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W, episode_length=6, graph_feat_type=feat)
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=5, async_reset=async_reset)
     g = torch.Generator(device=DEV); g.manual_seed(9)
@@ -187,7 +190,7 @@ def test_learner_side_rebuild_of_node_obs_and_adj(N, O, W, n, async_reset, feat)
     for t in range(15):
         node, adj = eng.rebuild_graph(eng.obs, rec)
         assert torch.equal(node, eng.node_obs), 'node_obs step %d' % t
-        np.testing.assert_allclose(adj.cpu().numpy(), eng.adj_env.cpu().numpy(), rtol=0, atol=1e-6)
+        assert torch.equal(adj, eng.adj_env), 'adj step %d' % t   # both sides start from the same f32 position table
         eng.step(torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32))
         assert eng.episode_started == ((t + 1) % 6 == 0)
         if eng.episode_started:
@@ -199,6 +202,44 @@ def test_learner_side_rebuild_of_node_obs_and_adj(N, O, W, n, async_reset, feat)
     assert none is None and torch.equal(node2[:n], eng.node_obs) and torch.equal(node2[n:], eng.node_obs.flip(0))
     none, adj2 = eng.rebuild_graph(obs2, rec2, want_node_obs=False)
     assert none is None and torch.equal(adj2[n:], adj2[:n].flip(0))
+
+
+def _run_ranks(script_args, world=2, timeout=600):
+    """Start ``world`` ranks of a script with torch.distributed.run (child processes; this process keeps the GPU)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + script_args
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout,
+                         cwd=os.path.dirname(HERE))
+    assert res.returncode == 0, res.stdout[-4000:]
+    return res.stdout
+
+
+def test_two_ranks_gather_reproduces_the_unsharded_rollout():
+    """The N > 1 path of bench.py with real processes on the GPU: two ranks step their shards, rank 0 gathers the
+    step and episode records (gloo: RCCL needs one GPU per rank) and rebuilds node_obs / adj; everything must equal
+    one unsharded engine bit for bit (tests/dist_rollout_check.py)."""
+    out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py')])
+    assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's own multi-rank loop (record rotation, gathers inside the timed region, max over ranks, one JSON
+    line from rank 0) with two ranks sharing the GPU over gloo."""
+    import json
+    out = _run_ranks([os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--n-envs', '512',
+                      '--steps', '30', '--warmup', '5'])
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-4000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
+    assert d['value'] == pytest.approx(2 * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
+    assert 'cpu_baseline' not in d and d['roofline']['kernel_launches'] == 30
 
 
 def test_rebuild_is_refused_for_other_scenarios():
