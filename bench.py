@@ -37,11 +37,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 CONFIGS = {
     # BASELINE.json configs[2] (and configs[4] per GPU): the configuration the target is quoted on
     'cfg3': dict(workload='navigation_graph, 32 agents + 8 obstacles (E=72), 65536 envs per GPU',
-                 env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=32, cpu_episodes=3),
+                 env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=32, cpu_episodes=12),
     # BASELINE.json configs[3]
     'cfg4': dict(workload='fair_graph_formation, 10 agents + 1 landmark + 3 obstacles + 2 walls (E=16), 65536 envs per GPU',
                  env=dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3),
-                 n_envs=65536, cpu_envs=16, cpu_episodes=4),
+                 n_envs=65536, cpu_envs=16, cpu_episodes=12),
     # the shipped FA+FR weights' configuration (model_weights/FA+FR/config.yaml)
     'fnav': dict(workload='nav_fairassign_fairrew_formation_graph, 3 agents + 3 obstacles (E=9), 65536 envs per GPU',
                  env=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3,

@@ -465,8 +465,17 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0;
     int step = 0, match = 0;
+    double Dg_old = 0, Tr_old = 0, left_old = 0;
+    int noc_old = 0, nac_old = 0;
     if (active) {
+        // the whole state of the agent in one round of loads (one memory latency per launch, which is what a small
+        // batch waits for; the kernel has the registers since the emission stopped needing them)
         x = p.agent_pos[g];
+        v = p.agent_vel[g]; pd = p.p_dist[g];
+        match = p.goal_match[g];
+        step = p.cur_step[env] + 1;   // environment.py:819, :823
+        Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left_old = p.dist_left[g];
+        noc_old = p.num_obst_coll[g]; nac_old = p.num_agent_coll[g];
         s_pos[i] = x;
     }
     load_statics(p, lds, env0, nenv);
@@ -476,21 +485,16 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     double2 goal = make_double2(0, 0);
     if (active) {
         const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x);
-        // everything else of the agent's state is first needed here: loaded after the pair loop, not carried through it
-        v = p.agent_vel[g]; pd = p.p_dist[g];
-        match = p.goal_match[g];
-        step = p.cur_step[env] + 1;   // environment.py:819, :823
         goal = s_pos[p.N + match];
         integrate_agent(p, F, x, v, pd);
     }
     __syncthreads();   // every lane has finished reading the old positions
 
-    double Dg_old = 0, Tr_old = 0, left_old = 0, dg = 0, Tr_new = 0;
+    double dg = 0, Tr_new = 0;
     bool will_reset = false;
     if (active) {
         s_pos[i] = x;
         store_agent_rows(p, base, i, x, v, goal);
-        Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left_old = p.dist_left[g];
         const bool open = Tr_old == -1.0;
         dg = dist2(x, goal);                                          // navigation_graph.py:583, :774
         Tr_new = (dg < p.thr && open) ? step * kDt : Tr_old;          // :587-589
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
         rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
         // state + small outputs
-        const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
+        const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
         p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
         p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left_new;
         p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
