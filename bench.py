@@ -128,6 +128,8 @@ def main():
     ap.add_argument('--record-path', action='store_true', help='N=1: write the step records / episode records as the '
                     'multi-GPU run does (the gather itself is a no-op with one rank)')
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
+    ap.add_argument('--no-tune-placement', action='store_true', help='keep the first allocation of node_obs / adj instead of '
+                    'the fastest of six (RolloutEngine tune_placement)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
                          'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
@@ -171,7 +173,8 @@ def main():
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
-    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset)
+    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
+                           tune_placement=0 if args.no_tune_placement else None)
     gather = (world > 1 or args.record_path) and not args.no_gather
     depth = 2
     # navigation_graph: the learner rebuilds node_obs / adj from obs + a record gathered once per episode
@@ -258,6 +261,10 @@ def main():
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed at episode end'),
+                       'output_placement': ('fastest of several allocations per buffer, emission-only launch ms: '
+                                            + '; '.join('%s %s' % (k, ' '.join('%.3f' % t for t in v))
+                                                        for k, v in eng.placement_ms.items())
+                                            if eng.placement_ms else 'first allocation'),
                        'exchange': (('RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)') + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)
                                     + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'

@@ -107,10 +107,17 @@ struct PhiloxStream {
 // log(u) for u in [1, 2], absolute error < 1e-16: u -> m in [1/sqrt2, sqrt2], s = (m-1)/(m+1),
 // log m = 2 s (1 + s^2/3 + ... + s^20/21) (|s| <= 0.172, truncation 6e-19).  ~27 f64 ops where the
 // library log1p spends 113; absolute (not relative) accuracy is what the force sum needs.
+// 1 / x to an ulp or so for normal x: v_rcp_f64 + two Newton steps (a correctly rounded f64 division is 12 instructions)
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ double log_1to2(double u) {
     const bool big = u > 1.4142135623730951;
     const double m = big ? u * 0.5 : u;
-    const double s = (m - 1.0) / (m + 1.0), w = s * s;
+    const double s = (m - 1.0) * rcp_nr(m + 1.0), w = s * s;
     double q = 1.0 / 21.0;
     q = fma(q, w, 1.0 / 19.0); q = fma(q, w, 1.0 / 17.0); q = fma(q, w, 1.0 / 15.0);
     q = fma(q, w, 1.0 / 13.0); q = fma(q, w, 1.0 / 11.0); q = fma(q, w, 1.0 / 9.0);
@@ -127,9 +134,37 @@ __device__ __forceinline__ double softplus_pen(double z, double k) {
     return (fmax(z, 0.0) + log_1to2(1.0 + t)) * k;
 }
 
+// sqrt(x) for x = 0 or x in the normal range (squared distances inside a 2 x 2 world): the library's own
+// Goldschmidt iteration on v_rsq_f64 (same bits) without its rescaling of tiny / huge arguments and its class test,
+// 13 instructions instead of 25 -- this sits inside the contact pairs and the matchings' inner loops.
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
+// sqrt(x) and 1 / sqrt(x) for x > 0 in the normal range (the contact pairs need both: d and the unit vector)
+__device__ __forceinline__ double sqrt_inv_pos(double x, double &inv) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    const double i2 = h + h;                 // 1 / sqrt(x) after one refinement; one Newton step against g
+    inv = fma(fma(-g, i2, 1.0), i2, i2);
+    return g;
+}
+
 __device__ __forceinline__ double dist2(double2 a, double2 b) {
     double dx = a.x - b.x, dy = a.y - b.y;
-    return sqrt(dx * dx + dy * dy);
+    return sqrt_pos(dx * dx + dy * dy);
 }
 
 // |(dx, dy)| for the f32 outputs: one v_sqrt_f32 (1 ulp; sqrtf's correctly rounded sequence is 17 instructions,
@@ -162,7 +197,9 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
 }
 // min / max of a double over a group of G lanes, result in every lane
 template <int G, bool MAX> __device__ __forceinline__ double group_extreme(double v) {
-#define FMARL_EXT_STEP(o) { const double o_ = (o); v = (MAX ? o_ > v : o_ < v) ? o_ : v; }
+    // one v_min_f64 / v_max_f64 per step (asm: the builtin form canonicalises both operands first; no NaNs here)
+#define FMARL_EXT_STEP(o) { const double o_ = (o); if (MAX) asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_)); \
+                            else asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_)); }
     FMARL_EXT_STEP(dpp_f64<0xB1>(v))                 // quad_perm [1,0,3,2]
     FMARL_EXT_STEP(dpp_f64<0x4E>(v))                 // quad_perm [2,3,0,1]
     if (G >= 8) FMARL_EXT_STEP(dpp_f64<0x141>(v))    // row_half_mirror

@@ -383,9 +383,11 @@ __device__ __forceinline__ double2 agent_force(const Params &p, const char *base
             const int b = p0 + k < p.N ? p0 + k : p0 + k + p.L;
             const double2 q = s_pos[b];
             const double dx = x.x - q.x, dy = x.y - q.y;
-            const double d = sqrt(dx * dx + dy * dy);
+            double inv_d;
+            const double d = sqrt_inv_pos(dx * dx + dy * dy, inv_d);   // two entities never sit on the same point
             const double dmin = b < first_wall ? dmin_e : dmin_w;
-            const double c = kContactForce * softplus_pen(-(d - dmin) / kContactMargin, kContactMargin) / d;
+            // core.py:389-392 divides by the margin and by d; multiplying by 1 / margin and 1 / d moves the force by an ulp
+            const double c = kContactForce * softplus_pen((dmin - d) * (1.0 / kContactMargin), kContactMargin) * inv_d;
             Fx += c * dx;
             Fy += c * dy;
         }

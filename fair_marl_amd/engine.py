@@ -25,7 +25,7 @@ class OutputSet(object):
 
 class RolloutEngine:
     def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True,
-                 emit_graph=True):
+                 emit_graph=True, tune_placement=None):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_args(cfg)
         cfg.validate()
@@ -51,6 +51,11 @@ class RolloutEngine:
             self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device) if emit_graph else None
             self.agent_id = torch.arange(N, device=self.device).view(1, N, 1).expand(n, N, 1)
         self.emit_info, self.emit_graph = emit_info, emit_graph
+        self.placement_ms = None
+        if tune_placement is None:   # worth it once the graph outputs are GBs (the step is then bound by their store stream)
+            tune_placement = 6 if emit_graph and cfg.scenario_name == 'navigation_graph' and n * N * E * F * 4 >= (1 << 30) else 0
+        if tune_placement and tune_placement > 1:
+            self._tune_output_placement(int(tune_placement))
         self._default_graph = (self.node_obs, self.adj_env)
         self.outs = self.new_output_set()
         self.use_outputs(self.outs)
@@ -68,6 +73,44 @@ class RolloutEngine:
             view = self.state[off.value: off.value + cnt.value * esz].view(_TORCH_DT[dt.value])
             self._fields[name] = view.view(shapes[name])
         _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
+
+    def _tune_output_placement(self, candidates, launches=5):
+        """Pick the fastest of several allocations for node_obs / adj.  How fast the store stream of the emission
+        runs depends on which physical pages an allocation happened to get: measured on MI355X at cfg 3, 1.42 to
+        1.65 ms per launch for different allocations inside ONE process, repeatable to 0.2 % for a given allocation
+        and independent of the offset inside it (tools/placement_probe.py).  Each candidate is timed with the pure
+        emission kernel (fmarl_rebuild_graph: writes node_obs / adj only, touches no env state); the losers are
+        freed.  ``placement_ms`` keeps the timings per buffer (first entry = the allocation the engine started with)."""
+        cfg, n, dev = self.cfg, self.n_envs, self.device
+        obs = torch.zeros(n, cfg.N, cfg.obs_dim, dtype=torch.float32, device=dev)
+        rec = torch.zeros(n, self.episode_record_words, dtype=torch.int32, device=dev)
+        self.placement_ms = {}
+        with torch.cuda.device(dev):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for name in ('node_obs', 'adj_env'):   # the two buffers are chosen independently
+                cands, times = [getattr(self, name)], []
+                for _ in range(candidates - 1):
+                    try:
+                        cands.append(torch.empty_like(cands[0]))
+                    except torch.cuda.OutOfMemoryError:
+                        break
+                for buf in cands:
+                    kw = dict(node_obs=buf, want_adj=False) if name == 'node_obs' else dict(adj_env=buf, want_node_obs=False)
+                    for _ in range(2):
+                        self.rebuild_graph(obs, rec, **kw)
+                    e0.record()
+                    for _ in range(launches):
+                        self.rebuild_graph(obs, rec, **kw)
+                    e1.record()
+                    e1.synchronize()
+                    times.append(e0.elapsed_time(e1) / launches)
+                best = min(range(len(cands)), key=times.__getitem__)
+                setattr(self, name, cands[best])
+                cands[best].zero_()
+                self.placement_ms[name] = times
+                del cands, buf
+            del obs, rec
+            torch.cuda.empty_cache()   # hand the losing allocations back to the driver
 
     def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None):
         """A set of per-step output buffers.  By default node_obs / adj are shared by all sets (large,
