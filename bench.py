@@ -129,7 +129,7 @@ def main():
                     'multi-GPU run does (the gather itself is a no-op with one rank)')
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
     ap.add_argument('--no-tune-placement', action='store_true', help='keep the first allocation of node_obs / adj instead of '
-                    'the fastest of six (RolloutEngine tune_placement)')
+                    'the fastest pair of a few (RolloutEngine tune_placement)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
                          'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
@@ -261,10 +261,11 @@ def main():
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed at episode end'),
-                       'output_placement': ('fastest of several allocations per buffer, emission-only launch ms: '
-                                            + '; '.join('%s %s' % (k, ' '.join('%.3f' % t for t in v))
-                                                        for k, v in eng.placement_ms.items())
-                                            if eng.placement_ms else 'first allocation'),
+                       'output_placement': ('fastest (node_obs, adj) allocation pair of %d x %d, emission-only launch ms %.3f '
+                                            '(first allocations %.3f, slowest pair %.3f)'
+                                            % (len(eng.placement_ms), len(eng.placement_ms[0]), min(map(min, eng.placement_ms)),
+                                               eng.placement_ms[0][0], max(map(max, eng.placement_ms)))
+                                            if eng.placement_ms else 'first allocations'),
                        'exchange': (('RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)') + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)
                                     + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'

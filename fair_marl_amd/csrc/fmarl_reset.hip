@@ -249,23 +249,31 @@ __global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOut
     double2 *s_pos = (double2 *)(base + p.lds_pos);
     double *s_stat = (double *)(base + p.lds_stat);
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
-    double Dg = 0;
+    double Dg = 0, pdist = 0;
     bool flagged = false;
     if (active) {
         flagged = p.reset_flag[env] != 0;
         x = p.agent_pos[g]; v = p.agent_vel[g]; Dg = p.dists_to_goal[g];
         s_pos[i] = x;
-        s_stat[i] = p.p_dist[g];
-        s_stat[p.N + i] = Dg;
+        pdist = p.p_dist[g];
+        if (!p.scan_stats) { s_stat[i] = pdist; s_stat[p.N + i] = Dg; }
         if (i == 0) *(int *)(base + p.lds_flag) = flagged ? 0 : 1;   // 1 = skip
     }
     if (!__syncthreads_or(flagged)) return;   // no freshly reset env in this workgroup (block-uniform exit)
     load_statics(p, lds, env0, nenv);
+    double sm = 0.0, sq = 0.0;
+    if (p.scan_stats) {   // every lane of the wave takes part (fmarl_dev.h); each agent then picks its vector
+        double dm_, dq_;
+        seg_all_runs(p.N, pdist, sm, sq);
+        seg_all_runs(p.N, Dg, dm_, dq_);
+        if (Dg != -1.0) { sm = dm_; sq = dq_; }
+    }
     __syncthreads();
     if (active && flagged) {
         const double2 goal = s_pos[p.N + p.goal_match[g]];
         double m, sd;   // navigation_graph.py:849-854
-        if (Dg == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
+        if (p.scan_stats) { m = sm; sd = sqrt(sq / p.N); }
+        else if (Dg == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + p.N, s_stat + p.N, p.N, p.N, m, sd);
         const double fairness = m / (sd + 0.0001);
         if (o.obs) {

@@ -263,7 +263,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_pos = off;    off = align16(off + p.E * 16);
     p.lds_agentf = off; off = align16(off + p.N * 16);
     p.lds_ego = off;    off = align16(off + ((form || fnav) ? 0 : p.N * kEgoWidth * 4));
-    p.lds_stat = off;   off = align16(off + 5 * p.N * 8);
+    p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
+    p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : 5 * p.N * 8));   // wave scans need no table
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 4);
     p.has_posf = !form && !fnav;
@@ -320,7 +321,6 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 #endif
     p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4 && p.lds_env_bytes < 65536;
     p.vec_adj = p.E % 4 == 0;
-    p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);

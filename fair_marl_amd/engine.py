@@ -75,42 +75,47 @@ class RolloutEngine:
         _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
 
     def _tune_output_placement(self, candidates, launches=5):
-        """Pick the fastest of several allocations for node_obs / adj.  How fast the store stream of the emission
-        runs depends on which physical pages an allocation happened to get: measured on MI355X at cfg 3, 1.42 to
-        1.65 ms per launch for different allocations inside ONE process, repeatable to 0.2 % for a given allocation
-        and independent of the offset inside it (tools/placement_probe.py).  Each candidate is timed with the pure
-        emission kernel (fmarl_rebuild_graph: writes node_obs / adj only, touches no env state); the losers are
-        freed.  ``placement_ms`` keeps the timings per buffer (first entry = the allocation the engine started with)."""
+        """Pick the fastest (node_obs allocation, adj allocation) pair out of a few.  How fast the store stream of the
+        emission runs depends on which physical pages the two allocations happened to get, and on the PAIR rather
+        than on either buffer: measured on MI355X at cfg 3 (tools/placement_pairs.py, one process) 1.34 to 1.54 ms per
+        emission launch over 6 x 6 pairs -- the same adj allocation is the best partner of one node_obs allocation and
+        the worst of another -- repeatable to 0.2 % for a given pair and independent of offsets of a few MB inside an
+        allocation (tools/placement_probe.py).  Every pair of 3 node_obs x ``candidates`` adj allocations is timed with
+        the pure emission kernel (fmarl_rebuild_graph: writes node_obs / adj only, touches no env state); the losers
+        are freed.  ``placement_ms`` keeps the timing matrix (row 0 / column 0 = the allocations the engine started with)."""
         cfg, n, dev = self.cfg, self.n_envs, self.device
         obs = torch.zeros(n, cfg.N, cfg.obs_dim, dtype=torch.float32, device=dev)
         rec = torch.zeros(n, self.episode_record_words, dtype=torch.int32, device=dev)
-        self.placement_ms = {}
         with torch.cuda.device(dev):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for name in ('node_obs', 'adj_env'):   # the two buffers are chosen independently
-                cands, times = [getattr(self, name)], []
+            nodes, adjs = [self.node_obs], [self.adj_env]
+            try:
                 for _ in range(candidates - 1):
-                    try:
-                        cands.append(torch.empty_like(cands[0]))
-                    except torch.cuda.OutOfMemoryError:
-                        break
-                for buf in cands:
-                    kw = dict(node_obs=buf, want_adj=False) if name == 'node_obs' else dict(adj_env=buf, want_node_obs=False)
+                    adjs.append(torch.empty_like(self.adj_env))
+                for _ in range(2):
+                    nodes.append(torch.empty_like(self.node_obs))
+            except torch.cuda.OutOfMemoryError:
+                pass
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            times = []
+            for node in nodes:
+                row = []
+                for adj in adjs:
                     for _ in range(2):
-                        self.rebuild_graph(obs, rec, **kw)
+                        self.rebuild_graph(obs, rec, node_obs=node, adj_env=adj)
                     e0.record()
                     for _ in range(launches):
-                        self.rebuild_graph(obs, rec, **kw)
+                        self.rebuild_graph(obs, rec, node_obs=node, adj_env=adj)
                     e1.record()
                     e1.synchronize()
-                    times.append(e0.elapsed_time(e1) / launches)
-                best = min(range(len(cands)), key=times.__getitem__)
-                setattr(self, name, cands[best])
-                cands[best].zero_()
-                self.placement_ms[name] = times
-                del cands, buf
-            del obs, rec
+                    row.append(e0.elapsed_time(e1) / launches)
+                times.append(row)
+            bi, bj = min(((i, j) for i in range(len(nodes)) for j in range(len(adjs))), key=lambda ij: times[ij[0]][ij[1]])
+            self.node_obs, self.adj_env = nodes[bi], adjs[bj]
+            self.node_obs.zero_()
+            self.adj_env.zero_()
+            del nodes, adjs, node, adj, obs, rec
             torch.cuda.empty_cache()   # hand the losing allocations back to the driver
+        self.placement_ms = times
 
     def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None):
         """A set of per-step output buffers.  By default node_obs / adj are shared by all sets (large,

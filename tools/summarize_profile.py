@@ -23,7 +23,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    return sorted(glob.glob(os.path.join(src, pattern)))[0]
+    return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # gpurun merges: older runs stay around
 
 
 def counter_mean(path, kernel, counter):
