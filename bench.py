@@ -130,6 +130,8 @@ def main():
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
     ap.add_argument('--no-tune-placement', action='store_true', help='keep the first allocation of node_obs / adj instead of '
                     'the fastest pair of a few (RolloutEngine tune_placement)')
+    ap.add_argument('--graph', action='store_true', help='N=1: capture one episode of steps in a hipGraph and replay it '
+                    '(launch-bound small batches, e.g. --config cfg2; implies --sync-reset; --steps is rounded to whole episodes)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
                          'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
@@ -173,6 +175,12 @@ def main():
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
+    if args.graph:
+        if world > 1:
+            raise SystemExit('bench.py: --graph is a single-GPU mode')
+        args.sync_reset = True
+        ep_len = cfg.episode_length
+        K, W = max(ep_len, K // ep_len * ep_len), (W + ep_len - 1) // ep_len * ep_len   # whole episodes
     eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
                            tune_placement=0 if args.no_tune_placement else None)
     gather = (world > 1 or args.record_path) and not args.no_gather
@@ -207,6 +215,21 @@ def main():
             tg.finish()
 
     eng.reset()
+    if args.graph:
+        # the per-kernel hipEvents cannot live inside a captured graph: the dominant kernel is timed in an eager pass
+        # over whole episodes first, then the same steps run as graph replays inside the timed region
+        tape_len = cfg.episode_length
+        tape = tape[:tape_len].contiguous()
+        eng.profile_enable(2 * tape_len)
+        run(0, 2 * tape_len)
+        torch.cuda.synchronize(device)
+        kernel_ms_eager = eng.profile_read()
+        eng.profile_enable(0)
+        episode_graph = eng.capture_steps(tape)
+
+        def run(first, count):   # noqa: F811 -- whole episodes, one launch each
+            for _ in range(count // tape_len):
+                episode_graph.replay()
     try:
         run(0, W)
         torch.cuda.synchronize(device)
@@ -220,7 +243,8 @@ def main():
         eng.reset()
         run(0, W)
         torch.cuda.synchronize(device)
-    eng.profile_enable(K)
+    if not args.graph:
+        eng.profile_enable(K)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -235,7 +259,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = eng.profile_read()
+    kernel_ms = kernel_ms_eager if args.graph else eng.profile_read()
 
     if rank == 0:
         agents = n_envs * cfg.N
@@ -259,6 +283,8 @@ def main():
             'config': {'workload': spec['workload'], 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
+                       'launch': ('one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed '
+                                  'region)' % cfg.episode_length if args.graph else 'one fmarl_step call per step'),
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed at episode end'),
                        'output_placement': ('fastest (node_obs, adj) allocation pair of %d x %d, emission-only launch ms %.3f '

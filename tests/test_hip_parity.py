@@ -507,6 +507,41 @@ def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
             staged.step(tape[0])
 
 
+def test_capture_rollout_fills_the_rollout_buffer_from_one_graph():
+    """RolloutEngine.capture_rollout: a random-action episode written into the time slots of a DeviceRolloutBuffer by ONE
+    hipGraph launch equals the same episode inserted step by step (obs / node_obs / adj of every slot, rewards, dones)."""
+    from fair_marl_amd.rollout_buffer import DeviceRolloutBuffer
+    cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=3, episode_length=6)
+    n, T = 130, 6
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=4, async_reset=False)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=4, async_reset=False)
+    buf_a, buf_b = DeviceRolloutBuffer(a), DeviceRolloutBuffer(b)
+    gen = torch.Generator(device=DEV); gen.manual_seed(8)
+    tape = torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32)
+    buf_a.reset(); buf_b.reset()
+    graph = b.capture_rollout(tape, outputs=buf_b._sets[1:])
+    for ep in range(2):
+        tape.copy_(torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32))
+        for t in range(T):
+            buf_a.insert_step(tape[t])
+        graph.replay()
+        torch.cuda.synchronize()
+        for name in ('obs', 'node_obs', 'adj_env', 'rewards', 'dones'):
+            assert torch.equal(getattr(buf_a, name), getattr(buf_b, name)), 'episode %d %s' % (ep, name)
+        buf_a.after_update(); buf_b.after_update()
+    # capture_steps: same thing into the engine's current output set; the staged reset is refused
+    g2 = b.capture_steps(tape)
+    g2.replay()
+    for t in range(T):
+        a.step(tape[t])
+    torch.cuda.synchronize()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.node_obs, b.node_obs)
+    staged = fm.RolloutEngine(cfg, n, device=DEV, seed=4, async_reset=True)
+    staged.reset()
+    with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='FMARL_FLAG_ASYNC_RESET'):
+        staged.capture_steps(tape)
+
+
 def test_misaligned_output_buffers():
     """16-byte row shapes need 16-byte aligned node_obs / adj (refused otherwise); generic shapes take any float
     pointer and still produce the same values (aligned frames inside the kernels)."""
