@@ -53,3 +53,25 @@ def test_ties_total_order():
             assert c[np.arange(n), p].max() == c[np.arange(n), lexifair_bruteforce(c)].max()
             eps = c + 1e-9 * np.arange(n * n).reshape(n, n)   # the same order made explicit
             assert np.array_equal(p, lexifair_bruteforce(eps))
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 7, 10, 16])
+def test_reference_procedure_with_highs_gives_the_same_assignment(n):
+    """oracle/lexifair_milp.py restates the reference's PROCEDURE (marl_fair_assign.py:16-55: n rounds of a min-max
+    MILP, fix the bottleneck row) and solves the MILPs with HiGHS instead of Gurobi; for distinct costs the result
+    must be the assignment the definition-based solvers return -- on the reference's own call-site inputs
+    (cdist of agent and goal positions, navigation_graph.py:555) and on its __main__ example."""
+    from oracle.lexifair_milp import lexifair_milp, solve_fair_assignment_milp
+    rs = np.random.RandomState(100 + n)
+    for _ in range(6 if n <= 10 else 2):
+        c = cost_matrix(rs.uniform(-1, 1, (n, 2)), rs.uniform(-0.8, 0.8, (n, 2)))
+        p = lexifair_milp(c)
+        assert np.array_equal(p, lexifair(c))
+        if n <= 7:
+            assert np.array_equal(p, lexifair_bruteforce(c))
+    if n == 3:
+        goals = np.array([[0., -0.5], [0.45, -0.5], [0.9, -0.5]])
+        agents = np.array([[-0.9, -0.9], [-0.9, 0.], [-0.9, 0.9]])
+        x, objs = solve_fair_assignment_milp(cost_matrix(agents, goals))
+        assert np.array_equal(np.where(x == 1)[1], [2, 1, 0])
+        assert np.allclose(objs, [1.8439088915, 1.6643316977, 1.4396180049])
