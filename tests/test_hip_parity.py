@@ -102,6 +102,38 @@ def test_reset_and_rollout_vs_philox_oracle(N, O, W, n, feat):
     check_state(eng, orc.st, 'end')
 
 
+@pytest.mark.parametrize('N', [2, 4, 8, 16, 32, 64, 3, 10])
+def test_constant_distance_vectors_keep_std_exactly_zero(N):
+    """np.std of a constant vector is exactly 0 and the fairness scalar divides by std + 1e-4
+    (navigation_graph.py:766-769): with every agent's dists_to_goal frozen at the same value the scalar is
+    value / 1e-4 and a std of 1e-9 instead of 0 would already show at 1e-5.  Powers of two take the wave-scan
+    statistics (prefix / suffix runs joined pairwise), the others the LDS loops; envs with two distinct values and
+    with one odd agent sit beside the constant ones."""
+    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=2)
+    n, seed = 9, 77
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed)
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    orc = no.OracleGraphVecEnv(ocfg, n, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    eng.reset(); orc.reset()
+    st = orc.st
+    st.times_required[...] = 2.0                      # arrived earlier: dists_to_goal stays frozen (:590-598)
+    st.dists_to_goal[...] = 0.3
+    st.dists_to_goal[3:6, N // 2:] = 0.7              # two values
+    st.dists_to_goal[6:, N - 1] = 0.3000001           # one agent a hair off
+    st.p_dist[...] = 0.9
+    eng.set_state(oracle_state_dict(st))
+    rs = np.random.RandomState(N)
+    for t in range(3):
+        a = rs.randint(0, 5, size=(n, N))
+        obs, ids, node, adj, rew, done, info = eng.step(torch.as_tensor(a, device=DEV), auto_reset=False)
+        ref = orc.step(a)
+        f = obs.cpu().numpy()[:, :, 6]
+        assert np.all(f[:3] == np.float32(0.3 / 1e-4)), 'constant vector: fairness must be exactly value / 1e-4'
+        np.testing.assert_allclose(f, ref[0][:, :, 6], rtol=2e-6, atol=0, err_msg='fairness step %d' % t)
+        want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
+        check_outputs((obs, ids, node, adj, rew, done, info), want, 'N=%d step %d' % (N, t))
+
+
 @pytest.mark.parametrize('case', range(36))
 def test_random_small_configs_vs_oracle(case):
     """Ragged / degenerate shapes and knobs: N = 1, no obstacles, walls, n_envs = 1, episode_length = 1,
