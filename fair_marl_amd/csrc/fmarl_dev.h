@@ -244,11 +244,7 @@ template <int G> __device__ __forceinline__ uint32_t group_or32(uint32_t v) {
 // (Chan, Golub, LeVeque): no cancellation, and a run of equal values keeps M2 = 0 exactly -- np.std of a constant
 // vector is exactly 0 and the fairness scalar divides by std + 1e-4 (navigation_graph.py:766, :769).
 // Segments are the N lanes of one env, N a power of two (N | 64), li = lane index inside the segment.
-__device__ __forceinline__ double rcp_small(double n) {   // 1 / n for the small integer counts (two Newton steps)
-    double r = __builtin_amdgcn_rcp(n);
-    r = fma(fma(-n, r, 1.0), r, r);
-    return fma(fma(-n, r, 1.0), r, r);
-}
+__device__ __forceinline__ double rcp_small(double n) { return rcp_nr(n); }   // 1 / n for the small integer counts
 // run A (ca values) joined with run B (cb values), both counts >= 1
 __device__ __forceinline__ void run_join(double ma, double qa, double ca, double mb, double qb, double cb, double &m, double &q) {
     const double w = cb * rcp_small(ca + cb), d = mb - ma;
@@ -288,6 +284,7 @@ __device__ __forceinline__ void seg_suffix_runs(int N, int li, double v, double 
     }
     if (N > 32) FMARL_RUN_STEP(__shfl(m, 32, 64), __shfl(q, 32, 64), li < 32, 32, 32 - (li & 31))
 }
+#undef FMARL_RUN_STEP
 // all lanes of the segment: mean and M2 of the segment's N values (butterfly of equal-sized runs, symmetric in the
 // two partners, so every lane ends with the same bits)
 __device__ __forceinline__ void seg_all_runs(int N, double v, double &m, double &q) {
