@@ -149,6 +149,12 @@ __device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_en
     for (int task = group; task < nenv * per_env; task += ngroups) {
         const int el = task / per_env, which = task - el * per_env;
         const FormLds t(p, lds, el);
+        // the matching on the previous slots only serves observation(agent 0) in its "free slot left" branch
+        // (ff:707-739): not when agent 0 sits on a previous slot or every slot is taken (common once agents hold the ring)
+        if (which == 1) {
+            const uint32_t full = p.N >= 32 ? ~0u : ((1u << p.N) - 1);
+            if ((int)t.words()[3] >= 0 || ((~t.words()[0]) & full) == 0) continue;
+        }
         hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
                            which == 0 ? t.theta() : (const double *)t.masks());
     }
