@@ -66,3 +66,23 @@ def fnav_state_from(fx, cfg, prefix='init_'):
     for k in fnv.State.FIELDS:
         getattr(st, k)[...] = fx[prefix + k]
     return st
+
+
+RUNNER = ['runner_nav.npz', 'runner_navw.npz', 'runner_form.npz', 'runner_fnav.npz']
+
+
+def runner_oracle_env(fx):
+    """Oracle vec env of a runner_*.npz fixture, resets on the fixture's Philox stream (seed, env, episode)."""
+    from oracle.philox import PhiloxStream
+    args = json.loads(str(fx['args']))
+    seed, n = int(fx['seed']), fx['obs'].shape[1]
+    streams = lambda e, ep: PhiloxStream(seed, e, ep)  # noqa: E731
+    sc = args['scenario_name']
+    if sc == 'fair_graph_formation':
+        cfg = form_cfg_of(fx)
+        return fo.OracleFormationVecEnv(cfg, n, mode='dummy', streams=streams), cfg, fo.INFO_KEYS
+    if sc == 'nav_fairassign_fairrew_formation_graph':
+        cfg = fnav_cfg_of(fx)
+        return fnv.OracleFairNavVecEnv(cfg, n, mode='dummy', streams=streams), cfg, fnv.INFO_KEYS
+    cfg = cfg_of(fx)
+    return no.OracleGraphVecEnv(cfg, n, mode='dummy', streams=streams), cfg, no.INFO_KEYS
