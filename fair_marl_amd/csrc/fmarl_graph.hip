@@ -32,6 +32,55 @@ __global__ __launch_bounds__(256) void update_graph_kernel(const float *adj, int
     if (lane == 0) nnz[env] = base;
 }
 
+// Position of entity e of one env in the reference's entity order (multiagent/core.py:179-186: agents, landmarks,
+// obstacles, walls; a wall's p_pos is (0, axis) for 'H' and (axis, 0) for 'V', navigation_graph.py:309-324).
+__device__ __forceinline__ double2 entity_pos(const Params &p, int env, int e) {
+    if (e < p.N) return p.agent_pos[(size_t)env * p.N + e];
+    e -= p.N;
+    if (e < p.L) return p.landmark_pos[(size_t)env * p.L + e];
+    e -= p.L;
+    if (e < p.O) return p.obstacle_pos[(size_t)env * p.O + e];
+    e -= p.O;
+    const double axis = p.wall_axis[(size_t)env * p.W + e];
+    return p.wall_orient[(size_t)env * p.W + e] == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
+}
+
+// Scenario.update_graph exactly as the reference computes it (navigation_graph.py:1037-1056 on the float64
+// cached_dist_mag of multiagent/core.py:204-228, np.linalg.norm(axis=2) = sqrt(dx*dx + dy*dy)): distances from the f64
+// state, `<=` against the f64 threshold, f64 weights -- the f32 adj output cannot decide a distance within a float32
+// ulp of max_edge_dist.  One wave per env, row-major ballot + popcount compaction.  Not on the rollout's hot path
+// (the reference's only consumer is the renderer, environment.py:491-506).
+__global__ __launch_bounds__(256) void update_graph_state_kernel(Params p, int32_t *edge_index, double *edge_weight,
+                                                                 int32_t *nnz, double max_edge_dist) {
+    const int lane = threadIdx.x & 63;
+    const int env = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (env >= p.n_envs) return;   // wave-uniform
+    const int E = p.E, EE = E * E;
+    int32_t *rows = edge_index + (size_t)env * 2 * EE, *cols = rows + EE;
+    double *wts = edge_weight + (size_t)env * EE;
+    int base = 0;
+    for (int q0 = 0; q0 < EE; q0 += 64) {
+        const int q = q0 + lane;
+        double d = 0.0;
+        int r = 0, c = 0;
+        if (q < EE) {
+            r = q / E; c = q - r * E;
+            const double2 a = entity_pos(p, env, r), b = entity_pos(p, env, c);
+            const double dx = a.x - b.x, dy = a.y - b.y;
+            d = sqrt(dx * dx + dy * dy);
+        }
+        const bool on = q < EE && d <= max_edge_dist && d > 0.0;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int k = base + __popcll(m & ((1ull << lane) - 1));
+            rows[k] = r; cols[k] = c; wts[k] = d;
+        }
+        base += __popcll(m);
+    }
+    for (int k = base + lane; k < EE; k += 64) { rows[k] = -1; cols[k] = -1; wts[k] = 0.0; }
+    if (lane == 0) nnz[env] = base;
+}
+
 // Policy-side edge construction, reference onpolicy/algorithms/utils/gnn.py:307-326 processAdj + the
 // PyG batching of :243-253: per graph b (graph b uses the adj of env b / graphs_per_env -- the reference
 // feeds every agent its own copy of the same matrix), edges (r, c) with 0 < adj[r][c] < max_edge_dist

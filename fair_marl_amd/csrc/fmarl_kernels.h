@@ -35,6 +35,8 @@ void launch_lexifair_state(const Params &p, hipStream_t stream);
 __global__ void update_graph_kernel(const float *adj, int32_t *edge_index, float *edge_weight, int32_t *nnz,
                                     int n_envs, int E, float max_edge_dist);
 
+__global__ void update_graph_state_kernel(Params p, int32_t *edge_index, double *edge_weight, int32_t *nnz, double max_edge_dist);
+
 __global__ void info_mean_kernel(const float *info, double *out, int n_envs, int N, double unreached_time);
 __global__ void edge_count_kernel(const float *adj, int32_t *nnz, int n_envs, int E, float thr, int strict);
 __global__ void edge_fill_kernel(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr,

@@ -114,9 +114,12 @@ struct Handle {
     Params base;        // everything but the state pointers
     size_t lds_bytes;
     int grid;
+    bool captured;      // a step of this handle was captured into a hipGraph: replays advance the device's step counters
+                        // behind the host's back, so the host-side lockstep shortcut is off for good
     bool lockstep;      // all envs share one step counter, known on the host
     int host_step;
     bool episode_started;   // the last reset / step call may have started episodes (host-side knowledge, conservative)
+    int device;         // HIP device the handle was created on (side stream, events, kernel attributes live there)
     bool async;         // FMARL_FLAG_ASYNC_RESET: next episode staged on `side`
     bool stage_dirty;   // staged data may be stale (caller wrote the state): next reset goes the synchronous way
     hipStream_t side;
@@ -124,6 +127,17 @@ struct Handle {
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int ev_cap, ev_n;
+};
+
+// Entry points that take a handle run on the handle's device whatever the caller's current device is
+// (a handle created while cuda:1 was current keeps working from a thread whose current device is cuda:0).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const Handle *h) {
+        int cur = -1;
+        if (h && hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
 int align16(int x) { return (x + 15) / 16 * 16; }
@@ -243,6 +257,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     Handle *h = new (std::nothrow) Handle();
     if (!h) return fail(FMARL_EINVAL, "fmarl_create: out of host memory");
     h->cfg = *cfg;
+    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: no current HIP device"); }
     make_layout(cfg, &h->layout);
     Params &p = h->base;
     memset(&p, 0, sizeof p);
@@ -356,7 +371,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
             return fail(FMARL_EHIP, "fmarl_create: cannot create the staging stream / events");
         }
     }
-    h->lockstep = false; h->host_step = 0; h->episode_started = false;
+    h->lockstep = false; h->host_step = 0; h->episode_started = false; h->captured = false;
     h->ev = nullptr; h->ev_cap = h->ev_n = 0;
     *handle = h;
     return FMARL_OK;
@@ -370,6 +385,7 @@ static void drop_events(Handle *h) {
 
 int fmarl_destroy(void *handle) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (h) {
         drop_events(h);
         if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
@@ -382,6 +398,7 @@ int fmarl_destroy(void *handle) {
 
 int fmarl_profile_enable(void *handle, int capacity) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || capacity < 0) return fail(FMARL_EINVAL, "fmarl_profile_enable: bad argument");
     drop_events(h);
     if (capacity == 0) return FMARL_OK;
@@ -394,6 +411,7 @@ int fmarl_profile_enable(void *handle, int capacity) {
 
 int fmarl_profile_read(void *handle, float *ms, int max_count, int *count) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || !ms || !count) return fail(FMARL_EINVAL, "fmarl_profile_read: bad argument");
     int n = h->ev_n < max_count ? h->ev_n : max_count;
     for (int i = 0; i < n; ++i) HIP_OK(hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
@@ -404,21 +422,23 @@ int fmarl_profile_read(void *handle, float *ms, int max_count, int *count) {
 
 int fmarl_init_state(void *handle, void *state, void *stream) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_init_state: null argument");
     hipStream_t st = (hipStream_t)stream;
     HIP_OK(hipMemsetAsync(state, 0, h->layout.total, st));
     int rc = launch_reset(h, state, kResetInit, nullptr, nullptr, st);
-    h->lockstep = h->cfg.scenario != FMARL_SCENARIO_FAIRNAV;   // fairnav episodes end early, env by env
+    h->lockstep = !h->captured && h->cfg.scenario != FMARL_SCENARIO_FAIRNAV;   // fairnav episodes end early, env by env
     h->host_step = 0;
     return rc;
 }
 
 int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlOutputs *outs, void *stream) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_reset: null argument");
     if (outs && !outputs_aligned(h->base, outs)) return fail(FMARL_EINVAL, "fmarl_reset: node_obs / adj must be 16-byte aligned for this shape");
     int rc = launch_reset(h, state, env_mask ? kResetMask : kResetAll, env_mask, outs, (hipStream_t)stream);
-    if (env_mask || h->cfg.scenario == FMARL_SCENARIO_FAIRNAV) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
+    if (env_mask || h->captured || h->cfg.scenario == FMARL_SCENARIO_FAIRNAV) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
     h->episode_started = true;
     return rc;
 }
@@ -426,16 +446,22 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlO
 int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
                const FmarlOutputs *outs, int auto_reset, void *stream) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || !state || !outs) return fail(FMARL_EINVAL, "fmarl_step: null argument");
     if ((action_idx == nullptr) == (action_vec == nullptr))
         return fail(FMARL_EINVAL, "fmarl_step: pass exactly one of action_idx / action_vec");
     hipStream_t st = (hipStream_t)stream;
     Params p = bind(h, state);
     if (!outputs_aligned(p, outs)) return fail(FMARL_EINVAL, "fmarl_step: node_obs / adj must be 16-byte aligned for this shape");
-    if (h->async) {   // the staging stream and its events are not part of the caller's graph
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(FMARL_EINVAL, "fmarl_step: stream capture needs a handle created without FMARL_FLAG_ASYNC_RESET");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        // the staging stream and its events are not part of the caller's graph
+        if (h->async) return fail(FMARL_EINVAL, "fmarl_step: stream capture needs a handle created without FMARL_FLAG_ASYNC_RESET");
+        // Nothing runs during capture and a replay can start at any phase of an episode, any number of times: the
+        // reset-or-not decision must not be baked from the host's mirror of the step counter.  Every captured step
+        // enqueues the auto-reset launches, which test cur_step per env on the device.
+        h->captured = true;
+        h->lockstep = false;
     }
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
@@ -466,6 +492,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
 
 static int copy_field(Handle *h, void *state, int field, void *host_or_dev, bool to_state, hipStream_t st, const char *who) {
     if (!h || !state || !host_or_dev) return fail(FMARL_EINVAL, "%s: null argument", who);
+    DeviceGuard on_device(h);
     if (field < 0 || field >= FMARL_NUM_FIELDS) return fail(FMARL_EINVAL, "%s: bad field id", who);
     const size_t bytes = h->layout.count[field] * (h->layout.dtype[field] == FMARL_DTYPE_F64 ? 8 : 4);
     if (bytes == 0) return FMARL_OK;
@@ -523,6 +550,18 @@ int fmarl_update_graph(const float *adj, int32_t *edge_index, float *edge_weight
     return FMARL_OK;
 }
 
+int fmarl_update_graph_state(void *handle, const void *state, int32_t *edge_index, double *edge_weight, int32_t *nnz,
+                             void *stream) {
+    Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
+    if (!h || !state || !edge_index || !edge_weight || !nnz) return fail(FMARL_EINVAL, "fmarl_update_graph_state: null argument");
+    Params p = bind(h, (void *)state);
+    hipLaunchKernelGGL(update_graph_state_kernel, dim3((p.n_envs + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, edge_index,
+                       edge_weight, nnz, h->cfg.max_edge_dist);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
 int fmarl_edge_count(const float *adj, int32_t *nnz, int n_envs, int num_entities, double max_edge_dist, int strict,
                      void *stream) {
     if (!adj || !nnz || n_envs < 1 || num_entities < 1) return fail(FMARL_EINVAL, "fmarl_edge_count: bad argument");
@@ -563,6 +602,7 @@ int fmarl_episode_started(void *handle) {
 
 int fmarl_pack_episode(void *handle, const void *state, void *record, void *stream) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || !state || !record) return fail(FMARL_EINVAL, "fmarl_pack_episode: null argument");
     if (h->cfg.scenario != FMARL_SCENARIO_NAVIGATION_GRAPH)
         return fail(FMARL_EINVAL, "fmarl_pack_episode: only navigation_graph has a rebuildable record");
@@ -577,6 +617,7 @@ int fmarl_pack_episode(void *handle, const void *state, void *record, void *stre
 int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int n_envs, float *node_obs, float *adj,
                         void *stream) {
     Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
     if (!h || !obs || !record || n_envs < 1 || (!node_obs && !adj)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: bad argument");
     if (h->cfg.scenario != FMARL_SCENARIO_NAVIGATION_GRAPH)
         return fail(FMARL_EINVAL, "fmarl_rebuild_graph: only navigation_graph has a rebuildable record");

@@ -39,7 +39,8 @@ class RolloutEngine:
         # current one runs; same results, the reset leaves the critical path (see include/fmarl.h)
         self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset, async_reset=async_reset)
         self.handle = C.c_void_p()
-        _lib.check(self.lib.fmarl_create(C.byref(self.c), C.byref(self.handle)), 'fmarl_create')
+        with torch.cuda.device(self.device):   # the handle's side stream, events and kernel attributes belong to THIS device
+            _lib.check(self.lib.fmarl_create(C.byref(self.c), C.byref(self.handle)), 'fmarl_create')
         nbytes = self.lib.fmarl_state_bytes(C.byref(self.c))
         n, N, E = self.n_envs, cfg.N, cfg.E
         D, F = cfg.obs_dim, cfg.node_feat
@@ -72,7 +73,8 @@ class RolloutEngine:
             esz = 8 if dt.value == _lib.DTYPE_F64 else 4
             view = self.state[off.value: off.value + cnt.value * esz].view(_TORCH_DT[dt.value])
             self._fields[name] = view.view(shapes[name])
-        _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
 
     def _tune_output_placement(self, candidates, launches=5):
         """Pick the fastest (node_obs allocation, adj allocation) pair out of a few.  How fast the store stream of the
@@ -273,8 +275,21 @@ class RolloutEngine:
         return perm
 
     def update_graph(self, adj_env=None):
-        """Scenario.update_graph: (edge_index (n, 2, E*E) padded with -1, edge_weight (n, E*E), nnz (n))."""
-        adj = self.adj_env if adj_env is None else torch.as_tensor(adj_env).to(self.device, torch.float32).contiguous()
+        """Scenario.update_graph (navigation_graph.py:1037-1056): (edge_index int32 (n, 2, E*E) padded with -1,
+        edge_weight (n, E*E), nnz (n)).  Without an argument the edges come from the CURRENT world state exactly as the
+        reference computes them -- float64 distances, ``<=`` in float64, float64 weights (call it where
+        MultiAgentGraphEnv.step does: before the step).  With a float32 ``adj_env`` (n, E, E) (e.g. a stored rollout
+        slot) the same rule is applied to that matrix in float32."""
+        if adj_env is None:
+            n, E = self.n_envs, self.cfg.E
+            ei = torch.empty(n, 2, E * E, dtype=torch.int32, device=self.device)
+            ew = torch.empty(n, E * E, dtype=torch.float64, device=self.device)
+            nnz = torch.empty(n, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.fmarl_update_graph_state(self.handle, self.state.data_ptr(), ei.data_ptr(), ew.data_ptr(),
+                                                             nnz.data_ptr(), self._stream()), 'fmarl_update_graph_state')
+            return ei, ew, nnz
+        adj = torch.as_tensor(adj_env).to(self.device, torch.float32).contiguous()
         n, E = adj.shape[0], adj.shape[1]
         ei = torch.empty(n, 2, E * E, dtype=torch.int32, device=self.device)
         ew = torch.empty(n, E * E, dtype=torch.float32, device=self.device)
@@ -309,26 +324,67 @@ class RolloutEngine:
                                                     self._stream()), 'fmarl_edge_fill')
         return ei, ea, offsets
 
-    def process_infos(self, dt=0.1):
-        """Episode metrics as the reference logs them (onpolicy/runner/shared/base_runner.py:197-306
-        process_infos + log_env): dict 'agent<i>/<name>' -> mean over the envs of the last step's info,
-        with Time_req_to_goal == -1 counted as episode_length * dt.  Reduced on the device."""
+    # name of every info key in env_infos, in the order process_infos fills the dict (base_runner.py:245-275)
+    _ENV_INFO_NAMES = (('individual_reward', 'individual_rewards'), ('Time_req_to_goal', 'time_to_goal'),
+                       ('Min_time_to_goal', 'min_time_to_goal'), ('Dist_to_goal', 'dist_to_goal'),
+                       ('Num_agent_collisions', 'num_agent_collisions'), ('Num_obst_collisions', 'num_obstacle_collisions'),
+                       ('Distance_mean', 'distance_mean'), ('Distance_variance', 'distance_variance'),
+                       ('Mean_by_variance', 'mean_variance'), ('Dists_traveled', 'dists_traveled'), ('Time_taken', 'time_taken'),
+                       ('Formation_dist', 'formation_dist'), ('Time_mean', 'time_mean'), ('Time_stddev', 'time_variance'),
+                       ('Time_mean_by_stddev', 'time_mn_by_stddev'))
+
+    def process_infos(self, dt=0.1, reduce='mean'):
+        """Episode metrics of the last step's infos, reference onpolicy/runner/shared/base_runner.py:197-276
+        ``process_infos``: dict 'agent<i>/<name>' for the 15 names of :245-258, Time_req_to_goal == -1 counted as
+        episode_length * dt (:212-215).  ``reduce='mean'`` gives what ``log_env`` (:291-306) logs, the mean over the
+        envs, reduced on the device (names whose key the scenario does not emit are left out, like the reference's
+        ``len(v) > 0`` test); ``reduce=None`` gives the reference's per-env lists as float64 device tensors (n,)
+        (empty for names the scenario does not emit)."""
         from .infos import key_map
         if self.outs.info_planes is None:
             raise RuntimeError('engine was created with emit_info=False')
         N = self.cfg.N
+        slots = dict(key_map(self.cfg.scenario_name))
+        if reduce is None:
+            planes = self.outs.info_planes.to(torch.float64)          # (K, n, N)
+            out = {}
+            for a in range(N):
+                for key, name in self._ENV_INFO_NAMES:
+                    if key not in slots:
+                        out['agent%d/%s' % (a, name)] = planes.new_empty(0)
+                        continue
+                    v = planes[slots[key], :, a]
+                    if key == 'Time_req_to_goal':
+                        v = torch.where(v == -1.0, torch.full_like(v, self.cfg.episode_length * dt), v)
+                    out['agent%d/%s' % (a, name)] = v
+            return out
         means = torch.empty(_lib.INFO_WIDTH, N, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fmarl_info_means(self.outs.info_planes.data_ptr(), means.data_ptr(), self.n_envs, N,
                                                  float(self.cfg.episode_length * dt), self._stream()), 'fmarl_info_means')
         m = means.cpu().numpy()
-        names = {'individual_reward': 'individual_rewards', 'Time_req_to_goal': 'time_to_goal', 'Dist_to_goal': 'dist_to_goal',
-                 'Num_agent_collisions': 'num_agent_collisions', 'Num_obst_collisions': 'num_obstacle_collisions',
-                 'Min_time_to_goal': 'min_time_to_goal', 'Distance_mean': 'distance_mean', 'Distance_variance': 'distance_variance',
-                 'Mean_by_variance': 'mean_variance', 'Dists_traveled': 'dists_traveled', 'Time_taken': 'time_taken',
-                 'Formation_dist': 'formation_dist', 'Time_mean': 'time_mean', 'Time_stddev': 'time_variance',
-                 'Time_mean_by_stddev': 'time_mn_by_stddev'}
-        return {'agent%d/%s' % (a, names[k]): float(m[slot, a]) for a in range(N) for k, slot in key_map(self.cfg.scenario_name)}
+        return {'agent%d/%s' % (a, name): float(m[slots[key], a]) for a in range(N) for key, name in self._ENV_INFO_NAMES
+                if key in slots}
+
+    _METRIC_KEYS = {'get_fairness_metric': 'Mean_by_variance', 'get_dist_mean': 'Distance_mean', 'get_dist_std': 'Distance_variance',
+                    'get_time_fairness': 'Time_mean_by_stddev', 'get_time_mean': 'Time_mean', 'get_time_std': 'Time_stddev'}
+
+    def _metric(self, reader):
+        """The ``get_*`` readers of base_runner.py:308-420: per agent the value of the FIRST env (``v[0]``) of one
+        env_infos name.  A name the scenario does not emit raises IndexError, as ``v[0]`` on the reference's empty list."""
+        from .infos import key_map
+        slots = dict(key_map(self.cfg.scenario_name))
+        key = self._METRIC_KEYS[reader]
+        if key not in slots:
+            raise IndexError('%s: scenario %s emits no %r' % (reader, self.cfg.scenario_name, key))
+        return [float(x) for x in self.outs.info_planes[slots[key], 0, :].to(torch.float64).cpu()]
+
+    def get_fairness_metric(self): return self._metric('get_fairness_metric')
+    def get_dist_mean(self): return self._metric('get_dist_mean')
+    def get_dist_std(self): return self._metric('get_dist_std')
+    def get_time_fairness(self): return self._metric('get_time_fairness')
+    def get_time_mean(self): return self._metric('get_time_mean')
+    def get_time_std(self): return self._metric('get_time_std')
 
     # ------------------------------------------------------------------ cross-GPU hand-off of the graph observation
     @property
@@ -398,19 +454,22 @@ class RolloutEngine:
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, capacity):
         """Record a hipEvent pair around each of the next ``capacity`` step-kernel launches (0 = off)."""
-        _lib.check(self.lib.fmarl_profile_enable(self.handle, int(capacity)), 'fmarl_profile_enable')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_profile_enable(self.handle, int(capacity)), 'fmarl_profile_enable')
         self._prof_cap = int(capacity)
 
     def profile_read(self):
         """Per-launch step-kernel durations [ms] since profile_enable / the last read (stream must be idle)."""
         buf = (C.c_float * max(self._prof_cap, 1))()
         cnt = C.c_int()
-        _lib.check(self.lib.fmarl_profile_read(self.handle, buf, self._prof_cap, C.byref(cnt)), 'fmarl_profile_read')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_profile_read(self.handle, buf, self._prof_cap, C.byref(cnt)), 'fmarl_profile_read')
         return [buf[i] for i in range(cnt.value)]
 
     def close(self):
         if getattr(self, 'handle', None) is not None and self.handle.value:
-            self.lib.fmarl_destroy(self.handle)
+            with torch.cuda.device(self.device):
+                self.lib.fmarl_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

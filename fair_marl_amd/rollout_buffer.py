@@ -81,9 +81,41 @@ class DeviceRolloutBuffer(object):
         self.step = t + 1
         return self._sets[t + 1]
 
+    def capture(self, action_tape):
+        """Capture ``insert_step(action_tape[t])`` for every t -- the step kernels writing their slots AND the masks /
+        active_masks of the runner's insert -- into one hipGraph.  ``replay()`` on the returned object runs the rollout
+        with one launch and leaves ``step`` where eager inserts would.  ``action_tape`` (T', n, N) int32 or (T', n, N, 5)
+        float32 is read at replay time; T' <= T - step.  Needs an engine with ``async_reset=False``."""
+        eng, dev = self.engine, self.engine.device
+        tape = action_tape.to(dev)
+        start = self.step
+        if start + tape.shape[0] > self.T:
+            raise RuntimeError('tape of %d steps does not fit behind step %d of %d' % (tape.shape[0], start, self.T))
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.device(dev), torch.cuda.graph(graph):
+            for t in range(tape.shape[0]):
+                self.insert_step(tape[t])
+        self.step = start
+        return _CapturedInserts(self, graph, tape, start)
+
     def after_update(self):
         """graph_buffer.py after_update: the last slot becomes the first of the next rollout."""
         for name in ('obs', 'node_obs', 'adj_env', 'masks', 'active_masks'):
             buf = getattr(self, name)
             buf[0].copy_(buf[-1])
         self.step = 0
+
+
+class _CapturedInserts(object):
+    """A captured run of ``insert_step`` calls (DeviceRolloutBuffer.capture)."""
+
+    def __init__(self, buf, graph, tape, start):
+        self.buf, self.graph, self.tape, self.start = buf, graph, tape, start
+
+    def replay(self):
+        if self.buf.step != self.start:
+            raise RuntimeError('captured inserts start at buffer step %d, the buffer is at %d' % (self.start, self.buf.step))
+        self.graph.replay()
+        self.buf.step = self.start + self.tape.shape[0]
+        self.buf.engine.use_outputs(self.buf._sets[self.buf.step])

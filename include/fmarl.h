@@ -179,7 +179,11 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask,
  * reference's one-hot / continuous form) is non-NULL.
  * auto_reset != 0 adds the vec-env worker's behaviour (env_wrappers.py:859-865): envs whose agents
  * are all done are reset and their obs / node_obs / adj are the reset observation while
- * reward / done / info stay those of the terminal step. */
+ * reward / done / info stay those of the terminal step.
+ * hipGraph capture: the call only enqueues work on `stream`, so a run of steps can be captured (handles without
+ * FMARL_FLAG_ASYNC_RESET).  A captured step always enqueues the auto-reset launches, which test every env's step
+ * counter on the device -- a graph may hold any number of steps and be replayed from any phase of an episode; the
+ * handle stops mirroring the step counter on the host from then on. */
 int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
                const FmarlOutputs *outs, int auto_reset, void *stream);
 
@@ -216,6 +220,14 @@ int fmarl_lexifair(const double *costs, int32_t *perm, int n_envs, int num_agent
  * edge_weight f32 (n, E*E), nnz i32 (n). */
 int fmarl_update_graph(const float *adj, int32_t *edge_index, float *edge_weight, int32_t *nnz,
                        int n_envs, int num_entities, double max_edge_dist, void *stream);
+
+/* The same from the world state, exactly as the reference computes it: float64 distances of the entities
+ * (multiagent/core.py:204-228, np.linalg.norm), `<=` against the float64 cfg.max_edge_dist, float64 weights.  The
+ * float32 adj output cannot decide a distance within a float32 ulp of the threshold; this entry point can.  Call it
+ * where MultiAgentGraphEnv.step does (environment.py:817-818: before the step).
+ * -> edge_index i32 (n, 2, E*E) (padded with -1), edge_weight f64 (n, E*E), nnz i32 (n). */
+int fmarl_update_graph_state(void *handle, const void *state, int32_t *edge_index, double *edge_weight, int32_t *nnz,
+                             void *stream);
 
 /* Policy-side edge construction, onpolicy/algorithms/utils/gnn.py:307-326 processAdj (strict != 0:
  * 0 < adj < max_edge_dist; strict == 0: the <= of update_graph) with the node-id offsets of the PyG batch

@@ -406,7 +406,7 @@ def test_lexifair_cost_matrix_update_graph():
     cfg = fm.EnvConfig(num_agents=6, num_landmarks=6, num_obstacles=3, num_walls=1)
     eng = fm.RolloutEngine(cfg, 9, device=DEV, seed=3)
     eng.reset()
-    ei, ew, nnz = eng.update_graph()
+    ei, ew, nnz = eng.update_graph(adj_env=eng.adj_env)   # the float32 rule on a stored matrix
     adj = eng.adj_env.cpu().numpy()
     ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
     for e in range(9):
@@ -419,70 +419,62 @@ def test_lexifair_cost_matrix_update_graph():
 
 
 def test_process_adj_matches_reference_semantics():
-    """gnn.py:307-326 processAdj on the batch of (env, agent) graphs, restated with torch ops on the CPU."""
+    """gnn.py:307-326 processAdj on the batch of (env, agent) graphs vs oracle.runner_oracle.process_adj (pinned by the
+    reference's own processAdj outputs, tests/test_runner_golden.py)."""
+    from oracle import runner_oracle as ro
     cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=3, num_walls=1, max_edge_dist=0.8)
     eng = fm.RolloutEngine(cfg, 11, device=DEV, seed=8)
     eng.reset()
-    adj = eng.adj.cpu()                       # (n, N, E, E) as the policy receives it
-    batch = adj.reshape(-1, cfg.E, cfg.E)     # one graph per (env, agent)
-    mask = ((batch < cfg.max_edge_dist) * (batch > 0)).float()
-    a = batch * mask
-    idx = a.nonzero(as_tuple=True)
-    want_attr = a[idx]
-    off = idx[0] * cfg.E
-    want_index = torch.stack((off + idx[1], off + idx[2]), dim=0)
+    batch = eng.adj.cpu().numpy().reshape(-1, cfg.E, cfg.E)     # one graph per (env, agent), as the policy receives it
+    want_index, want_attr = ro.process_adj(batch, cfg.max_edge_dist)
     ei, ea, offsets = eng.process_adj(per_agent=True)
-    assert torch.equal(ei.cpu(), want_index) and torch.equal(ea.cpu(), want_attr)
-    assert offsets[-1].item() == want_attr.numel()
+    assert np.array_equal(ei.cpu().numpy(), want_index) and np.array_equal(ea.cpu().numpy(), want_attr)
+    assert offsets[-1].item() == want_attr.size
     ei1, ea1, off1 = eng.process_adj(per_agent=False)
-    assert ei1.shape[1] * cfg.N == ei.shape[1]
+    w1, a1 = ro.process_adj(eng.adj_env.cpu().numpy(), cfg.max_edge_dist)
+    assert np.array_equal(ei1.cpu().numpy(), w1) and np.array_equal(ea1.cpu().numpy(), a1)
     ei2, ea2, _ = eng.process_adj(per_agent=False, strict=False)   # update_graph's <=
     assert ei2.shape[1] >= ei1.shape[1]
 
 
 def test_device_rollout_buffer_matches_reference_insert():
-    """DeviceRolloutBuffer (GraphReplayBuffer layout, filled in place) vs the reference runner's host-side
-    insert (graph_mpe_runner.py:438-488) restated with NumPy on the outputs of a twin engine."""
+    """DeviceRolloutBuffer (GraphReplayBuffer layout, filled in place) vs oracle.runner_oracle.ReplayBuffer (pinned by
+    the reference's GraphReplayBuffer + GMPERunner.insert, tests/test_runner_golden.py) fed by a twin engine."""
+    from oracle import runner_oracle as ro
     cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=2, episode_length=6)
     n, T = 20, 6
     a_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=3)
     b_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=3)
     buf = fm.DeviceRolloutBuffer(b_eng, episode_length=T)
+    want = ro.ReplayBuffer(T, n, cfg.N, cfg.obs_dim, cfg.E, cfg.node_feat)
     obs, ids, node, adj = a_eng.reset()
+    want.warmup(obs.cpu().numpy(), ids.cpu().numpy(), node.cpu().numpy(), adj.cpu().numpy())
     buf.reset()
-    want = dict(obs=[obs.cpu().numpy()], node=[node.cpu().numpy()], adj=[adj.cpu().numpy()], rew=[], masks=[np.ones((n, 3, 1))],
-                active=[np.ones((n, 3, 1))])
     g = torch.Generator(device=DEV); g.manual_seed(0)
     for t in range(T):
         a = torch.randint(0, 5, (n, 3), device=DEV, generator=g, dtype=torch.int32)
         obs, ids, node, adj, rew, done, info = a_eng.step(a)
         buf.insert_step(a)
-        dones = done.cpu().numpy().astype(bool)
-        dones_env = np.all(dones, axis=1)
-        masks = np.ones((n, 3, 1), dtype=np.float32); masks[dones] = 0
-        active = np.ones((n, 3, 1), dtype=np.float32); active[dones] = 0; active[dones_env] = 1
-        want['obs'].append(obs.cpu().numpy()); want['node'].append(node.cpu().numpy()); want['adj'].append(adj.cpu().numpy())
-        want['rew'].append(rew.cpu().numpy()[..., None]); want['masks'].append(masks); want['active'].append(active)
-    assert np.array_equal(buf.obs.cpu().numpy(), np.stack(want['obs']))
-    assert np.array_equal(buf.node_obs.cpu().numpy(), np.stack(want['node']))
-    assert np.array_equal(buf.adj.cpu().numpy(), np.stack(want['adj']))
-    assert np.array_equal(buf.rewards.cpu().numpy(), np.stack(want['rew']))
-    assert np.array_equal(buf.masks.cpu().numpy(), np.stack(want['masks']))
-    assert np.array_equal(buf.active_masks.cpu().numpy(), np.stack(want['active']))
-    so = buf.share_obs.cpu().numpy()   # graph_mpe_runner.py:470-478
-    o = np.stack(want['obs'])
-    assert np.array_equal(so, np.repeat(o.reshape(T + 1, n, 1, -1), 3, axis=2))
+        want.insert(obs.cpu().numpy(), ids.cpu().numpy(), node.cpu().numpy(), adj.cpu().numpy(), rew.cpu().numpy(),
+                    done.cpu().numpy().astype(bool))
+    for k in ('obs', 'node_obs', 'adj', 'share_obs', 'rewards', 'masks', 'active_masks', 'agent_id', 'share_agent_id'):
+        assert np.array_equal(getattr(buf, k).cpu().numpy(), getattr(want, k)), k
     assert buf.obs.shape == (T + 1, n, 3, 7) and buf.rewards.shape == (T, n, 3, 1) and buf.adj.shape == (T + 1, n, 3, 8, 8)
     assert (buf.masks[-1] == 0).all()   # the last step ended the episode
     buf.after_update()
-    assert torch.equal(buf.obs[0], buf.obs[-1]) and buf.step == 0
+    want.after_update()
+    for k in ('obs', 'node_obs', 'adj', 'share_obs', 'masks', 'active_masks'):
+        assert np.array_equal(getattr(buf, k)[0].cpu().numpy(), getattr(want, k)[0]), k
+    assert buf.step == 0
     with pytest.raises(RuntimeError):
         for _ in range(T + 1):
             buf.insert_step(a)
 
 
 def test_process_infos_matches_reference_logging():
-    """base_runner.py:197-306 process_infos + log_env restated with NumPy on the same info records."""
+    """base_runner.py:197-306 process_infos + log_env, all names, vs oracle.runner_oracle.process_infos (pinned by the
+    reference's own process_infos outputs)."""
+    from oracle import runner_oracle as ro
     cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=2, min_dist_thresh=0.3)
     n = 300
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=2)
@@ -490,15 +482,19 @@ def test_process_infos_matches_reference_logging():
     g = torch.Generator(device=DEV); g.manual_seed(0)
     for t in range(12):
         res = eng.step(torch.randint(0, 5, (n, 4), device=DEV, generator=g, dtype=torch.int32))
-    info = res[6].cpu().numpy().astype(np.float64)    # (n, N, 14)
-    got = eng.process_infos()
-    t_req = info[..., 1].copy(); t_req[t_req == -1] = cfg.episode_length * 0.1
-    for a in range(4):
-        assert abs(got['agent%d/individual_rewards' % a] - info[:, a, 13].mean()) < 1e-9
-        assert abs(got['agent%d/time_to_goal' % a] - t_req[:, a].mean()) < 1e-9
-        assert abs(got['agent%d/mean_variance' % a] - info[:, a, 6].mean()) < 1e-6
-        assert abs(got['agent%d/num_agent_collisions' % a] - info[:, a, 2].mean()) < 1e-9
-    assert len(got) == 4 * 14 and (t_req != info[..., 1]).any()
+    info = res[6].cpu().numpy().astype(np.float64)    # (n, N, 14) in FMARL_INFO_* order == oracle INFO_KEYS order
+    want = ro.process_infos(info, no.INFO_KEYS, cfg.episode_length)
+    got, lists = eng.process_infos(), eng.process_infos(reduce=None)
+    assert list(lists) == list(want)
+    for k, v in want.items():
+        if len(v) == 0:
+            assert k not in got and lists[k].numel() == 0
+        else:
+            assert np.array_equal(lists[k].cpu().numpy(), np.array(v)), k
+            assert abs(got[k] - np.mean(v)) < 1e-9 * (1 + abs(np.mean(v))), k
+    assert len(got) == 4 * 14 and (info[..., 1] == -1).any()
+    for reader in ro.METRIC_PATTERNS:
+        assert getattr(eng, reader)() == ro.metric(want, reader)
 
 
 def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
@@ -572,6 +568,76 @@ def test_capture_rollout_fills_the_rollout_buffer_from_one_graph():
     staged.reset()
     with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='FMARL_FLAG_ASYNC_RESET'):
         staged.capture_steps(tape)
+
+
+def test_graph_of_any_length_replays_across_episode_ends():
+    """A captured run whose length is no multiple of episode_length, replayed from different phases of an episode and
+    followed by eager steps, equals eager stepping bit for bit: captured steps enqueue device-checked auto-resets, the
+    host never bakes the reset decision."""
+    cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=2, episode_length=8)
+    n, T = 64, 5
+    eager = fm.RolloutEngine(cfg, n, device=DEV, seed=6, async_reset=False)
+    graph = fm.RolloutEngine(cfg, n, device=DEV, seed=6, async_reset=False)
+    gen = torch.Generator(device=DEV); gen.manual_seed(4)
+    tape = torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32)
+    eager.reset(); graph.reset()
+    for t in range(3):   # capture in the middle of an episode
+        a = torch.randint(0, 5, (n, 3), device=DEV, generator=gen, dtype=torch.int32)
+        eager.step(a); graph.step(a)
+    g = graph.capture_steps(tape)
+    for rep in range(7):   # 35 steps: four episode ends, each at a different position inside the graph
+        tape.copy_(torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32))
+        g.replay()
+        for t in range(T):
+            eager.step(tape[t])
+        torch.cuda.synchronize()
+        sa, sb = eager.get_state(), graph.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), 'replay %d %s' % (rep, k)
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+            assert torch.equal(getattr(eager, k), getattr(graph, k)), 'replay %d %s' % (rep, k)
+    assert int(eager.get_state()['episode'].min()) >= 5
+    for t in range(11):    # eager steps after the replays still reset on time
+        a = torch.randint(0, 5, (n, 3), device=DEV, generator=gen, dtype=torch.int32)
+        ra, rb = eager.step(a), graph.step(a)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[5], rb[5]), t
+    graph.reset(); eager.reset()   # a full reset does not re-arm the host-side shortcut on a captured handle
+    g.replay()
+    for t in range(T):
+        eager.step(tape[t])
+    for t in range(6):
+        a = torch.randint(0, 5, (n, 3), device=DEV, generator=gen, dtype=torch.int32)
+        ra, rb = eager.step(a), graph.step(a)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[5], rb[5]), t
+
+
+def test_captured_inserts_fill_masks_like_eager_inserts():
+    """DeviceRolloutBuffer.capture: the graph holds the mask / active_mask ops of insert too."""
+    from fair_marl_amd.rollout_buffer import DeviceRolloutBuffer
+    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3, num_obstacles=2,
+                       min_dist_thresh=0.35, episode_length=9)
+    n, T = 90, 9
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=5, async_reset=False)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=5, async_reset=False)
+    buf_a, buf_b = DeviceRolloutBuffer(a), DeviceRolloutBuffer(b)
+    gen = torch.Generator(device=DEV); gen.manual_seed(1)
+    tape = torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32)
+    buf_a.reset(); buf_b.reset()
+    cap = buf_b.capture(tape)
+    for ep in range(3):
+        tape.copy_(torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32))
+        for t in range(T):
+            buf_a.insert_step(tape[t])
+        cap.replay()
+        torch.cuda.synchronize()
+        assert buf_b.step == buf_a.step == T
+        for name in ('obs', 'node_obs', 'adj_env', 'rewards', 'dones', 'masks', 'active_masks'):
+            assert torch.equal(getattr(buf_a, name), getattr(buf_b, name)), 'episode %d %s' % (ep, name)
+        buf_a.after_update(); buf_b.after_update()
+    assert (buf_a.masks == 0).any() and (buf_a.active_masks != buf_a.masks).any()   # per-agent dones of this scenario
+    with pytest.raises(RuntimeError, match='start at buffer step'):
+        buf_b.step = 2
+        cap.replay()
 
 
 def test_misaligned_output_buffers():
