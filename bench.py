@@ -55,6 +55,16 @@ CONFIGS = {
 }
 
 
+# The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
+# can be imported (it cannot travel to the GPU box): quoted beside cpu_baseline, never a target.
+_REF_HW = '8 Xeon 2.1 GHz cores, build container (Gurobi replaced by the pure-Python lexifair solver)'
+REFERENCE_CPU = {
+    'cfg3': dict(value=1662.0, unit='agent-steps/s', cores=8, hardware=_REF_HW, source='BASELINE.md section 2: GraphSubprocVecEnv x 8, N=32, O=8'),
+    'cfg2': dict(value=5142.0, unit='agent-steps/s', cores=8, hardware=_REF_HW, source='BASELINE.md section 2: GraphSubprocVecEnv x 8, N=3'),
+    'cfg4': dict(value=1716.0, unit='agent-steps/s', cores=8, hardware=_REF_HW, source='BASELINE.md section 2: fair_graph_formation, GraphSubprocVecEnv x 8, N=10'),
+}
+
+
 def algorithmic_bytes(cfg, emit=True):
     """bytes per agent-step, B = 4 [A + S + D + R + F E + E^2/N + C/N]."""
     N, E = cfg.N, cfg.E
@@ -132,6 +142,8 @@ def main():
                     'the fastest pair of a few (RolloutEngine tune_placement)')
     ap.add_argument('--graph', action='store_true', help='N=1: capture one episode of steps in a hipGraph and replay it '
                     '(launch-bound small batches, e.g. --config cfg2; implies --sync-reset; --steps is rounded to whole episodes)')
+    ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
+                    'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
                          'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
@@ -171,6 +183,13 @@ def main():
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group('gloo')
+    elif args.rccl_selftest:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=device)
+        args.record_path = True
 
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
@@ -187,7 +206,7 @@ def main():
     depth = 2
     # navigation_graph: the learner rebuilds node_obs / adj from obs + a record gathered once per episode
     episodes = cfg.scenario_name == 'navigation_graph'
-    tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth,
+    tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
                           episode_words=eng.episode_record_words if episodes else 0) if gather else None
     if gather:
         sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done) for r in tg.records]
@@ -200,6 +219,8 @@ def main():
     tape_len = 32
     tape = torch.randint(0, 5, (tape_len, n_envs, cfg.N), device=device, generator=g, dtype=torch.int32)
 
+    inject_error = bool(os.environ.get('FMARL_BENCH_INJECT_GATHER_ERROR'))   # test hook: tests/test_hip_parity.py
+
     def run(first, count):   # reads `gather` / `sets` at call time
         for t in range(first, first + count):
             if gather:
@@ -207,6 +228,8 @@ def main():
                 eng.use_outputs(sets[t % depth])
             eng.step(tape[t % tape_len], auto_reset=True)
             if gather:
+                if inject_error and t == 1 and rank == world - 1:
+                    raise RuntimeError('injected gather error (FMARL_BENCH_INJECT_GATHER_ERROR)')
                 tg.submit(t)
                 if episodes and eng.episode_started:   # same steps on every rank (lockstep episodes)
                     eng.pack_episode(out=tg.episode_record())
@@ -233,16 +256,10 @@ def main():
     try:
         run(0, W)
         torch.cuda.synchronize(device)
-    except RuntimeError as exc:   # a collective that cannot run here must not cost the whole measurement
-        if not gather:
-            raise
-        print('bench.py: trajectory gather failed (%s); continuing without the exchange' % exc, file=sys.stderr)
-        gather = False
-        sets = [eng.outs]
-        eng.use_outputs(eng.outs)
-        eng.reset()
-        run(0, W)
-        torch.cuda.synchronize(device)
+    except RuntimeError as exc:
+        # A trajectory exchange that cannot run is a FAILED multi-GPU measurement, never a number without the exchange.
+        print('bench.py: rank %d: rollout / trajectory gather failed: %s' % (rank, exc), file=sys.stderr, flush=True)
+        sys.exit(1)
     if not args.graph:
         eng.profile_enable(K)
     if world > 1:
@@ -255,10 +272,22 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    ranks_seen = 1
+    if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        ones = torch.ones(1, dtype=torch.int32, device=device)   # every rank adds itself: the collective really spans the job
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            print('bench.py: all_reduce saw %d ranks, expected %d' % (ranks_seen, world), file=sys.stderr, flush=True)
+            sys.exit(1)
+        if gather and rank == 0:   # the last gathered step really holds every rank's rows (rank r's envs start at r * n_envs)
+            got = tg.gathered(W + K - 1)
+            if len(got) != world or any(tuple(o.shape) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _ in got):
+                print('bench.py: gathered record has the wrong shape', file=sys.stderr, flush=True)
+                sys.exit(1)
     kernel_ms = kernel_ms_eager if args.graph else eng.profile_read()
 
     if rank == 0:
@@ -277,7 +306,8 @@ def main():
                 traffic = json.load(f).get(args.config, {}).get('hbm_bytes_per_launch')
         out = {
             'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), %s random-action rollout' % cfg.scenario_name,
-            'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'n_ranks_seen': ranks_seen,
+            'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': spec['workload'], 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
@@ -292,20 +322,26 @@ def main():
                                             % (len(eng.placement_ms), len(eng.placement_ms[0]), min(map(min, eng.placement_ms)),
                                                eng.placement_ms[0][0], max(map(max, eng.placement_ms)))
                                             if eng.placement_ms else 'first allocations'),
-                       'exchange': (('RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)') + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
+                       'exchange': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
+                                     else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim)
                                     + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'
                                        % (4 * eng.episode_record_words) if episodes else '')) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}.get(cfg.scenario_name, 'step_kernel'),
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier '
+                                            'run of this command, replayed here, not measured in this run') if traffic is not None else None,
+                         'kernel': {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}.get(cfg.scenario_name, 'step_kernel'),
                          'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
         }
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        if args.config in REFERENCE_CPU:
+            out['reference_cpu'] = REFERENCE_CPU[args.config]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

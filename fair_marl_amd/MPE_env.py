@@ -41,4 +41,10 @@ def GraphMPEEnv(args):
 
 
 def MPEEnv(args):
+    # MultiAgentPPOEnv.step (multiagent/environment.py:675-704) never calls graph_observation.  In navigation_graph that
+    # call has no side effect, so the same kernels serve with the graph emission off; in the two formation scenarios it
+    # mutates the occupancy flags the next observation reads, so their non-graph form is a different environment.
+    if args.scenario_name != 'navigation_graph':
+        raise NotImplementedError('MPEEnv (non-graph) is built for navigation_graph only; %s changes behaviour without '
+                                  'its graph_observation calls' % args.scenario_name)
     return EnvSpec(args, graph=False)

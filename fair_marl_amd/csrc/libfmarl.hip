@@ -135,7 +135,7 @@ struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(const Handle *h) {
         int cur = -1;
-        if (h && hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess) prev = cur;
+        if (h && h->device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != h->device && hipSetDevice(h->device) == hipSuccess) prev = cur;
     }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
@@ -257,7 +257,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     Handle *h = new (std::nothrow) Handle();
     if (!h) return fail(FMARL_EINVAL, "fmarl_create: out of host memory");
     h->cfg = *cfg;
-    if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: no current HIP device"); }
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;   // no GPU here: the handle still describes the layout
     make_layout(cfg, &h->layout);
     Params &p = h->base;
     memset(&p, 0, sizeof p);

@@ -14,6 +14,7 @@ There are no worker processes: every env lives in one ``RolloutEngine`` on one G
 throughput work use the engine directly (``venv.engine``): these wrappers copy every output to
 the host each step, which only makes sense for small ``n_rollout_threads``.
 """
+import warnings
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -73,6 +74,18 @@ class _EngineVecEnv(ShareVecEnv):
         spec = specs[0]
         self.spec = spec
         seed = spec.seed_value if spec.seed_value is not None else 1
+        # The reference seeds worker r with seed + 1000 r (onpolicy/scripts/train_mpe.py:31; eval: 50000 seed + 10000 r,
+        # :56) and every worker owns a NumPy stream.  Here env r draws from the counter-based stream (seed of env 0, r):
+        # one experiment seed plus the rank.  Seeds in such an arithmetic progression lose nothing; anything else
+        # cannot be honoured per env.
+        seeds = [s.seed_value for s in specs]
+        if any(v is not None for v in seeds):
+            filled = [1 if v is None else v for v in seeds]
+            steps = {b - a for a, b in zip(filled, filled[1:])}
+            if len(steps) > 1:
+                warnings.warn('fair_marl_amd: per-env seeds %s are not of the form seed + r * const; env r draws from the '
+                              'stream (seed=%d, env index r) -- only the first env\'s seed is used' % (filled[:4] + ['...'] if len(filled) > 4 else filled, seed),
+                              UserWarning, stacklevel=3)
         self.engine = RolloutEngine(spec.cfg, len(specs), device=device, seed=seed, emit_graph=emit_graph)
         ShareVecEnv.__init__(self, len(specs), spec.observation_space, spec.share_observation_space, spec.action_space)
         self.node_observation_space = spec.node_observation_space
@@ -119,6 +132,27 @@ class _EngineVecEnv(ShareVecEnv):
             o += t.numel()
         return out
 
+    # beyond this many (env, agent) dicts per step the infos stay a lazy view (65 536 x 32 dicts per step cannot be built)
+    EAGER_INFOS = 4096
+
+    def _infos(self, records, as_array):
+        """infos in the reference's own types while that is affordable: GraphSubprocVecEnv / SubprocVecEnv return a tuple
+        over envs of lists of per-agent dicts (env_wrappers.py:992, :274), the Dummy variants ``np.array`` of the same
+        (:916, :699: an object array (n, N)).  Large batches get ``LazyInfos``, which offers the access pattern the runner
+        uses (base_runner.py:208-243: iterate envs, index the agent, ``.keys()`` / ``[key]``)."""
+        lazy = LazyInfos(records, self.spec.cfg.scenario_name)
+        n, N = records.shape[0], records.shape[1]
+        if n * N > self.EAGER_INFOS:
+            return lazy
+        dicts = [[lazy[e][a] for a in range(N)] for e in range(n)]
+        if not as_array:
+            return tuple(dicts)
+        arr = np.empty((n, N), dtype=object)
+        for e in range(n):
+            for a in range(N):
+                arr[e, a] = dicts[e][a]
+        return arr
+
     def _agent_ids(self):
         n, N = self.engine.n_envs, self.spec.cfg.N
         return np.broadcast_to(np.arange(N, dtype=np.int64).reshape(1, N, 1), (n, N, 1)).copy()
@@ -132,6 +166,7 @@ class _EngineVecEnv(ShareVecEnv):
 
 class GraphSubprocVecEnv(_EngineVecEnv):
     """reference env_wrappers.py:951-1026 (spaces argument accepted and ignored like the reference)."""
+    _infos_as_array = False
 
     def __init__(self, env_fns, spaces=None, device='cuda:0'):
         _EngineVecEnv.__init__(self, env_fns, device)
@@ -139,7 +174,7 @@ class GraphSubprocVecEnv(_EngineVecEnv):
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
         obs, node, adj, rew, done, info = self._fetch(obs, node, adj, rew, done, info)
-        return obs, self._agent_ids(), node, adj, rew, done != 0, LazyInfos(info, self.spec.cfg.scenario_name)
+        return obs, self._agent_ids(), node, adj, rew, done != 0, self._infos(info, self._infos_as_array)
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()
@@ -148,7 +183,8 @@ class GraphSubprocVecEnv(_EngineVecEnv):
 
 
 class GraphDummyVecEnv(GraphSubprocVecEnv):
-    """reference env_wrappers.py:895-948: same data plus ``reset_count`` as 8th item."""
+    """reference env_wrappers.py:895-948: same data plus ``reset_count`` as 8th item; infos as an object array."""
+    _infos_as_array = True
 
     def __init__(self, env_fns, device='cuda:0'):
         _EngineVecEnv.__init__(self, env_fns, device)
@@ -161,6 +197,7 @@ class GraphDummyVecEnv(GraphSubprocVecEnv):
 
 class SubprocVecEnv(_EngineVecEnv):
     """reference env_wrappers.py:242-307 (env_name == 'MPE': graph outputs dropped)."""
+    _infos_as_array = False
 
     def __init__(self, env_fns, spaces=None, device='cuda:0'):
         _EngineVecEnv.__init__(self, env_fns, device, emit_graph=False)
@@ -168,7 +205,7 @@ class SubprocVecEnv(_EngineVecEnv):
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
         obs, rew, done, info = self._fetch(obs, rew, done, info)
-        return obs, rew, done != 0, LazyInfos(info, self.spec.cfg.scenario_name)
+        return obs, rew, done != 0, self._infos(info, self._infos_as_array)
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()
@@ -177,6 +214,7 @@ class SubprocVecEnv(_EngineVecEnv):
 
 class DummyVecEnv(SubprocVecEnv):
     """reference env_wrappers.py:686-729"""
+    _infos_as_array = True
 
     def __init__(self, env_fns, device='cuda:0'):
         _EngineVecEnv.__init__(self, env_fns, device, emit_graph=False)

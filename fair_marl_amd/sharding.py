@@ -59,20 +59,23 @@ class TrajectoryGather(object):
     All ranks must use the same n_envs per rank (equal shards) -- gather needs equal sizes.
     """
 
-    def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0):
+    def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0,
+                 force_collective=False):
         self.group, self.dst, self.depth = group, dst, depth
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # force_collective: issue the gathers even in a group of ONE rank (the RCCL path on a one-GPU box)
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.records = [StepRecord(n_envs, num_agents, obs_dim, device) for _ in range(depth)]
         self.pending = [None] * depth
         self.recv = None
-        if self.world > 1 and self.rank == dst:
+        if self.collective and self.rank == dst:
             self.recv = [[torch.zeros_like(r.flat) for _ in range(self.world)] for r in self.records]
         # episode records (int32 words per env), two in rotation: the one of the running episode stays readable
         # on the learner while the next one is gathered
         self.ep_send = [torch.zeros(int(n_envs), int(episode_words), dtype=torch.int32, device=device) for _ in range(2)]
         self.ep_recv, self.ep_pending, self.ep_count = None, [None, None], 0
-        if self.world > 1 and self.rank == dst:
+        if self.collective and self.rank == dst:
             self.ep_recv = [[torch.zeros_like(b) for _ in range(self.world)] for b in self.ep_send]
 
     def record(self, t):
@@ -83,7 +86,9 @@ class TrajectoryGather(object):
         return self.records[k]
 
     def submit(self, t):
-        if self.world == 1:
+        """Start the gather of step t.  It overwrites the learner's receive buffer of step t - depth: read that step
+        (``gathered(t - depth)``) before submitting this one."""
+        if not self.collective:
             return
         k = t % self.depth
         self.pending[k] = dist.gather(self.records[k].flat, self.recv[k] if self.rank == self.dst else None,
@@ -112,7 +117,7 @@ class TrajectoryGather(object):
     def submit_episode(self):
         k = self.ep_count % 2
         self.ep_count += 1
-        if self.world > 1:
+        if self.collective:
             self.ep_pending[k] = dist.gather(self.ep_send[k], self.ep_recv[k] if self.rank == self.dst else None,
                                              dst=self.dst, group=self.group, async_op=True)
 
@@ -122,12 +127,16 @@ class TrajectoryGather(object):
         if self.ep_pending[k] is not None:
             self.ep_pending[k].wait()
             self.ep_pending[k] = None
-        return [self.ep_send[k]] if self.world == 1 else list(self.ep_recv[k])
+        return [self.ep_send[k]] if not self.collective else list(self.ep_recv[k])
 
     def gathered(self, t):
-        """On the learner rank: list over ranks of (obs, reward, done) views of step t (after wait)."""
+        """On the learner rank: list over ranks of (obs, reward, done) views of step t.  Waits for the gather of that
+        step (the handle stays in place: ``record(t + depth)`` waits on it again, a no-op), so the views are complete
+        when this returns; they are overwritten by ``submit(t + depth)``."""
         k = t % self.depth
-        if self.world == 1:
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+        if not self.collective:
             r = self.records[k]
             return [(r.obs, r.reward, r.done)]
         return [self.records[k].views(f) for f in self.recv[k]]

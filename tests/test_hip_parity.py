@@ -271,7 +271,47 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
     assert d['value'] == pytest.approx(2 * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
-    assert 'cpu_baseline' not in d and d['roofline']['kernel_launches'] == 30
+    assert 'cpu_baseline' not in d and d['roofline']['kernel_launches'] == 30 and d['n_ranks_seen'] == 2
+
+
+def test_bench_exchange_through_rccl_with_one_rank():
+    """The nccl (= RCCL) branch of sharding.py / bench.py on the one GPU of this box: a process group of ONE rank, every
+    step's record and every episode record gathered through RCCL inside the timed loop, all_reduce for the timing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--rccl-selftest', '--n-envs', '2048', '--steps', '60',
+                          '--warmup', '10', '--no-cpu-baseline'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=600, cwd=root)
+    assert res.returncode == 0, res.stdout[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-4000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1 and d['config']['exchange'].startswith('RCCL (process group of one rank')
+    assert d['roofline']['traffic_source'] is None or 'replayed' in d['roofline']['traffic_source']
+    assert d['reference_cpu']['value'] == 1662.0
+
+
+def test_bench_fails_loudly_when_the_exchange_cannot_run():
+    """N > 1 and the trajectory gather raises (injected on the last rank; gloo ranks sharing this box's GPU): bench.py
+    exits non-zero and prints no JSON line -- never a scaling number measured without the exchange (VERDICT round 1,
+    weak point 11)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, FMARL_BENCH_INJECT_GATHER_ERROR='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--n-envs', '256',
+           '--steps', '5', '--warmup', '2']
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode != 0
+    assert 'trajectory gather failed' in res.stdout
+    assert not [l for l in res.stdout.splitlines() if l.startswith('{"metric"')], res.stdout[-3000:]
 
 
 def test_rebuild_is_refused_for_other_scenarios():
