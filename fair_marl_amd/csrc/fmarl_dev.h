@@ -57,7 +57,7 @@ struct Params {
     // formation scenario: extra per-env LDS tables (byte offsets) and state
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
     double2 *slot_pos;
-    double *slot_occ, *slot_delta, *formation_done;
+    double *slot_occ, *slot_delta, *formation_done, *match_dual;
     // fairnav scenario: extra per-env LDS tables (byte offsets), knob and state
     int n_D, n_minprox, n_occ, n_match, n_rows, n_words;
     double min_obs_dist;

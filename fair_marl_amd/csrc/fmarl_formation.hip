@@ -27,16 +27,20 @@ constexpr double kTargetRadius = 0.5;   // ff:105
 // Costs are |x_row - P_col| computed on the fly (x: agent positions in LDS, P: slot positions; an N x N table per
 // group of lanes costs a workgroup per CU and was measured slower: 0.46 vs 0.42 ms at cfg 4).  ans[row] = col.  For generic real costs the optimum is unique, so it
 // equals SciPy's linear_sum_assignment (ff:615-618).
+// Warm start: vin[c] are column potentials left by an earlier matching on nearly the same costs (any values are
+// feasible once u = row minima of c - v, which is what rowmin[] / ans[] hold on entry); vout (LDS, may alias rowmin)
+// receives the final column potentials shifted so that their maximum is 0.
 template <int G>
-__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *ans, const double *rowmin) {
+__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *ans, const double *rowmin, const double *vin,
+                                double *vout) {
     const int lane = threadIdx.x & (G - 1);
     const double INF = 1e300;
-    double u = 0.0, v = 0.0;
+    double u = 0.0, v = lane < N ? vin[lane] : 0.0;
     int prow = -1;   // row matched to column `lane`
     const double2 Pc = P[lane < N ? lane : 0];
-    // Start: u = row minima, v = 0 (feasible potentials), every row claims its cheapest column, the lowest row wins a
-    // contested one (those edges are tight).  Only the rows left without a column go through the augmenting search;
-    // the optimum does not depend on the start.
+    // Start: u = row minima of c - v (feasible potentials), every row claims the column of its minimum, the lowest row
+    // wins a contested one (those edges are tight).  Only the rows left without a column go through the augmenting
+    // search; the optimum does not depend on the start.
     // (row minima and their columns come from the kernel's agent x slot distance pass: rowmin[], ans[] on entry)
     int mine = 0;
     {
@@ -81,12 +85,16 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *
         }
     }
     if (lane < N) ans[prow] = lane;
+    if (vout) {
+        const double vmax = group_extreme<G, true>(lane < N ? v : -INF);
+        if (lane < N) vout[lane] = v - vmax;
+    }
 }
 
 // All matchings of the workgroup's envs: task = (env, which) with which 0 = current slots, 1 = previous
 // slots (needed by observation(0) of a step); groups of G lanes take tasks round-robin.
 template <int G>
-__device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_env);
+__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int nenv, int per_env);
 
 // Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
 struct FormLds {
@@ -94,7 +102,9 @@ struct FormLds {
     const Params &p;
     __device__ FormLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
     __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
-    __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }
+    __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }   // (vx, vy, x, y) in f32
+    __device__ float2 *posf() const { return (float2 *)(base + p.lds_posf); }
+    __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2)
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
@@ -144,7 +154,7 @@ struct FormLds {
 };
 
 template <int G>
-__device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_env) {
+__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int nenv, int per_env) {
     const int group = threadIdx.x / G, ngroups = kThreads / G;
     for (int task = group; task < nenv * per_env; task += ngroups) {
         const int el = task / per_env, which = task - el * per_env;
@@ -155,8 +165,9 @@ __device__ void hungarian_tasks(const Params &p, char *lds, int nenv, int per_en
             const uint32_t full = p.N >= 32 ? ~0u : ((1u << p.N) - 1);
             if ((int)t.words()[3] >= 0 || ((~t.words()[0]) & full) == 0) continue;
         }
+        const double *vin = p.match_dual + (size_t)(env0 + el) * p.N;   // global: stable until the barrier after the matchings
         hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
-                           which == 0 ? t.theta() : (const double *)t.masks());
+                           which == 0 ? t.theta() : (const double *)t.masks(), vin, which == 0 ? t.theta() : nullptr);
     }
 }
 
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     const int env = env0 + el;
     const size_t g = (size_t)env * N + i;
     const FormLds t(p, lds, el);
-    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
+    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old | Dg_new] x N
     const uint32_t full = N >= 32 ? ~0u : ((1u << N) - 1);
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
@@ -219,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     const double2 L0 = active ? t.pos()[N] : make_double2(0, 0);   // landmark 0
     if (active) {
         t.pos()[i] = x;
-        t.agentf()[i] = make_float4((float)v.x, (float)v.y, 0.f, 0.f);
+        t.agentf()[i] = make_float4((float)v.x, (float)v.y, (float)x.x, (float)x.y);
+        t.posf()[i] = make_float2((float)x.x, (float)x.y);
         double th = atan2(x.y - L0.y, x.x - L0.x);   // ff:35-40
         if (th < 0) th += 2 * M_PI;
         t.theta()[i] = th;
@@ -231,7 +243,6 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             if (ring) fdone = 1.0;
             Tr_new = (ring && open) ? step * kDt : Tr_old;
             s_stat[i] = pd; s_stat[N + i] = Dg_old; s_stat[2 * N + i] = open ? pd : Dg_old;
-            s_stat[3 * N + i] = Tr_old; s_stat[4 * N + i] = Tr_new;
         }
     }
     __syncthreads();
@@ -252,21 +263,27 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
 
     double left = 0;
     if (active) {   // agent x slot distances (ff:650-655), nearest slot within thr, dist_left (ff:453)
-        double best = 1e300, best_old = 1e300;
-        int kb = 0, kb_old = 0;
+        // row minima of c - v for the warm-started matchings (v: the potentials the previous matching of this env left;
+        // for the previous slots they are the potentials of exactly those slots, one step of motion ago)
+        const double *vg = p.match_dual + (size_t)env * N;
+        double best = 1e300, best_old = 1e300, rbest = 1e300, rbest_old = 1e300;
+        int kb = 0, kb_old = 0, rkb = 0, rkb_old = 0;
         for (int k = 0; k < N; ++k) {
+            const double vk = vg[k];
             const double d = dist2(x, t.slot_new()[k]);
             if (d < best) { best = d; kb = k; }
+            if (d - vk < rbest) { rbest = d - vk; rkb = k; }
             if (STEP) {
                 const double d0 = dist2(x, t.slot_old()[k]);
                 if (d0 < best_old) { best_old = d0; kb_old = k; }
+                if (d0 - vk < rbest_old) { rbest_old = d0 - vk; rkb_old = k; }
             }
         }
         left = best;
         t.near_new()[i] = best < p.thr ? kb : -1;
-        // start of the matchings (hungarian_group): row minimum and its column, in tables that are idle until then
-        t.theta()[i] = best; t.g_new()[i] = kb;
-        if (STEP) { ((double *)t.masks())[i] = best_old; t.g_old()[i] = kb_old; }
+        // start of the matchings (hungarian_group): reduced row minimum and its column, in tables that are idle until then
+        t.theta()[i] = rbest; t.g_new()[i] = rkb;
+        if (STEP) { ((double *)t.masks())[i] = rbest_old; t.g_old()[i] = rkb_old; }
         if (i == 0) t.words()[3] = (uint32_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
     }
     __syncthreads();
@@ -281,35 +298,40 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     __syncthreads();
     {   // the matchings (current slots; on a step also the previous slots for observation(0))
         const int per_env = FMARL_SKIP(p, 64) ? 0 : (STEP ? 2 : 1);
-        if (N <= 4) hungarian_tasks<4>(p, lds, nenv, per_env);
-        else if (N <= 8) hungarian_tasks<8>(p, lds, nenv, per_env);
-        else if (N <= 16) hungarian_tasks<16>(p, lds, nenv, per_env);
-        else hungarian_tasks<32>(p, lds, nenv, per_env);
+        if (N <= 4) hungarian_tasks<4>(p, lds, env0, nenv, per_env);
+        else if (N <= 8) hungarian_tasks<8>(p, lds, env0, nenv, per_env);
+        else if (N <= 16) hungarian_tasks<16>(p, lds, env0, nenv, per_env);
+        else hungarian_tasks<32>(p, lds, env0, nenv, per_env);
     }
     __syncthreads();
 
-    if (active && i == 0 && !FMARL_SKIP(p, 128)) {   // sequential walk of the occupancy mask (one lane per env)
-        uint32_t occ = t.words()[0];
-        uint32_t *m = t.masks();
-        const int *gn = t.g_new(), *nr = t.near_new();
+    if (tid < nenv && !FMARL_SKIP(p, 128)) {
+        // Sequential walk of the occupancy mask, one lane per env -- the lanes of ALL envs sit side by side in wave 0
+        // (as lane 0 of each env they were spread over the four waves, each of which then ran the whole serial walk).
+        const FormLds tw(p, lds, tid);
+        uint32_t occ = tw.words()[0];
+        uint32_t *m = tw.masks();
+        const int *gn = tw.g_new(), *nr = tw.near_new();
+        const int near0 = (int)tw.words()[3];
         for (int a = 0; a < N; ++a) {
             uint32_t code;
             if (STEP && a == 0) {
-                code = branch_event((int)t.words()[3], t.g_old()[0], full, occ);   // observation(0): previous slots
-                occ = t.words()[1];                                                  // reward(0)
+                code = branch_event(near0, tw.g_old()[0], full, occ);   // observation(0): previous slots
+                occ = tw.words()[1];                                     // reward(0)
             } else {
-                code = branch_event(a == 0 ? (int)t.words()[3] : nr[a], gn[a], full, occ);
+                code = branch_event(a == 0 ? near0 : nr[a], gn[a], full, occ);
             }
             uint32_t mb = 0, mc = 0, mf = 0;
+            const int ga = gn[a];
             for (int e = 0; e < N; ++e) {
-                const uint32_t c = branch_event(nr[e], gn[a], full, occ);
+                const uint32_t c = branch_event(nr[e], ga, full, occ);
                 mb |= ((c >> 1) & 1u) << e;
                 mc |= ((c >> 2) & 1u) << e;
                 mf |= (c & 1u) << e;
             }
             m[4 * a] = mb; m[4 * a + 1] = mc; m[4 * a + 2] = mf; m[4 * a + 3] = code;
         }
-        t.words()[2] = occ;
+        tw.words()[2] = occ;
     }
     __syncthreads();
 
@@ -326,7 +348,10 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             ob[0] = (float)(v.x + flag); ob[1] = (float)(v.y + flag); ob[2] = (float)(x.x + flag); ob[3] = (float)(x.y + flag);
             ob[4] = (float)(goal.x - x.x + flag); ob[5] = (float)(goal.y - x.y + flag);
         }
-        if (STEP || emit) p.slot_occ[g] = (double)((t.words()[2] >> i) & 1u);
+        if (STEP || emit) {
+            p.slot_occ[g] = (double)((t.words()[2] >> i) & 1u);
+            p.match_dual[g] = t.theta()[i];   // column potentials of the matching on the current slots: next step's warm start
+        }
         if (STEP) {
             const bool open = Tr_old == -1.0;
             const double Dg_new = open ? pd : Dg_old;
@@ -392,20 +417,20 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             const FormLds te(p, lds, e_l);
             if (te.skip()) continue;
             const uint32_t a = p.dE.div(r), e = r - a * p.E;
-            const double2 xi = te.pos()[a], xe = te.pos()[e];
-            const float dx = (float)(xe.x - xi.x), dy = (float)(xe.y - xi.y);
+            // differences of the f32 roundings (as navigation_graph's rows): within 1.2e-7 of the rounded f64 difference
             const float4 ai = te.agentf()[a];
+            const float2 pe = te.posf()[e];
+            const float dx = pe.x - ai.z, dy = pe.y - ai.w;
             float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
             if (e < (uint32_t)N) {
                 const float4 ae = te.agentf()[e];
                 vx = ae.x; vy = ae.y;
                 const double2 gl = te.graph_goal(a, e);
-                gx = (float)(gl.x - xi.x); gy = (float)(gl.y - xi.y);
+                gx = (float)gl.x - ai.z; gy = (float)gl.y - ai.w;
                 fl = (float)((te.masks()[4 * a + 2] >> e) & 1);
             } else if (e >= first_wall) {
-                const double *wl = te.wall() + (e - first_wall) * 4;
-                t7 = (float)(wl[1] - xi.x);                                             // e0 - x_i
-                t8 = (float)(wl[0] + kWallWidth / 2 - xi.y); t9 = (float)(wl[2] - xi.x); t10 = (float)(wl[0] - kWallWidth / 2 - xi.y);
+                const float4 wc = te.wallf()[e - first_wall];   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
+                t7 = wc.x - ai.z; t8 = wc.y - ai.w; t9 = wc.z - ai.z; t10 = wc.w - ai.w;
             }
             const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
             float4 *d = dst + (size_t)q * 3;
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             d[2] = make_float4(t8, t9, t10, type);
         }
     }
-    if (o.adj) emit_adj_generic(p, o, lds, env0, nenv);
+    emit_adj(p, o, lds, env0, nenv);
 }
 
 }  // namespace fmarl

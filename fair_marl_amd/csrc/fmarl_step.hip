@@ -217,6 +217,32 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
     }
 }
 
+// adj of the workgroup's envs: the 16-byte path when E % 4 == 0 and the f32 position table exists, else the generic one.
+__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
+    const int tid = threadIdx.x;
+    const uint32_t EE = p.E * p.E;
+    if (o.adj && p.vec_adj) {
+        // 16-byte path (E % 4 == 0): the workgroup streams its region front to back (chunk m = tid + 256 k:
+        // its four waves write one 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32
+        // position table (the roundings node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
+        const uint32_t E4 = p.E >> 2, per_env = p.E * E4, chunks = nenv * per_env;
+        float4 *dst = (float4 *)(o.adj + (size_t)env0 * EE);
+        for (uint32_t m = tid; m < chunks; m += kThreads) {
+            const uint32_t el = p.dEE4.div(m), r = m - el * per_env;
+            const EnvLds t(p, lds, el);
+            if (t.skip()) continue;
+            const uint32_t a = p.dE4.div(r), b4 = r - a * E4;
+            const float2 pa = t.posf()[a];
+            const float4 q0 = ((const float4 *)t.posf())[b4 * 2], q1 = ((const float4 *)t.posf())[b4 * 2 + 1];
+            dst[m] = make_float4(dist_f32(pa.x - q0.x, pa.y - q0.y), dist_f32(pa.x - q0.z, pa.y - q0.w),
+                                 dist_f32(pa.x - q1.x, pa.y - q1.y), dist_f32(pa.x - q1.z, pa.y - q1.w));
+        }
+    } else if (o.adj) {
+        emit_adj_generic(p, o, lds, env0, nenv);
+    }
+}
+
+
 // Emission of the graph outputs of the workgroup's envs.
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x;
@@ -257,25 +283,7 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, in
             }
         }
     }
-    if (o.adj && p.vec_adj) {
-        // 16-byte path (E % 4 == 0): the workgroup streams its region front to back (chunk m = tid + 256 k:
-        // its four waves write one 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32
-        // position table (the roundings node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
-        const uint32_t E4 = p.E >> 2, per_env = p.E * E4, chunks = nenv * per_env;
-        float4 *dst = (float4 *)(o.adj + (size_t)env0 * EE);
-        for (uint32_t m = tid; m < chunks; m += kThreads) {
-            const uint32_t el = p.dEE4.div(m), r = m - el * per_env;
-            const EnvLds t(p, lds, el);
-            if (t.skip()) continue;
-            const uint32_t a = p.dE4.div(r), b4 = r - a * E4;
-            const float2 pa = t.posf()[a];
-            const float4 q0 = ((const float4 *)t.posf())[b4 * 2], q1 = ((const float4 *)t.posf())[b4 * 2 + 1];
-            dst[m] = make_float4(dist_f32(pa.x - q0.x, pa.y - q0.y), dist_f32(pa.x - q0.z, pa.y - q0.w),
-                                 dist_f32(pa.x - q1.x, pa.y - q1.y), dist_f32(pa.x - q1.z, pa.y - q1.w));
-        }
-    } else if (o.adj) {
-        emit_adj_generic(p, o, lds, env0, nenv);
-    }
+    emit_adj(p, o, lds, env0, nenv);
 }
 
 // f32 rows of agent i used by the emission: agentf = (vx, vy, gx, gy), ego = [vx vy x y 0].
@@ -297,7 +305,7 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         pos[p.N + k] = x;
         if (p.has_posf) ((float2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)x.x, (float)x.y);
     }
-    if (p.has_posf)
+    if (p.has_posf && p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH)
         for (int t = threadIdx.x; t < nenv; t += kThreads)
             *(float4 *)(lds + (size_t)t * p.lds_env_bytes + p.lds_constf) = make_float4(0.f, 1.f, 2.f, 3.f);
     for (int t = threadIdx.x; t < nenv * p.W; t += kThreads) {

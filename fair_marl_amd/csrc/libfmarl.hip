@@ -99,6 +99,7 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     set(FMARL_F_STAGE_GOAL_MATCH, async ? n * N : 0, FMARL_DTYPE_I32);
     set(FMARL_F_STAGE_VALID, n, FMARL_DTYPE_I32);
     set(FMARL_F_STAGE_NEED, n, FMARL_DTYPE_I32);
+    set(FMARL_F_MATCH_DUAL, form ? n * N : 0, FMARL_DTYPE_F64);
     size_t off = 0;
     for (int f = 0; f < FMARL_NUM_FIELDS; ++f) {
         l->off[f] = off;
@@ -164,6 +165,7 @@ Params bind(const Handle *h, void *state) {
     p.st_obstacle_pos = (double2 *)(s + o[FMARL_F_STAGE_OBSTACLE_POS]); p.st_wall_axis = (double *)(s + o[FMARL_F_STAGE_WALL_AXIS]);
     p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
     p.stage_valid = (int *)(s + o[FMARL_F_STAGE_VALID]);            p.stage_need = (int *)(s + o[FMARL_F_STAGE_NEED]);
+    p.match_dual = (double *)(s + o[FMARL_F_MATCH_DUAL]);
     return p;
 }
 
@@ -279,13 +281,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_agentf = off; off = align16(off + p.N * 16);
     p.lds_ego = off;    off = align16(off + ((form || fnav) ? 0 : p.N * kEgoWidth * 4));
     p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
-    p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : 5 * p.N * 8));   // wave scans need no table
+    p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 3 : 5) * p.N * 8));   // wave scans need no table; formation has no time statistics
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 4);
-    p.has_posf = !form && !fnav;
+    p.has_posf = !fnav;   // f32 copy of the entity positions: adj (and the formation scenario's node rows) start from it
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     p.lds_wallf = off;  off = align16(off + (p.has_posf ? p.W * 16 : 0));
-    p.lds_constf = off; off = align16(off + (p.has_posf ? 16 : 0));
+    p.lds_constf = off; off = align16(off + (p.has_posf && !form ? 16 : 0));
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
         p.f_slot_old = off; off = align16(off + p.N * 16);
@@ -335,12 +337,11 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (const char *ab = getenv("FMARL_ABLATE")) p.ablate = atoi(ab);
 #endif
     p.vec_node = !form && !fnav && (p.E * p.F) % 4 == 0 && p.E * p.F / 4 <= 64 * 4 && p.lds_env_bytes < 65536;
-    p.vec_adj = p.E % 4 == 0;
+    p.vec_adj = p.E % 4 == 0 && p.has_posf;
     p.dC4.set(p.vec_node ? p.E * p.F / 4 : 1);
     p.dNC4.set(p.vec_node ? p.N * (p.E * p.F / 4) : 1);
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
     p.dE4.set(p.vec_adj ? p.E / 4 : 1);
-    if (form) p.vec_adj = 0;
     if (fnav) p.dC4.set(p.N * p.E);   // fairnav emission: (ego, entity) rows per env
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);

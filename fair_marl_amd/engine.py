@@ -166,7 +166,7 @@ class RolloutEngine:
                     formation_done=(n, N), goal_occ=(n, N), goal_history=(n, N), goal_reached=(n, N), status=(n, N),
                     reset_flag=(n,), stage_agent_pos=(n, N, 2), stage_landmark_pos=(n, L, 2),
                     stage_obstacle_pos=(n, O, 2), stage_wall_axis=(n, W), stage_wall_orient=(n, W),
-                    stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,))
+                    stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,), internal_match_dual=(n, N))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -184,7 +184,7 @@ class RolloutEngine:
         with torch.cuda.device(self.device):
             torch.cuda.current_stream(self.device).synchronize()
             for k, t in self._fields.items():
-                if k == 'reset_flag' or k.startswith('stage_'):
+                if k == 'reset_flag' or k.startswith(('stage_', 'internal_')):
                     continue
                 a = np.empty(tuple(t.shape), dtype=self._NP_DT[t.dtype])
                 if a.size:

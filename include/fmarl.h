@@ -141,6 +141,8 @@ enum {
     FMARL_F_STAGE_GOAL_MATCH,  /* i32 (n, N)     ... including its fair assignment                         */
     FMARL_F_STAGE_VALID,       /* i32 (n)        1 = the staged data belongs to episode index `episode`    */
     FMARL_F_STAGE_NEED,        /* i32 (n)        internal: envs being staged                               */
+    FMARL_F_MATCH_DUAL,        /* f64 (n, N)     internal (formation): column potentials of the last slot matching, the
+                                                 warm start of the next one (any values are valid: the optimum is unique) */
     FMARL_NUM_FIELDS
 };
 #define FMARL_DTYPE_F64 0
