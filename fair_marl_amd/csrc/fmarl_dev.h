@@ -43,6 +43,7 @@ struct Params {
     int n_envs, N, L, O, W, E, D, F;
     int episode_length, has_max_speed, env_offset, scenario;
     int epb;                 // environments per workgroup = kThreads / N
+    int epw;                 // formation scenario: environments per wave (every env inside one wave), epb = 4 epw
     int feat_global;   // FMARL_FLAG_GLOBAL_FEATURES: node rows are [vel, pos, goal, type] without the ego part
     int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
     int lds_posf, has_posf;  // navigation_graph: f32 copy of the entity positions (adj is computed from it)

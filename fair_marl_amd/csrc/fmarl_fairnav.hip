@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
             }
         }
     }
-    if (o.adj) emit_adj_generic(p, o, lds, env0, nenv);
+    if (o.adj) emit_adj_generic(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
 }
 
 }  // namespace fmarl

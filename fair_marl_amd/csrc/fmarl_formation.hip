@@ -31,7 +31,7 @@ constexpr double kTargetRadius = 0.5;   // ff:105
 // feasible once u = row minima of c - v, which is what rowmin[] / ans[] hold on entry); vout (LDS, may alias rowmin)
 // receives the final column potentials shifted so that their maximum is 0.
 template <int G>
-__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *ans, const double *rowmin, const double *vin,
+__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int8_t *ans, const double *rowmin, const double *vin,
                                 double *vout) {
     const int lane = threadIdx.x & (G - 1);
     const double INF = 1e300;
@@ -84,7 +84,7 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *
             j = jprev;
         }
     }
-    if (lane < N) ans[prow] = lane;
+    if (lane < N) ans[prow] = (int8_t)lane;
     if (vout) {
         const double vmax = group_extreme<G, true>(lane < N ? v : -INF);
         if (lane < N) vout[lane] = v - vmax;
@@ -94,7 +94,7 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int *
 // All matchings of the workgroup's envs: task = (env, which) with which 0 = current slots, 1 = previous
 // slots (needed by observation(0) of a step); groups of G lanes take tasks round-robin.
 template <int G>
-__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int nenv, int per_env);
+__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env);
 
 // Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
 struct FormLds {
@@ -102,70 +102,48 @@ struct FormLds {
     const Params &p;
     __device__ FormLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
     __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
-    __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }   // (vx, vy, x, y) in f32
+    __device__ float2 *velf() const { return (float2 *)(base + p.lds_agentf); }     // (vx, vy) in f32
     __device__ float2 *posf() const { return (float2 *)(base + p.lds_posf); }
     __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2)
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
     __device__ double2 *slot_old() const { return (double2 *)(base + p.f_slot_old); }
-    __device__ int *g_new() const { return (int *)(base + p.f_g); }
-    __device__ int *g_old() const { return (int *)(base + p.f_g) + p.N; }
-    __device__ int *near_new() const { return (int *)(base + p.f_g) + 2 * p.N; }
-    __device__ uint32_t *masks() const { return (uint32_t *)(base + p.f_masks); }   // [N][4]: b, c, flag, obs code
+    // small per-agent indices as bytes (N <= 32): slot of the matching on the current / previous slots, nearest slot
+    // within thr (-1: none), and at [3 N] the nearest previous slot of agent 0
+    __device__ int8_t *g_new() const { return (int8_t *)(base + p.f_g); }
+    __device__ int8_t *g_old() const { return (int8_t *)(base + p.f_g) + p.N; }
+    __device__ int8_t *near_new() const { return (int8_t *)(base + p.f_g) + 2 * p.N; }
+    __device__ int8_t *near_old0() const { return (int8_t *)(base + p.f_g) + 3 * p.N; }
+    __device__ uint32_t *masks() const { return (uint32_t *)(base + p.f_masks); }   // [N][3]: b, flag, obs code
     __device__ double *theta() const { return (double *)(base + p.f_theta); }
-    __device__ uint32_t *words() const { return (uint32_t *)(base + p.f_words); }     // occ_old, occ_new, occ_final, near_old0
+    __device__ uint32_t *words() const { return (uint32_t *)(base + p.lds_flag) + 1; }   // occ_old, occ_new, occ_final (behind the flag)
+    __device__ uint32_t *openmask() const { return (uint32_t *)(base + p.lds_stat + 2 * p.N * 8); }   // bit j: agent j has not arrived yet
     __device__ bool skip() const { return *flag() != 0; }
 
     // goal of agent entity e as seen in the graph row of ego i (ff:916-943)
     __device__ double2 graph_goal(uint32_t i, uint32_t e) const {
         const int nr = near_new()[e];
         if (nr >= 0) return slot_new()[nr];
-        const uint32_t *m = masks() + 4 * i;
-        if ((m[0] >> e) & 1) return slot_new()[g_new()[i]];
+        if ((masks()[3 * i] >> e) & 1) return slot_new()[g_new()[i]];
         return pos()[e];
-    }
-    // feature column f of entity e in the row block of ego i (ff:896-971), ego part included
-    __device__ float node_feature(uint32_t i, uint32_t e, uint32_t f) const {
-        const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
-        if (f == 11) return e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
-        const double2 xi = pos()[i];
-        if (f < 2) {
-            const float4 ai = agentf()[i];
-            const float vi = f == 0 ? ai.x : ai.y;
-            if (e >= N) return 0.f - vi;
-            const float4 ae = agentf()[e];
-            return (f == 0 ? ae.x : ae.y) - vi;
-        }
-        if (f == 6) return e < N ? (float)((masks()[4 * i + 2] >> e) & 1) : 1.f;
-        if (e < N && (f == 4 || f == 5)) {
-            const double2 gl = graph_goal(i, e);
-            return (float)(f == 4 ? gl.x - xi.x : gl.y - xi.y);
-        }
-        if (e >= first_wall && f >= 7) {   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
-            const double *wl = wall() + (e - first_wall) * 4;
-            const double c = f == 7 ? wl[1] : (f == 8 ? wl[0] + kWallWidth / 2 : (f == 9 ? wl[2] : wl[0] - kWallWidth / 2));
-            return (float)(c - ((f & 1) ? xi.x : xi.y));   // f = 7, 9 -> x ; 8, 10 -> y
-        }
-        const double2 xe = pos()[e];
-        const bool is_y = f < 6 ? (f & 1) : !(f & 1);   // columns 2..5: x y x y ; 7..10: x y x y
-        return (float)(is_y ? xe.y - xi.y : xe.x - xi.x);
     }
 };
 
 template <int G>
-__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int nenv, int per_env) {
-    const int group = threadIdx.x / G, ngroups = kThreads / G;
-    for (int task = group; task < nenv * per_env; task += ngroups) {
-        const int el = task / per_env, which = task - el * per_env;
+__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env) {
+    // the wave's own envs only: its 64 / G lane groups take the tasks round-robin, no other wave is involved
+    const int group = (threadIdx.x & 63) / G, ngroups = 64 / G;
+    for (int task = group; task < nenv_w * per_env; task += ngroups) {
+        const int elw = task / per_env, which = task - elw * per_env, el = el0w + elw;
         const FormLds t(p, lds, el);
         // the matching on the previous slots only serves observation(agent 0) in its "free slot left" branch
         // (ff:707-739): not when agent 0 sits on a previous slot or every slot is taken (common once agents hold the ring)
         if (which == 1) {
             const uint32_t full = p.N >= 32 ? ~0u : ((1u << p.N) - 1);
-            if ((int)t.words()[3] >= 0 || ((~t.words()[0]) & full) == 0) continue;
+            if (*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0) continue;
         }
-        const double *vin = p.match_dual + (size_t)(env0 + el) * p.N;   // global: stable until the barrier after the matchings
+        const double *vin = p.match_dual + (size_t)(env0 + el) * p.N;   // global: rewritten only after the matchings
         hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
                            which == 0 ? t.theta() : (const double *)t.masks(), vin, which == 0 ? t.theta() : nullptr);
     }
@@ -178,6 +156,12 @@ __device__ __forceinline__ bool wall_box_hit_plain(double2 x, double axis, doubl
     return (axis - s / 2 <= pperp) && (pperp <= axis + s / 2) && (e0 - s / 2 <= ppar) && (ppar <= e1 + s / 2);
 }
 
+// Ordering point between phases of one wave that talk through LDS.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One branch event of ff:707-739 / ff:916-943 on the occupancy mask.  Returns type (0 = near slot,
 // 1 = Hungarian slot of `ego`, 2 = own position) in bits 1..2 and the observed flag in bit 0.
 __device__ __forceinline__ uint32_t branch_event(int near_e, int g_ego, uint32_t full, uint32_t &occ) {
@@ -185,6 +169,22 @@ __device__ __forceinline__ uint32_t branch_event(int near_e, int g_ego, uint32_t
     if ((~occ) & full) return 2u | ((occ >> g_ego) & 1u);
     occ = 0;
     return 4u;
+}
+
+// mean and population std (two-pass, like np.mean / np.std) of the dists_to_goal vector seen by the agent loop: entry j
+// is this step's value for j < split -- the path length pd[j] while agent j is still under way (bit j of open), else
+// the value frozen at its arrival -- and the previous step's value (stale[j]) for j >= split.
+__device__ __forceinline__ void travelled_stats(const double *pd, const double *stale, uint32_t open, int n, int split,
+                                                double &mean, double &sd) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += (j < split && ((open >> j) & 1u)) ? pd[j] : stale[j];
+    mean = s / n;
+    double q = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double d = ((j < split && ((open >> j) & 1u)) ? pd[j] : stale[j]) - mean;
+        q += d * d;
+    }
+    sd = sqrt(q / n);
 }
 
 // STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877)
@@ -196,12 +196,19 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     const int tid = threadIdx.x, N = p.N;
     const int env0 = blockIdx.x * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
-    const int el = tid / N, i = tid - el * N;
-    const bool active = el < nenv;
+    // Every env lives inside ONE wave (p.epw = 64 / N envs per wave, p.epb = 4 p.epw): after the shared entity tables are
+    // loaded no wave ever waits for another one -- all the ordering between the phases below is wave-local
+    // (wave_sync: LDS executes a wave's instructions in order, a fence keeps the compiler from reordering them).
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int elw = lane / N, i = lane - elw * N;
+    const int el0w = wave * p.epw;                            // first env of this wave
+    const int nenv_w = max(0, min(p.epw, nenv - el0w));      // envs of this wave
+    const int el = el0w + elw;
+    const bool active = elw < nenv_w;
     const int env = env0 + el;
     const size_t g = (size_t)env * N + i;
-    const FormLds t(p, lds, el);
-    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old | Dg_new] x N
+    const FormLds t(p, lds, active ? el : 0);
+    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old] x N, then the mask of agents still under way
     const uint32_t full = N >= 32 ? ~0u : ((1u << N) - 1);
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
         t.pos()[i] = x;
         t.slot_old()[i] = p.slot_pos[g];
-        if (i == 0) { t.words()[0] = 0; t.words()[1] = 0; }
+        if (i == 0) { t.words()[0] = 0; t.words()[1] = 0; *t.openmask() = 0; }
         step = p.cur_step[env] + (STEP ? 1 : 0);
         emit = STEP ? !(auto_reset && step >= p.episode_length) : p.reset_flag[env] != 0;
         if (i == 0) *t.flag() = emit ? 0 : 1;
@@ -220,17 +227,17 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
     if (!STEP && !__syncthreads_or(active && p.reset_flag[env] != 0)) return;
     load_statics(p, lds, env0, nenv);
-    __syncthreads();
+    __syncthreads();   // the only workgroup barrier: the entity tables are loaded by all four waves together
     if (active && p.slot_occ[g] != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
 
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd);
-    __syncthreads();   // every lane has finished reading the old positions
+    wave_sync();   // every lane has finished reading the old positions
 
     double Dg_old = 0, Tr_old = 0, Tr_new = 0, fdone = 0;
     const double2 L0 = active ? t.pos()[N] : make_double2(0, 0);   // landmark 0
     if (active) {
         t.pos()[i] = x;
-        t.agentf()[i] = make_float4((float)v.x, (float)v.y, (float)x.x, (float)x.y);
+        t.velf()[i] = make_float2((float)v.x, (float)v.y);
         t.posf()[i] = make_float2((float)x.x, (float)x.y);
         double th = atan2(x.y - L0.y, x.x - L0.x);   // ff:35-40
         if (th < 0) th += 2 * M_PI;
@@ -242,10 +249,11 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             const bool ring = fd < 1.05 * kTargetRadius && fd > 0.95 * kTargetRadius;
             if (ring) fdone = 1.0;
             Tr_new = (ring && open) ? step * kDt : Tr_old;
-            s_stat[i] = pd; s_stat[N + i] = Dg_old; s_stat[2 * N + i] = open ? pd : Dg_old;
+            s_stat[i] = pd; s_stat[N + i] = Dg_old;
+            if (open) atomicOr(t.openmask(), 1u << i);
         }
     }
-    __syncthreads();
+    wave_sync();
 
     if (active) {   // slots: ff:630-648 (step: inside reward(agent 0)); on reset they come from the state
         double2 P;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         }
         t.slot_new()[i] = P;
     }
-    __syncthreads();
+    wave_sync();
 
     double left = 0;
     if (active) {   // agent x slot distances (ff:650-655), nearest slot within thr, dist_left (ff:453)
@@ -280,13 +288,13 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             }
         }
         left = best;
-        t.near_new()[i] = best < p.thr ? kb : -1;
+        t.near_new()[i] = (int8_t)(best < p.thr ? kb : -1);
         // start of the matchings (hungarian_group): reduced row minimum and its column, in tables that are idle until then
-        t.theta()[i] = rbest; t.g_new()[i] = rkb;
-        if (STEP) { ((double *)t.masks())[i] = rbest_old; t.g_old()[i] = rkb_old; }
-        if (i == 0) t.words()[3] = (uint32_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
+        t.theta()[i] = rbest; t.g_new()[i] = (int8_t)rkb;
+        if (STEP) { ((double *)t.masks())[i] = rbest_old; t.g_old()[i] = (int8_t)rkb_old; }
+        if (i == 0) *t.near_old0() = (int8_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
     }
-    __syncthreads();
+    wave_sync();
 
     if (active) {
         // occupancy recomputed in reward(agent 0): any agent within thr of slot i (ff:660-661)
@@ -295,24 +303,23 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         for (int a = 0; a < N; ++a) occ |= dist2(t.pos()[a], Pi) < p.thr;
         if (occ) atomicOr(&t.words()[1], 1u << i);
     }
-    __syncthreads();
+    wave_sync();
     {   // the matchings (current slots; on a step also the previous slots for observation(0))
         const int per_env = FMARL_SKIP(p, 64) ? 0 : (STEP ? 2 : 1);
-        if (N <= 4) hungarian_tasks<4>(p, lds, env0, nenv, per_env);
-        else if (N <= 8) hungarian_tasks<8>(p, lds, env0, nenv, per_env);
-        else if (N <= 16) hungarian_tasks<16>(p, lds, env0, nenv, per_env);
-        else hungarian_tasks<32>(p, lds, env0, nenv, per_env);
+        if (N <= 4) hungarian_tasks<4>(p, lds, env0, el0w, nenv_w, per_env);
+        else if (N <= 8) hungarian_tasks<8>(p, lds, env0, el0w, nenv_w, per_env);
+        else if (N <= 16) hungarian_tasks<16>(p, lds, env0, el0w, nenv_w, per_env);
+        else hungarian_tasks<32>(p, lds, env0, el0w, nenv_w, per_env);
     }
-    __syncthreads();
+    wave_sync();
 
-    if (tid < nenv && !FMARL_SKIP(p, 128)) {
-        // Sequential walk of the occupancy mask, one lane per env -- the lanes of ALL envs sit side by side in wave 0
-        // (as lane 0 of each env they were spread over the four waves, each of which then ran the whole serial walk).
-        const FormLds tw(p, lds, tid);
+    if (lane < nenv_w && !FMARL_SKIP(p, 128)) {
+        // Sequential walk of the occupancy mask: one lane per env, the wave's envs side by side in its first lanes
+        const FormLds tw(p, lds, el0w + lane);
         uint32_t occ = tw.words()[0];
         uint32_t *m = tw.masks();
-        const int *gn = tw.g_new(), *nr = tw.near_new();
-        const int near0 = (int)tw.words()[3];
+        const int8_t *gn = tw.g_new(), *nr = tw.near_new();
+        const int near0 = *tw.near_old0();
         for (int a = 0; a < N; ++a) {
             uint32_t code;
             if (STEP && a == 0) {
@@ -321,24 +328,23 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             } else {
                 code = branch_event(a == 0 ? near0 : nr[a], gn[a], full, occ);
             }
-            uint32_t mb = 0, mc = 0, mf = 0;
+            uint32_t mb = 0, mf = 0;
             const int ga = gn[a];
             for (int e = 0; e < N; ++e) {
                 const uint32_t c = branch_event(nr[e], ga, full, occ);
                 mb |= ((c >> 1) & 1u) << e;
-                mc |= ((c >> 2) & 1u) << e;
                 mf |= (c & 1u) << e;
             }
-            m[4 * a] = mb; m[4 * a + 1] = mc; m[4 * a + 2] = mf; m[4 * a + 3] = code;
+            m[3 * a] = mb; m[3 * a + 1] = mf; m[3 * a + 2] = code;
         }
         tw.words()[2] = occ;
     }
-    __syncthreads();
+    wave_sync();
 
     if (active) {
-        const uint32_t code = t.masks()[4 * i + 3];
+        const uint32_t code = t.masks()[3 * i + 2];
         const bool old_slots = STEP && i == 0;
-        const int nr = i == 0 ? (int)t.words()[3] : t.near_new()[i];
+        const int nr = i == 0 ? (int)*t.near_old0() : (int)t.near_new()[i];
         double2 goal = x;   // type 2
         if (code & 1u && !(code & 6u)) goal = (old_slots ? t.slot_old() : t.slot_new())[nr];                 // type 0
         else if (code & 2u) goal = old_slots ? t.slot_old()[t.g_old()[0]] : t.slot_new()[t.g_new()[i]];     // type 1
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             const double delta = dist2(x, t.slot_new()[t.g_new()[i]]);   // ff:665
             double fairness, m, sd;   // ff:623-628, same stale/fresh rule as navigation_graph
             if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
-            else mixed_stats(s_stat + 2 * N, s_stat + N, N, i, m, sd);
+            else travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i, m, sd);
             fairness = m / (sd + 0.0001);
             int ag_hits = 0;
             for (int j = 0; j < N; ++j)
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             if (o.done) o.done[g] = step >= p.episode_length;
             if (o.info) {   // ff:477-499
                 double dm, ds;
-                mixed_stats(s_stat + 2 * N, s_stat + N, N, i + 1, dm, ds);
+                travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i + 1, dm, ds);
                 const size_t plane = (size_t)p.n_envs * N;
                 float *inf = o.info + g;
                 inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left;
@@ -410,36 +416,36 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (o.node_obs) {
         // one lane per (ego, entity) row of F = 12 floats = three 16-byte stores: [dv dx] [goal flag dx.x] [dx.y dx type];
         // the three chunks share the position loads and the index math; consecutive lanes write consecutive rows (ff:896-971)
-        const uint32_t NE = N * p.E, total = nenv * NE, first_wall = N + p.L + p.O;
-        float4 *dst = (float4 *)(o.node_obs + (size_t)env0 * NE * 12);
-        for (uint32_t q = tid; q < total; q += kThreads) {
+        // (each wave streams the rows of its own envs)
+        const uint32_t NE = N * p.E, total = nenv_w * NE, first_wall = N + p.L + p.O;
+        float4 *dst = (float4 *)(o.node_obs + ((size_t)env0 + el0w) * NE * 12);
+        for (uint32_t q = lane; q < total; q += 64) {
             const uint32_t e_l = p.dNE.div(q), r = q - e_l * NE;
-            const FormLds te(p, lds, e_l);
+            const FormLds te(p, lds, el0w + e_l);
             if (te.skip()) continue;
             const uint32_t a = p.dE.div(r), e = r - a * p.E;
             // differences of the f32 roundings (as navigation_graph's rows): within 1.2e-7 of the rounded f64 difference
-            const float4 ai = te.agentf()[a];
-            const float2 pe = te.posf()[e];
-            const float dx = pe.x - ai.z, dy = pe.y - ai.w;
+            const float2 vi = te.velf()[a], pi = te.posf()[a], pe = te.posf()[e];
+            const float dx = pe.x - pi.x, dy = pe.y - pi.y;
             float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
             if (e < (uint32_t)N) {
-                const float4 ae = te.agentf()[e];
-                vx = ae.x; vy = ae.y;
+                const float2 ve = te.velf()[e];
+                vx = ve.x; vy = ve.y;
                 const double2 gl = te.graph_goal(a, e);
-                gx = (float)gl.x - ai.z; gy = (float)gl.y - ai.w;
-                fl = (float)((te.masks()[4 * a + 2] >> e) & 1);
+                gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
+                fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
             } else if (e >= first_wall) {
                 const float4 wc = te.wallf()[e - first_wall];   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
-                t7 = wc.x - ai.z; t8 = wc.y - ai.w; t9 = wc.z - ai.z; t10 = wc.w - ai.w;
+                t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
             }
             const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
             float4 *d = dst + (size_t)q * 3;
-            d[0] = make_float4(vx - ai.x, vy - ai.y, dx, dy);
+            d[0] = make_float4(vx - vi.x, vy - vi.y, dx, dy);
             d[1] = make_float4(gx, gy, fl, t7);
             d[2] = make_float4(t8, t9, t10, type);
         }
     }
-    emit_adj(p, o, lds, env0, nenv);
+    emit_adj(p, o, lds, env0, el0w, el0w + nenv_w, lane, 64);
 }
 
 }  // namespace fmarl

@@ -8,7 +8,7 @@ namespace fmarl {
 __global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
                             int auto_reset);
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv);
-__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv);
+__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin, int el_end, uint32_t thr, uint32_t nthr);
 __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
 
 // fmarl_reset.hip

@@ -181,12 +181,14 @@ __device__ __forceinline__ void flush_rows(const Params &p, char *lds, const flo
 // adj for any E: a lane owns one 16-byte aligned chunk of the workgroup's region (4 entries, possibly of two rows
 // or envs), computes |x_a - x_b| for each and stores 16 bytes; the ragged ends and chunks that touch an env which
 // keeps its previous matrix fall back to 4-byte stores.  Shared by the three scenarios (same LDS tables).
-__device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
-    const uint32_t EE = p.E * p.E, total = nenv * EE;
-    float *dst = o.adj + (size_t)env0 * EE;
+// The caller's `nthr` threads (index `thr`) emit the envs [el_begin, el_end) of the workgroup.
+__device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin, int el_end,
+                                 uint32_t thr, uint32_t nthr) {
+    const uint32_t EE = p.E * p.E, total = (el_end - el_begin) * EE;
+    float *dst = o.adj + ((size_t)env0 + el_begin) * EE;
     const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 3), end = shift + total;
     float *gal = dst - shift;
-    for (uint32_t k = threadIdx.x; k < ((end + 3) >> 2); k += kThreads) {
+    for (uint32_t k = thr; k < ((end + 3) >> 2); k += nthr) {
         float v[4];
         bool ok[4];
 #pragma unroll
@@ -195,11 +197,11 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
             ok[j] = idx >= shift && idx < end;
             v[j] = 0.f;
             if (ok[j]) {
-                const uint32_t q = idx - shift, el = p.dEE.div(q);
+                const uint32_t q = idx - shift, elq = p.dEE.div(q), el = el_begin + elq;
                 const EnvLds t(p, lds, el);
                 if (t.skip()) { ok[j] = false; continue; }
-                const uint32_t r = q - el * EE, a = p.dE.div(r), b = r - a * p.E;
-                if (p.has_posf) {   // navigation_graph: the f32 position table (what a learner-side rebuild has)
+                const uint32_t r = q - elq * EE, a = p.dE.div(r), b = r - a * p.E;
+                if (p.has_posf) {   // the f32 position table (what a learner-side rebuild has)
                     const float2 pa = t.posf()[a], pb = t.posf()[b];
                     v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
                 } else {
@@ -217,17 +219,18 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
     }
 }
 
-// adj of the workgroup's envs: the 16-byte path when E % 4 == 0 and the f32 position table exists, else the generic one.
-__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
-    const int tid = threadIdx.x;
+// adj of the envs [el_begin, el_end) of the workgroup by `nthr` threads: the 16-byte path when E % 4 == 0 and the f32
+// position table exists, else the generic one.
+__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin, int el_end,
+                         uint32_t thr, uint32_t nthr) {
     const uint32_t EE = p.E * p.E;
     if (o.adj && p.vec_adj) {
-        // 16-byte path (E % 4 == 0): the workgroup streams its region front to back (chunk m = tid + 256 k:
-        // its four waves write one 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32
-        // position table (the roundings node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
-        const uint32_t E4 = p.E >> 2, per_env = p.E * E4, chunks = nenv * per_env;
+        // 16-byte path (E % 4 == 0): the threads stream the region front to back (a workgroup's four waves write one
+        // 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32 position table (the roundings
+        // node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
+        const uint32_t E4 = p.E >> 2, per_env = p.E * E4;
         float4 *dst = (float4 *)(o.adj + (size_t)env0 * EE);
-        for (uint32_t m = tid; m < chunks; m += kThreads) {
+        for (uint32_t m = el_begin * per_env + thr; m < el_end * per_env; m += nthr) {
             const uint32_t el = p.dEE4.div(m), r = m - el * per_env;
             const EnvLds t(p, lds, el);
             if (t.skip()) continue;
@@ -238,7 +241,7 @@ __device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds
                                  dist_f32(pa.x - q1.x, pa.y - q1.y), dist_f32(pa.x - q1.z, pa.y - q1.w));
         }
     } else if (o.adj) {
-        emit_adj_generic(p, o, lds, env0, nenv);
+        emit_adj_generic(p, o, lds, env0, el_begin, el_end, thr, nthr);
     }
 }
 
@@ -283,7 +286,7 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, in
             }
         }
     }
-    emit_adj(p, o, lds, env0, nenv);
+    emit_adj(p, o, lds, env0, 0, nenv, tid, kThreads);
 }
 
 // f32 rows of agent i used by the emission: agentf = (vx, vy, gx, gy), ego = [vx vy x y 0].

@@ -278,12 +278,12 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // per-env LDS layout (fmarl_step.hip EnvLds)
     int off = 0;
     p.lds_pos = off;    off = align16(off + p.E * 16);
-    p.lds_agentf = off; off = align16(off + p.N * 16);
+    p.lds_agentf = off; off = align16(off + p.N * (form ? 8 : 16));   // formation: (vx, vy) only
     p.lds_ego = off;    off = align16(off + ((form || fnav) ? 0 : p.N * kEgoWidth * 4));
     p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
-    p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 3 : 5) * p.N * 8));   // wave scans need no table; formation has no time statistics
+    p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 2 * p.N * 8 + 4 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
-    p.lds_flag = off;   off = align16(off + 4);
+    p.lds_flag = off;   off = align16(off + 16);   // flag + three scenario words
     p.has_posf = !fnav;   // f32 copy of the entity positions: adj (and the formation scenario's node rows) start from it
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     p.lds_wallf = off;  off = align16(off + (p.has_posf ? p.W * 16 : 0));
@@ -291,10 +291,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
         p.f_slot_old = off; off = align16(off + p.N * 16);
-        p.f_g = off;        off = align16(off + 3 * p.N * 4);
-        p.f_masks = off;    off = align16(off + 4 * p.N * 4);
+        p.f_g = off;        off = align16(off + 3 * p.N + 1);
+        p.f_masks = off;    off = align16(off + (3 * p.N * 4 > p.N * 8 ? 3 * p.N * 4 : p.N * 8));
         p.f_theta = off;    off = align16(off + p.N * 8);
-        p.f_words = off;    off = align16(off + 16);
+        p.f_words = off;   // (the three occupancy words sit behind the skip flag)
     }
     if (fnav) {   // fmarl_fairnav.hip FairNavLds
         p.n_D = off;       off = align16(off + p.N * p.L * 8);
@@ -313,15 +313,16 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     const int budget = 48 * 1024 - (kThreads / 64) * p.stage_wave_bytes;
     if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
     if (epb < 1) epb = 1;
-    if (form) {   // the step's 2 matchings per env are dealt to groups of G lanes: keep the last round of tasks full
-        int G = 4;
-        while (G < p.N) G *= 2;
-        const int groups = kThreads / (G < 32 ? G : 32);
-        for (int e = epb; e >= 1 && 10 * e >= 9 * epb; --e)
-            if ((2 * e) % groups == 0) { epb = e; break; }
+    if (form) {   // every env inside one wave (fmarl_formation.hip): 64 / N envs per wave, four waves
+        int epw = 64 / p.N;
+        if (epw < 1) { delete h; return fail(FMARL_EINVAL, "fmarl_create: fair_graph_formation is built for num_agents <= 32"); }
+        while (epw > 1 && (kThreads / 64) * epw * p.lds_env_bytes > budget) --epw;
+        p.epw = epw;
+        epb = (kThreads / 64) * epw;
     }
     // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
     if ((p.n_envs + epb - 1) / epb < 512) { int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb); }
+    if (form) { p.epw = (epb + kThreads / 64 - 1) / (kThreads / 64); epb = p.epw * (kThreads / 64); }
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     p.lds_stage = align16(epb * p.lds_env_bytes);
