@@ -20,6 +20,7 @@
 #include "fmarl_dev.h"
 #include "fmarl_kernels.h"
 #include "fmarl_lexifair.hip"
+#include "fmarl_reset.hip"
 #include "fmarl_step.hip"
 
 namespace fmarl {
@@ -133,10 +134,11 @@ __device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *
 }
 
 template <int G>
-__device__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv) {
+__device__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool only_flagged) {
     const int group = threadIdx.x / G, ngroups = kThreads / G, lane = threadIdx.x % G;
     for (int el = group; el < nenv; el += ngroups) {
         const FairNavLds t(p, lds, el);
+        if (only_flagged && t.skip()) continue;   // (group-uniform)
         double c[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) c[j] = (lane < p.N && j < p.N) ? t.D()[lane * p.L + j] : 0.0;
@@ -145,10 +147,34 @@ __device__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv) {
     }
 }
 
+// Placement table of the in-kernel reset (fmarl_reset.hip place_env): the env's own LDS entity table in float64.
+struct PlacedEnvLds {
+    double2 *pos;
+    const Params &p;
+    int env;
+    __device__ double2 g_obstacle(int k) const { return pos[p.N + p.L + k]; }
+    __device__ double2 g_agent(int k) const { return pos[k]; }
+    __device__ double2 g_landmark(int k) const { return pos[p.N + k]; }
+    __device__ void set_obstacle(int k, double2 x) { pos[p.N + p.L + k] = x; p.obstacle_pos[(size_t)env * p.O + k] = x; }
+    __device__ void set_agent(int k, double2 x) { pos[k] = x; p.agent_pos[(size_t)env * p.N + k] = x; }
+    __device__ void set_landmark(int k, double2 x) { pos[p.N + k] = x; p.landmark_pos[(size_t)env * p.L + k] = x; }
+    __device__ bool any_closer(int kind, int k, double2 x, double thr) const {
+        bool hit = false;
+        for (int j = 0; j < k; ++j)
+            hit |= closer_than(kind == 0 ? g_obstacle(j) : (kind == 1 ? g_agent(j) : g_landmark(j)), x, thr);
+        return hit;
+    }
+};
+
+// One pass over the workgroup's envs.
+//   STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877); returns, per lane, whether the lane's
+//                 env has ended (all agents done) and auto_reset asks for its reset
+//   STEP = false: observation of freshly reset envs (MultiAgentGraphEnv.reset, environment.py:892-897).  `second`:
+//                 called by the step kernel itself for the envs that just ended (`flagged_in`), right after their
+//                 placement; the fair assignment of the new episode is then solved here as well (nf:469).
 template <bool STEP>
-__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
-                                                           const float *action_vec, int auto_reset) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+__device__ bool fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
+                             const float *action_vec, int auto_reset, bool second, bool flagged_in) {
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int env0 = blockIdx.x * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
@@ -169,8 +195,10 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         step = p.cur_step[env] + (STEP ? 1 : 0);
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
+    const bool flagged = STEP ? false : (second ? flagged_in : (active && p.reset_flag[env] != 0));
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
-    if (!STEP && !__syncthreads_or(active && p.reset_flag[env] != 0)) return;
+    if (!STEP && !second && !__syncthreads_or(flagged)) return false;
+    if (!STEP && active && i == 0) *t.flag() = flagged ? 0 : 1;   // (a step knows it once the agents' done flags are in)
     load_statics(p, lds, env0, nenv);
     __syncthreads();
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
@@ -185,11 +213,15 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         t.minprox()[i] = m;
     }
     __syncthreads();
-    if (STEP && !FMARL_SKIP(p, 64)) {   // reward(agent 0): lexicographic-fair re-assignment on the new positions (nf:704-721)
-        if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv);
-        else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv);
-        else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv);
-        else fairnav_assign_tasks<32>(p, lds, nenv);
+    if ((STEP || second) && !FMARL_SKIP(p, 64)) {
+        // step: reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721);
+        // in-kernel reset: the assignment of the new episode (nf:469), for the envs that were just placed
+        if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv, !STEP);
+        else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv, !STEP);
+        else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv, !STEP);
+        else fairnav_assign_tasks<32>(p, lds, nenv, !STEP);
+        __syncthreads();
+        if (!STEP && active && flagged) p.goal_match[g] = t.match()[i];
     } else if (active) {
         t.match()[i] = p.goal_match[g];
     }
@@ -223,10 +255,11 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         t.agentf()[i] = make_float4((float)v.x, (float)v.y, newly ? 1.f : 0.f, 0.f);
     }
     __syncthreads();
-    bool emit = false;
+    bool emit = false, ended = false;
     if (active) {
-        emit = STEP ? !(auto_reset && t.words()[1] != 0) : p.reset_flag[env] != 0;
-        if (i == 0) *t.flag() = emit ? 0 : 1;
+        ended = STEP && auto_reset && t.words()[1] != 0;
+        emit = STEP ? !ended : flagged;
+        if (STEP && i == 0) *t.flag() = emit ? 0 : 1;
     }
 
     // ---- the sequential part: occupancy / history walk in agent order
@@ -336,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         }
     }
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
-    if (FMARL_SKIP(p, 32)) return;
+    if (FMARL_SKIP(p, 32)) return ended;
     if (o.node_obs) {
         // one lane per (ego, entity) row: the 13 features share their loads; the rows leave through the waves' LDS
         // windows (fmarl_step.hip flush_rows) unless some env of the workgroup keeps its previous rows
@@ -367,6 +400,35 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
         }
     }
     if (o.adj) emit_adj_generic(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    return ended;
+}
+
+// STEP = true : one env step; envs whose agents are all done (stop-on-goal `status` or the episode length) are reset
+//               HERE when auto_reset is set (the vec-env worker's behaviour, env_wrappers.py:859-865): placement by one
+//               lane per ended env on the env's LDS entity table, then the reset pass over those envs.  Episodes of this
+//               scenario end env by env, at any step: a reset pipeline of its own would have to be launched behind every
+//               step (three launches that nearly always find nothing to do: 31 % of the step time at 65 536 x 3).
+// STEP = false: the observation part of an explicit reset (fmarl_reset: placement and assignment by their own kernels).
+template <bool STEP>
+__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                           const float *action_vec, int auto_reset) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const bool ended = fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset, false, false);
+    if (!STEP) return;
+    if (!__syncthreads_or(ended)) return;   // (every lane of an env agrees; block-uniform)
+    const int N = p.N, tid = threadIdx.x;
+    const int env0 = blockIdx.x * p.epb, nenv = min(p.epb, p.n_envs - env0);
+    const int el = tid / N, i = tid - el * N;
+    if (el < nenv && i == 0) {
+        p.reset_flag[env0 + el] = ended ? 1 : 0;
+        if (ended) {
+            PlacedEnvLds pl{FairNavLds(p, lds, el).pos(), p, env0 + el};
+            place_env(p, pl, kResetAuto, env0 + el, false);
+        }
+    }
+    __threadfence_block();   // the reset pass re-reads the state of the placed envs from global memory
+    __syncthreads();
+    fairnav_pass<false>(p, o, lds, nullptr, nullptr, 0, true, ended);
 }
 
 }  // namespace fmarl

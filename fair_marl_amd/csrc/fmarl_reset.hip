@@ -61,8 +61,8 @@ struct Placed {
 };
 
 // navigation_graph.py:650-684 is_obstacle_collision(pos, size = 0.05)
-template <bool LDS>
-__device__ bool obstacle_hit(const Params &p, const Placed<LDS> &pl, const double *wall, double2 x) {
+template <class PL>
+__device__ bool obstacle_hit(const Params &p, const PL &pl, const double *wall, double2 x) {
     const bool plain = p.scenario == FMARL_SCENARIO_FORMATION;   // fair_graph_formation.py:518-530: no 1.05 factors
     const bool fairnav = p.scenario == FMARL_SCENARIO_FAIRNAV;   // nav_fairassign_...py:592-613: 2.0 (s+s), walls +-1.5 s
     bool hit = pl.any_closer(0, p.O, x, (fairnav ? 2.0 : 1.05) * (kEntitySize + kEntitySize));
@@ -77,31 +77,14 @@ __device__ bool obstacle_hit(const Params &p, const Placed<LDS> &pl, const doubl
     return hit;
 }
 
-template <bool LDS>
-__global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, const uint8_t *mask) {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env >= p.n_envs) return;
-    // kResetStage: the position / wall / goal_match pointers of `p` are bound to the staging fields and
-    // only placement is done (for envs without valid staged data); everything else belongs to the commit.
-    const bool stage = mode == kResetStage;
-    bool doit = true;
-    if (mode == kResetMask) doit = mask[env] != 0;
-    else if (mode == kResetAuto) {   // all agents done (environment.py:237-247: status or episode length)
-        doit = p.cur_step[env] >= p.episode_length;
-        if (!doit && p.scenario == FMARL_SCENARIO_FAIRNAV) {
-            doit = true;
-            for (int i = 0; i < p.N; ++i) doit &= p.status[(size_t)env * p.N + i] != 0.0;
-        }
-    } else if (stage) doit = p.stage_valid[env] == 0;
-    if (stage) p.stage_need[env] = doit ? 1 : 0;
-    else p.reset_flag[env] = doit ? 1 : 0;
-    if (!doit) return;
-    if (!stage) p.stage_valid[env] = 0;   // a synchronous reset consumes this episode index: staged data is stale
-
+// reset_world + random_scenario of ONE env by the calling lane (navigation_graph.py:212-575 and the two formation
+// scenarios' variants): Philox draws in the reference's draw order, rejection sampling through `pl` (where the placed
+// positions are kept for the tests), per-agent vectors reset.  Shared by reset_place_kernel and the in-kernel reset of
+// fairnav_kernel (fmarl_fairnav.hip).  `stage`: positions only, into the staging fields `p` is bound to.
+template <class PL>
+__device__ void place_env(const Params &p, PL &pl, int mode, int env, bool stage) {
     const int N = p.N, L = p.L;
     const size_t a0 = (size_t)env * N;
-    Placed<LDS> pl{(float2 *)lds_raw, p, env, (int)threadIdx.x};
     int episode = 0;
     if (mode == kResetInit) {
         for (int i = 0; i < N; ++i) { p.goal_match[a0 + i] = i; p.min_time[a0 + i] = __builtin_huge_val(); }
@@ -188,6 +171,32 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
             p.min_time[a0 + i] = dist2(pl.g_agent(i), pl.g_landmark(p.goal_match[a0 + i])) / p.max_speed;
     }
     p.episode[env] = episode + 1;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, const uint8_t *mask) {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.n_envs) return;
+    // kResetStage: the position / wall / goal_match pointers of `p` are bound to the staging fields and
+    // only placement is done (for envs without valid staged data); everything else belongs to the commit.
+    const bool stage = mode == kResetStage;
+    bool doit = true;
+    if (mode == kResetMask) doit = mask[env] != 0;
+    else if (mode == kResetAuto) {   // all agents done (environment.py:237-247: status or episode length)
+        doit = p.cur_step[env] >= p.episode_length;
+        if (!doit && p.scenario == FMARL_SCENARIO_FAIRNAV) {
+            doit = true;
+            for (int i = 0; i < p.N; ++i) doit &= p.status[(size_t)env * p.N + i] != 0.0;
+        }
+    } else if (stage) doit = p.stage_valid[env] == 0;
+    if (stage) p.stage_need[env] = doit ? 1 : 0;
+    else p.reset_flag[env] = doit ? 1 : 0;
+    if (!doit) return;
+    if (!stage) p.stage_valid[env] = 0;   // a synchronous reset consumes this episode index: staged data is stale
+
+    Placed<LDS> pl{(float2 *)lds_raw, p, env, (int)threadIdx.x};
+    place_env(p, pl, mode, env, stage);
 }
 
 // Asynchronous reset, step 2 of 2: make the staged episode the live one for the selected envs

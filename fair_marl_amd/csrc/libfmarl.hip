@@ -480,7 +480,9 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     HIP_OK(hipGetLastError());
     if (h->lockstep) ++h->host_step;
     h->episode_started = false;
-    if (auto_reset) {
+    if (auto_reset && p.scenario == FMARL_SCENARIO_FAIRNAV) {
+        h->episode_started = true;   // this scenario's episodes end env by env: fairnav_kernel<true> resets them itself
+    } else if (auto_reset) {
         const bool may_reset = !h->lockstep || h->host_step >= h->cfg.episode_length;
         if (may_reset) {
             int rc = launch_reset(h, state, kResetAuto, nullptr, outs, st);
