@@ -11,7 +11,7 @@ INFO_WIDTH = 14
  F_WALL_ORIENT, F_WALL_LENGTH, F_GOAL_MATCH, F_DISTS_TO_GOAL, F_TIMES_REQUIRED, F_DIST_LEFT,
  F_NUM_OBST_COLL, F_NUM_AGENT_COLL, F_MIN_TIME, F_CUR_STEP, F_EPISODE, F_SLOT_POS, F_SLOT_OCC,
  F_SLOT_DELTA, F_FORMATION_DONE, F_GOAL_OCC, F_GOAL_HISTORY, F_GOAL_REACHED, F_STATUS, F_RESET_FLAG, F_STAGE_AGENT_POS, F_STAGE_LANDMARK_POS, F_STAGE_OBSTACLE_POS,
- F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, F_MATCH_DUAL, NUM_FIELDS) = range(38)
+ F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, F_PLACE_FAILS, F_STAGE_PLACE_FAILS, F_MATCH_DUAL, NUM_FIELDS) = range(40)
 FLAG_ASYNC_RESET = 1
 FLAG_GLOBAL_FEATURES = 2
 FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_e0',
@@ -20,7 +20,7 @@ FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos
                'slot_pos', 'slot_occ', 'slot_delta', 'formation_done', 'goal_occ', 'goal_history', 'goal_reached', 'status',
                'reset_flag', 'stage_agent_pos',
                'stage_landmark_pos', 'stage_obstacle_pos', 'stage_wall_axis', 'stage_wall_orient', 'stage_goal_match',
-               'stage_valid', 'stage_need', 'internal_match_dual')
+               'stage_valid', 'stage_need', 'place_fails', 'stage_place_fails', 'internal_match_dual')
 DTYPE_F64, DTYPE_I32 = 0, 1
 SCENARIOS = {'navigation_graph': 0, 'fair_graph_formation': 1, 'nav_fairassign_fairrew_formation_graph': 2}
 
@@ -37,7 +37,7 @@ class FmarlConfig(C.Structure):
 
 class FmarlOutputs(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('node_obs', C.c_void_p), ('adj', C.c_void_p), ('reward', C.c_void_p),
-                ('done', C.c_void_p), ('info', C.c_void_p)]
+                ('done', C.c_void_p), ('info', C.c_void_p), ('edge_nnz', C.c_void_p)]
 
 
 _SIGS = {
@@ -65,6 +65,8 @@ _SIGS = {
     'fmarl_edge_count': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     'fmarl_edge_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                   C.c_double, C.c_int, C.c_void_p]),
+    'fmarl_edge_offsets': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'fmarl_edge_fill_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'fmarl_episode_record_words': (C.c_size_t, [C.POINTER(FmarlConfig)]),
     'fmarl_episode_started': (C.c_int, [C.c_void_p]),
     'fmarl_pack_episode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -49,6 +49,7 @@ struct Params {
     int lds_posf, has_posf;  // navigation_graph: f32 copy of the entity positions (adj is computed from it)
     int lds_wallf, lds_constf;   // navigation_graph: f32 wall corner words (4 per wall) and the constants 0, 1, 2, 3
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
+    float edge_thr;          // (float)max_edge_dist: the policy-edge threshold of the fused processAdj count
     uint64_t seed;
     FastDiv dNEF, dEF, dF, dEE, dE, dNE, dC4, dNC4, dEE4, dE4;
     int ablate;              // -DFMARL_MEASURE builds only (tools/ablate.sh): bit mask of phases to skip
@@ -72,6 +73,7 @@ struct Params {
     double2 *st_agent_pos, *st_landmark_pos, *st_obstacle_pos;
     double *st_wall_axis;
     int *st_wall_orient, *st_goal_match, *stage_valid, *stage_need;
+    int *place_fails, *st_place_fails;   // placements accepted after kMaxTries colliding draws (live / staged episode)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10 (oracle/philox.py)

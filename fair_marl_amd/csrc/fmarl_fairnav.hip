@@ -173,7 +173,7 @@ struct PlacedEnvLds {
 //                 called by the step kernel itself for the envs that just ended (`flagged_in`), right after their
 //                 placement; the fair assignment of the new episode is then solved here as well (nf:469).
 template <bool STEP>
-__device__ bool fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
+__device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
                              const float *action_vec, int auto_reset, bool second, bool flagged_in) {
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int env0 = blockIdx.x * p.epb;
@@ -399,7 +399,7 @@ __device__ bool fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, 
             }
         }
     }
-    if (o.adj) emit_adj_generic(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    emit_adj<false>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
     return ended;
 }
 

@@ -117,7 +117,112 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const float *adj, const 
         const unsigned long long m = __ballot(on);
         if (on) {
             const int64_t k = base + __popcll(m & ((1ull << lane) - 1));
-            rows[k] = node0 + q / E; cols[k] = node0 + q % E; edge_attr[k] = d;
+            if (k < total) { rows[k] = node0 + q / E; cols[k] = node0 + q % E; edge_attr[k] = d; }   // total = capacity of the buffers
+        }
+        base += __popcll(m);
+    }
+}
+
+// Exclusive prefix sum of the per-graph edge counts, int32 counts -> int64 offsets (n_graphs + 1), graph b counting
+// nnz[b / graphs_per_env].  Three small launches, no scratch memory: the chunk totals are parked in the offsets array
+// itself, at the position where the prefix of the NEXT chunk belongs.
+constexpr int kScanChunk = 2048;   // graphs per workgroup (256 threads x 8)
+
+__global__ __launch_bounds__(256) void edge_scan_totals_kernel(const int32_t *nnz, int n_graphs, int gpe, int64_t *offsets) {
+    __shared__ int64_t part[256];
+    const int c0 = blockIdx.x * kScanChunk;
+    int64_t s = 0;
+    for (int k = threadIdx.x; k < kScanChunk; k += 256) {
+        const int b = c0 + k;
+        if (b < n_graphs) s += nnz[b / gpe];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[min(c0 + kScanChunk, n_graphs)] = part[0];
+}
+
+// one workgroup: running sum over the chunk boundaries (at most a few thousand), offsets[0] = 0
+__global__ __launch_bounds__(256) void edge_scan_chunks_kernel(int n_graphs, int64_t *offsets) {
+    __shared__ int64_t part[256];
+    __shared__ int64_t carry;
+    const int n_chunks = (n_graphs + kScanChunk - 1) / kScanChunk;
+    if (threadIdx.x == 0) { carry = 0; offsets[0] = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_chunks; base += 256) {
+        const int c = base + threadIdx.x;
+        const size_t pos = (size_t)min((c + 1) * kScanChunk, n_graphs);
+        const int64_t v = c < n_chunks ? offsets[pos] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {   // inclusive Hillis-Steele scan of the 256 totals
+            const int64_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (c < n_chunks) offsets[pos] = carry + part[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_scan_fill_kernel(const int32_t *nnz, int n_graphs, int gpe, int64_t *offsets) {
+    __shared__ int64_t part[256];
+    const int c0 = blockIdx.x * kScanChunk, t0 = c0 + threadIdx.x * 8;
+    int64_t v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int b = t0 + k; v[k] = b < n_graphs ? nnz[b / gpe] : 0; s += v[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int64_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int64_t run = offsets[c0] + part[threadIdx.x] - s;   // prefix of this thread's first graph
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int b = t0 + k;
+        // (the boundary entries c0 and c0 + kScanChunk already hold their final values)
+        if (b < n_graphs && b != c0) offsets[b] = run;
+        run += v[k];
+    }
+}
+
+// processAdj from the world state: one wave per graph recomputes the env's adj entries exactly as
+// the emission did -- float32 roundings of the entity positions (navigation_graph, fair_graph_formation) or the float32
+// rounding of the float64 differences (fairnav) -- and compacts the policy edges 0 < d < max_edge_dist in row-major
+// order behind offsets[b]: rows | cols with node ids b * E + r, edge_attr = the adj entry.  adj is not read.
+__global__ __launch_bounds__(256) void edge_fill_state_kernel(Params p, const int64_t *offsets, int64_t *edge_index,
+                                                              float *edge_attr, int64_t capacity, int gpe) {
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= p.n_envs * gpe) return;   // wave-uniform
+    const int env = b / gpe, E = p.E, EE = E * E;
+    int64_t *rows = edge_index, *cols = edge_index + capacity;
+    int64_t base = offsets[b];
+    const int64_t node0 = (int64_t)b * E;
+    for (int q0 = 0; q0 < EE; q0 += 64) {
+        const int q = q0 + lane;
+        float d = 0.f;
+        int r = 0, c = 0;
+        if (q < EE) {
+            r = q / E; c = q - r * E;
+            const double2 a = entity_pos(p, env, r), bb = entity_pos(p, env, c);
+            d = p.has_posf ? dist_f32((float)a.x - (float)bb.x, (float)a.y - (float)bb.y)
+                           : dist_f32((float)(a.x - bb.x), (float)(a.y - bb.y));
+        }
+        const bool on = q < EE && d > 0.f && d < p.edge_thr;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int64_t k = base + __popcll(m & ((1ull << lane) - 1));
+            if (k < capacity) { rows[k] = node0 + r; cols[k] = node0 + c; edge_attr[k] = d; }
         }
         base += __popcll(m);
     }

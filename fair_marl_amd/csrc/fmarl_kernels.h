@@ -8,7 +8,6 @@ namespace fmarl {
 __global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
                             int auto_reset);
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv);
-__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin, int el_end, uint32_t thr, uint32_t nthr);
 __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
 
 // fmarl_reset.hip
@@ -38,6 +37,10 @@ __global__ void update_graph_kernel(const float *adj, int32_t *edge_index, float
 
 __global__ void update_graph_state_kernel(Params p, int32_t *edge_index, double *edge_weight, int32_t *nnz, double max_edge_dist);
 
+__global__ void edge_scan_totals_kernel(const int32_t *nnz, int n_graphs, int gpe, int64_t *offsets);
+__global__ void edge_scan_chunks_kernel(int n_graphs, int64_t *offsets);
+__global__ void edge_scan_fill_kernel(const int32_t *nnz, int n_graphs, int gpe, int64_t *offsets);
+__global__ void edge_fill_state_kernel(Params p, const int64_t *offsets, int64_t *edge_index, float *edge_attr, int64_t capacity, int gpe);
 __global__ void info_mean_kernel(const float *info, double *out, int n_envs, int N, double unreached_time);
 __global__ void edge_count_kernel(const float *adj, int32_t *nnz, int n_envs, int E, float thr, int strict);
 __global__ void edge_fill_kernel(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr,

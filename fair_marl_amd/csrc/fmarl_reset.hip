@@ -62,7 +62,7 @@ struct Placed {
 
 // navigation_graph.py:650-684 is_obstacle_collision(pos, size = 0.05)
 template <class PL>
-__device__ bool obstacle_hit(const Params &p, const PL &pl, const double *wall, double2 x) {
+__device__ __forceinline__ bool obstacle_hit(const Params &p, const PL &pl, const double *wall, double2 x) {
     const bool plain = p.scenario == FMARL_SCENARIO_FORMATION;   // fair_graph_formation.py:518-530: no 1.05 factors
     const bool fairnav = p.scenario == FMARL_SCENARIO_FAIRNAV;   // nav_fairassign_...py:592-613: 2.0 (s+s), walls +-1.5 s
     bool hit = pl.any_closer(0, p.O, x, (fairnav ? 2.0 : 1.05) * (kEntitySize + kEntitySize));
@@ -82,7 +82,7 @@ __device__ bool obstacle_hit(const Params &p, const PL &pl, const double *wall, 
 // positions are kept for the tests), per-agent vectors reset.  Shared by reset_place_kernel and the in-kernel reset of
 // fairnav_kernel (fmarl_fairnav.hip).  `stage`: positions only, into the staging fields `p` is bound to.
 template <class PL>
-__device__ void place_env(const Params &p, PL &pl, int mode, int env, bool stage) {
+__device__ __forceinline__ void place_env(const Params &p, PL &pl, int mode, int env, bool stage) {
     const int N = p.N, L = p.L;
     const size_t a0 = (size_t)env * N;
     int episode = 0;
@@ -124,12 +124,14 @@ __device__ void place_env(const Params &p, PL &pl, int mode, int env, bool stage
     }
     const double thr = 1.05 * (kEntitySize + kEntitySize);
     const double thr_goal = (fairnav ? 1.2 : 1.05) * (kEntitySize + kEntitySize);   // nav_fairassign_...py:643
+    int fails = 0;   // placements accepted with every draw colliding (the reference would still be drawing)
     for (int k = 0, tries = 0; k < N;) {   // :389-457
         double2 x = rng.uniform_pair(-ws / 2, ws / 2);
         ++tries;
         bool bad = obstacle_hit(p, pl, wall, x);
         bad |= pl.any_closer(1, k, x, thr);   // :689-698
         if (!bad || tries >= kMaxTries) {
+            fails += bad ? 1 : 0;
             pl.set_agent(k, x);
             if (!stage) p.agent_vel[a0 + k] = make_double2(0.0, 0.0);
             ++k; tries = 0;
@@ -141,8 +143,9 @@ __device__ void place_env(const Params &p, PL &pl, int mode, int env, bool stage
         ++tries;
         bool bad = obstacle_hit(p, pl, wall, x);
         bad |= pl.any_closer(2, k, x, thr_goal);   // :707-716
-        if (!bad || tries >= kMaxTries) { pl.set_landmark(k, x); ++k; tries = 0; }
+        if (!bad || tries >= kMaxTries) { fails += bad ? 1 : 0; pl.set_landmark(k, x); ++k; tries = 0; }
     }
+    p.place_fails[env] = fails;   // (staging: `p` is bound to the staging twin, committed with the rest)
     if (stage) return;   // min_time, episode counter: reset_commit_kernel
     if (formation) {
         // fair_graph_formation.py:394-417: slots on the circle about landmark 0, occupancy cleared;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void reset_commit_kernel(Params p, int mo
         p.wall_axis[gw] = p.st_wall_axis[gw]; p.wall_orient[gw] = p.st_wall_orient[gw];
         p.wall_e0[gw] = -p.wall_length[env]; p.wall_e1[gw] = p.wall_length[env];
     }
-    if (i == 0) { p.cur_step[env] = 0; p.episode[env] += 1; p.stage_valid[env] = 0; }
+    if (i == 0) { p.cur_step[env] = 0; p.episode[env] += 1; p.stage_valid[env] = 0; p.place_fails[env] = p.st_place_fails[env]; }
 }
 
 // Asynchronous reset, staging side: placement + assignment done -> the staged data is valid.

@@ -181,9 +181,31 @@ __device__ __forceinline__ void flush_rows(const Params &p, char *lds, const flo
 // adj for any E: a lane owns one 16-byte aligned chunk of the workgroup's region (4 entries, possibly of two rows
 // or envs), computes |x_a - x_b| for each and stores 16 bytes; the ragged ends and chunks that touch an env which
 // keeps its previous matrix fall back to 4-byte stores.  Shared by the three scenarios (same LDS tables).
+// Fused processAdj count (onpolicy/algorithms/utils/gnn.py:307-326): while a lane walks its chunks
+// of the adj region it counts the entries with 0 < d < max_edge_dist; the chunks of one env are consecutive, so the lane
+// hands its subtotal to the env's LDS counter only when it moves on to the next env.
+struct EdgeCount {   // plain values only (no reference to the kernel's Params: that would pin the struct in scratch memory)
+    const char *slots;   // counter of env 0 of the workgroup; the others follow at a stride of lds_env_bytes
+    int stride, cur, cnt;
+    float thr;
+    __device__ __forceinline__ EdgeCount(const Params &p, const char *lds)
+        : slots(lds + p.lds_flag + 16), stride(p.lds_env_bytes), cur(-1), cnt(0), thr(p.edge_thr) {}
+    __device__ __forceinline__ int *slot(int el) const { return (int *)(slots + (size_t)el * stride); }
+    __device__ __forceinline__ void add(int el, float d) {
+        if (el != cur) { flush(); cur = el; }
+        cnt += (d > 0.f && d < thr) ? 1 : 0;
+    }
+    __device__ __forceinline__ void flush() { if (cnt) atomicAdd(slot(cur), cnt); cnt = 0; }
+};
+// `nthr` == 64: the caller is one wave that owns its envs (wave-local ordering); otherwise the whole workgroup
+__device__ __forceinline__ void emit_sync(uint32_t nthr) {
+    if (nthr == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
 // The caller's `nthr` threads (index `thr`) emit the envs [el_begin, el_end) of the workgroup.
-__device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin, int el_end,
-                                 uint32_t thr, uint32_t nthr) {
+__device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
+                                                 int el_end, uint32_t thr, uint32_t nthr, EdgeCount &ec, bool count) {
     const uint32_t EE = p.E * p.E, total = (el_end - el_begin) * EE;
     float *dst = o.adj + ((size_t)env0 + el_begin) * EE;
     const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 3), end = shift + total;
@@ -208,6 +230,7 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
                     const double2 pa = t.pos()[a], pb = t.pos()[b];
                     v[j] = dist_f32((float)(pa.x - pb.x), (float)(pa.y - pb.y));
                 }
+                if (count) ec.add((int)el, v[j]);
             }
         }
         if (ok[0] & ok[1] & ok[2] & ok[3]) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
@@ -220,11 +243,20 @@ __device__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const c
 }
 
 // adj of the envs [el_begin, el_end) of the workgroup by `nthr` threads: the 16-byte path when E % 4 == 0 and the f32
-// position table exists, else the generic one.
-__device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin, int el_end,
-                         uint32_t thr, uint32_t nthr) {
+// position table exists, else the generic one; with FmarlOutputs.edge_nnz also every emitted env's policy-edge count.
+// CAN_VEC = false: the caller's scenario never has the float32 position table (fairnav), so the 16-byte path is not compiled in.
+template <bool CAN_VEC = true>
+__device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
+                                         int el_end, uint32_t thr, uint32_t nthr) {
+    if (!o.adj) return;
     const uint32_t EE = p.E * p.E;
-    if (o.adj && p.vec_adj) {
+    const bool count = o.edge_nnz != nullptr;   // (uniform)
+    EdgeCount ec(p, lds);
+    if (count) {
+        for (int el = el_begin + (int)thr; el < el_end; el += nthr) *ec.slot(el) = 0;
+        emit_sync(nthr);
+    }
+    if (CAN_VEC && p.vec_adj) {
         // 16-byte path (E % 4 == 0): the threads stream the region front to back (a workgroup's four waves write one
         // 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32 position table (the roundings
         // node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
@@ -237,11 +269,19 @@ __device__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds
             const uint32_t a = p.dE4.div(r), b4 = r - a * E4;
             const float2 pa = t.posf()[a];
             const float4 q0 = ((const float4 *)t.posf())[b4 * 2], q1 = ((const float4 *)t.posf())[b4 * 2 + 1];
-            dst[m] = make_float4(dist_f32(pa.x - q0.x, pa.y - q0.y), dist_f32(pa.x - q0.z, pa.y - q0.w),
-                                 dist_f32(pa.x - q1.x, pa.y - q1.y), dist_f32(pa.x - q1.z, pa.y - q1.w));
+            const float4 d = make_float4(dist_f32(pa.x - q0.x, pa.y - q0.y), dist_f32(pa.x - q0.z, pa.y - q0.w),
+                                         dist_f32(pa.x - q1.x, pa.y - q1.y), dist_f32(pa.x - q1.z, pa.y - q1.w));
+            dst[m] = d;
+            if (count) { ec.add((int)el, d.x); ec.add((int)el, d.y); ec.add((int)el, d.z); ec.add((int)el, d.w); }
         }
-    } else if (o.adj) {
-        emit_adj_generic(p, o, lds, env0, el_begin, el_end, thr, nthr);
+    } else {
+        emit_adj_generic(p, o, lds, env0, el_begin, el_end, thr, nthr, ec, count);
+    }
+    if (count) {
+        ec.flush();
+        emit_sync(nthr);
+        for (int el = el_begin + (int)thr; el < el_end; el += nthr)
+            if (!EnvLds(p, lds, el).skip()) o.edge_nnz[env0 + el] = *ec.slot(el);
     }
 }
 

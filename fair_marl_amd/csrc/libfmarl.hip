@@ -99,6 +99,8 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     set(FMARL_F_STAGE_GOAL_MATCH, async ? n * N : 0, FMARL_DTYPE_I32);
     set(FMARL_F_STAGE_VALID, n, FMARL_DTYPE_I32);
     set(FMARL_F_STAGE_NEED, n, FMARL_DTYPE_I32);
+    set(FMARL_F_PLACE_FAILS, n, FMARL_DTYPE_I32);
+    set(FMARL_F_STAGE_PLACE_FAILS, async ? n : 0, FMARL_DTYPE_I32);
     set(FMARL_F_MATCH_DUAL, form ? n * N : 0, FMARL_DTYPE_F64);
     size_t off = 0;
     for (int f = 0; f < FMARL_NUM_FIELDS; ++f) {
@@ -166,6 +168,7 @@ Params bind(const Handle *h, void *state) {
     p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
     p.stage_valid = (int *)(s + o[FMARL_F_STAGE_VALID]);            p.stage_need = (int *)(s + o[FMARL_F_STAGE_NEED]);
     p.match_dual = (double *)(s + o[FMARL_F_MATCH_DUAL]);
+    p.place_fails = (int *)(s + o[FMARL_F_PLACE_FAILS]);             p.st_place_fails = (int *)(s + o[FMARL_F_STAGE_PLACE_FAILS]);
     return p;
 }
 
@@ -188,7 +191,7 @@ int launch_stage(Handle *h, void *state, hipStream_t st) {
     Params q = p;   // same kernels, pointers bound to the staging fields
     q.agent_pos = p.st_agent_pos; q.landmark_pos = p.st_landmark_pos; q.obstacle_pos = p.st_obstacle_pos;
     q.wall_axis = p.st_wall_axis; q.wall_orient = p.st_wall_orient; q.goal_match = p.st_goal_match;
-    q.reset_flag = p.stage_need;
+    q.reset_flag = p.stage_need; q.place_fails = p.st_place_fails;
     launch_place(h, q, kResetStage, nullptr, h->side);
     launch_lexifair_state(q, h->side);
     hipLaunchKernelGGL(stage_finish_kernel, dim3((p.n_envs + 255) / 256), dim3(256), 0, h->side, p);
@@ -275,6 +278,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.world_size = cfg->world_size; p.max_speed = cfg->max_speed; p.collision_rew = cfg->collision_rew;
     p.goal_rew = cfg->goal_rew; p.thr = cfg->min_dist_thresh; p.fair_rew = cfg->fair_rew; p.zeroshift = cfg->zeroshift;
     p.seed = cfg->seed;
+    p.edge_thr = (float)cfg->max_edge_dist;
     // per-env LDS layout (fmarl_step.hip EnvLds)
     int off = 0;
     p.lds_pos = off;    off = align16(off + p.E * 16);
@@ -283,7 +287,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
     p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 2 * p.N * 8 + 4 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
-    p.lds_flag = off;   off = align16(off + 16);   // flag + three scenario words
+    p.lds_flag = off;   off = align16(off + 20);   // flag + three scenario words + the env's policy-edge counter
     p.has_posf = !fnav;   // f32 copy of the entity positions: adj (and the formation scenario's node rows) start from it
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     p.lds_wallf = off;  off = align16(off + (p.has_posf ? p.W * 16 : 0));
@@ -581,6 +585,34 @@ int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_inde
         return fail(FMARL_EINVAL, "fmarl_edge_fill: bad argument");
     hipLaunchKernelGGL(edge_fill_kernel, dim3((n_graphs + 3) / 4), dim3(256), 0, (hipStream_t)stream, adj, offsets,
                        edge_index, edge_attr, total, n_graphs, graphs_per_env, num_entities, (float)max_edge_dist, strict);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_edge_offsets(const int32_t *nnz, int n_envs, int graphs_per_env, int64_t *offsets, void *stream) {
+    if (!nnz || !offsets || n_envs < 1 || graphs_per_env < 1 || (int64_t)n_envs * graphs_per_env > 0x7fffffff)
+        return fail(FMARL_EINVAL, "fmarl_edge_offsets: bad argument");
+    const int n_graphs = n_envs * graphs_per_env, chunks = (n_graphs + kScanChunk - 1) / kScanChunk;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(edge_scan_totals_kernel, dim3(chunks), dim3(256), 0, st, nnz, n_graphs, graphs_per_env, offsets);
+    hipLaunchKernelGGL(edge_scan_chunks_kernel, dim3(1), dim3(256), 0, st, n_graphs, offsets);
+    hipLaunchKernelGGL(edge_scan_fill_kernel, dim3(chunks), dim3(256), 0, st, nnz, n_graphs, graphs_per_env, offsets);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offsets, int64_t *edge_index, float *edge_attr,
+                          int64_t capacity, int graphs_per_env, void *stream) {
+    Handle *h = (Handle *)handle;
+    DeviceGuard on_device(h);
+    if (!h || !state || !offsets || capacity < 0 || graphs_per_env < 1 || (capacity > 0 && (!edge_index || !edge_attr)))
+        return fail(FMARL_EINVAL, "fmarl_edge_fill_state: bad argument");
+    if (capacity == 0) return FMARL_OK;
+    Params p = bind(h, (void *)state);
+    const int64_t graphs = (int64_t)p.n_envs * graphs_per_env;
+    if (graphs > 0x7fffffff / 64) return fail(FMARL_EINVAL, "fmarl_edge_fill_state: too many graphs");
+    hipLaunchKernelGGL(edge_fill_state_kernel, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, offsets,
+                       edge_index, edge_attr, capacity, graphs_per_env);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

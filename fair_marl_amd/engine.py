@@ -20,12 +20,12 @@ _TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32}
 
 class OutputSet(object):
     """obs / reward / done / info tensors of one step + the FmarlOutputs struct pointing at them."""
-    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'c')
+    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'edge_nnz', 'c')
 
 
 class RolloutEngine:
     def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True,
-                 emit_graph=True, tune_placement=None):
+                 emit_graph=True, tune_placement=None, count_edges=False):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_args(cfg)
         cfg.validate()
@@ -52,6 +52,8 @@ class RolloutEngine:
             self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device) if emit_graph else None
             self.agent_id = torch.arange(N, device=self.device).view(1, N, 1).expand(n, N, 1)
         self.emit_info, self.emit_graph = emit_info, emit_graph
+        # count_edges: the adj emission also counts every env's policy edges (process_adj then never reads adj back)
+        self.count_edges = bool(count_edges and emit_graph)
         self.placement_ms = None
         if tune_placement is None:   # worth it once the graph outputs are GBs (the step is then bound by their store stream)
             tune_placement = 6 if emit_graph and cfg.scenario_name == 'navigation_graph' and n * N * E * F * 4 >= (1 << 30) else 0
@@ -136,6 +138,7 @@ class RolloutEngine:
             o.info = o.info_planes.permute(1, 2, 0) if self.emit_info else None
             o.node_obs = node_obs if node_obs is not None else self._default_graph[0]
             o.adj_env = adj_env if adj_env is not None else self._default_graph[1]
+            o.edge_nnz = torch.zeros(n, dtype=torch.int32, device=self.device) if self.count_edges else None
         E, F = self.cfg.E, self.cfg.node_feat
         for t, shape, dt in ((o.obs, (n, N, D), torch.float32), (o.reward, (n, N), torch.float32), (o.done, (n, N), torch.uint8),
                              (o.node_obs, (n, N, E, F), torch.float32), (o.adj_env, (n, E, E), torch.float32)):
@@ -146,7 +149,8 @@ class RolloutEngine:
         o.c = _lib.FmarlOutputs(o.obs.data_ptr(), o.node_obs.data_ptr() if o.node_obs is not None else None,
                                 o.adj_env.data_ptr() if o.adj_env is not None else None,
                                 o.reward.data_ptr(), o.done.data_ptr(),
-                                o.info_planes.data_ptr() if o.info_planes is not None else None)
+                                o.info_planes.data_ptr() if o.info_planes is not None else None,
+                                o.edge_nnz.data_ptr() if o.edge_nnz is not None else None)
         return o
 
     def use_outputs(self, out_set):
@@ -166,7 +170,8 @@ class RolloutEngine:
                     formation_done=(n, N), goal_occ=(n, N), goal_history=(n, N), goal_reached=(n, N), status=(n, N),
                     reset_flag=(n,), stage_agent_pos=(n, N, 2), stage_landmark_pos=(n, L, 2),
                     stage_obstacle_pos=(n, O, 2), stage_wall_axis=(n, W), stage_wall_orient=(n, W),
-                    stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,), internal_match_dual=(n, N))
+                    stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,), place_fails=(n,), stage_place_fails=(n,),
+                    internal_match_dual=(n, N))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -209,6 +214,13 @@ class RolloutEngine:
                                                         a.ctypes.data, self._stream()), 'fmarl_set_state')
             torch.cuda.current_stream(self.device).synchronize()   # host sources must outlive the copies
         _lib.check(self.lib.fmarl_state_changed(self.handle), 'fmarl_state_changed')
+
+    def placement_exhausted(self):
+        """int32 device tensor (n,): entities of each env's current episode that the reset placed although all 10 000
+        rejection-sampling draws collided with something (include/fmarl.h FMARL_F_PLACE_FAILS).  The reference loops until
+        a free spot turns up (navigation_graph.py:389-457, :472-535) -- forever in a world too crowded to have one; the
+        bounded loop accepts the last draw instead and says so here.  All zeros for any sane configuration."""
+        return self._fields['place_fails']
 
     # ------------------------------------------------------------------ hot path
     @property
@@ -299,29 +311,44 @@ class RolloutEngine:
                                                    float(self.cfg.max_edge_dist), self._stream()), 'fmarl_update_graph')
         return ei, ew, nnz
 
-    def process_adj(self, adj_env=None, per_agent=False, strict=True):
-        """Policy-side edge list (reference onpolicy/algorithms/utils/gnn.py:307-326 processAdj + the PyG
-        batching of :243-253): edges with 0 < adj < max_edge_dist in row-major order, node ids offset by
-        graph index * E.  ``per_agent=True`` replicates every env's graph N times like the reference batch
-        of (env, agent) graphs; the default emits each env's graph once.  Returns
-        (edge_index int64 (2, total), edge_attr f32 (total,), offsets int64 (n_graphs + 1))."""
-        adj = self.adj_env if adj_env is None else torch.as_tensor(adj_env).to(self.device, torch.float32).contiguous()
-        n, E = adj.shape[0], adj.shape[1]
-        reps = self.cfg.N if per_agent else 1
-        nnz = torch.empty(n, dtype=torch.int32, device=self.device)
+    def process_adj(self, adj_env=None, per_agent=False, strict=True, max_edges=None):
+        """Policy-side edge list (reference onpolicy/algorithms/utils/gnn.py:307-326 processAdj + the PyG batching of
+        :243-253): edges with 0 < adj < max_edge_dist in row-major order, node ids offset by graph index * E.
+        ``per_agent=True`` replicates every env's graph N times like the reference batch of (env, agent) graphs; the
+        default emits each env's graph once.  Returns (edge_index int64 (2, cap), edge_attr f32 (cap,), offsets int64
+        (n_graphs + 1)); ``offsets[-1]`` is the number of edges.
+
+        Without ``adj_env``, on an engine created with ``count_edges=True``, this is the fused path of SURVEY section 8 f-3:
+        the counts come from the adj emission of the last step / reset, the prefix sum runs on the device and the edges
+        are rebuilt from the world state -- adj is never read back.  ``max_edges=None`` sizes the result exactly, which
+        takes the one host read of ``offsets[-1]`` any exact-size tensor needs; with ``max_edges=K`` the buffers hold K
+        edges (extra ones are dropped, ``offsets`` still counts them) and nothing synchronises with the host.
+        With ``adj_env`` (e.g. a stored rollout slot), ``strict=False`` (update_graph's ``<=``) or without
+        ``count_edges`` the counts come from one pass over the float32 matrix and the edges from a second one."""
+        n = self.n_envs if adj_env is None else int(adj_env.shape[0])
+        E, reps = self.cfg.E, (self.cfg.N if per_agent else 1)
+        thr = float(self.cfg.max_edge_dist)
+        fused = adj_env is None and strict and self.outs.edge_nnz is not None
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fmarl_edge_count(adj.data_ptr(), nnz.data_ptr(), n, E, float(self.cfg.max_edge_dist),
-                                                 1 if strict else 0, self._stream()), 'fmarl_edge_count')
-            counts = nnz.to(torch.int64).repeat_interleave(reps)
-            offsets = torch.zeros(n * reps + 1, dtype=torch.int64, device=self.device)
-            offsets[1:] = torch.cumsum(counts, 0)
-            total = int(offsets[-1].item())
-            ei = torch.empty(2, total, dtype=torch.int64, device=self.device)
-            ea = torch.empty(total, dtype=torch.float32, device=self.device)
-            if total:
-                _lib.check(self.lib.fmarl_edge_fill(adj.data_ptr(), offsets.data_ptr(), ei.data_ptr(), ea.data_ptr(), total,
-                                                    n * reps, reps, E, float(self.cfg.max_edge_dist), 1 if strict else 0,
-                                                    self._stream()), 'fmarl_edge_fill')
+            if fused:
+                nnz = self.outs.edge_nnz
+            else:
+                adj = self.adj_env if adj_env is None else torch.as_tensor(adj_env).to(self.device, torch.float32).contiguous()
+                E = adj.shape[1]
+                nnz = torch.empty(n, dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.fmarl_edge_count(adj.data_ptr(), nnz.data_ptr(), n, E, thr, 1 if strict else 0, self._stream()),
+                           'fmarl_edge_count')
+            offsets = torch.empty(n * reps + 1, dtype=torch.int64, device=self.device)
+            _lib.check(self.lib.fmarl_edge_offsets(nnz.data_ptr(), n, reps, offsets.data_ptr(), self._stream()), 'fmarl_edge_offsets')
+            cap = int(offsets[-1].item()) if max_edges is None else int(max_edges)
+            ei = torch.empty(2, cap, dtype=torch.int64, device=self.device)
+            ea = torch.empty(cap, dtype=torch.float32, device=self.device)
+            if cap and fused:
+                _lib.check(self.lib.fmarl_edge_fill_state(self.handle, self.state.data_ptr(), offsets.data_ptr(), ei.data_ptr(),
+                                                          ea.data_ptr(), cap, reps, self._stream()), 'fmarl_edge_fill_state')
+            elif cap:
+                _lib.check(self.lib.fmarl_edge_fill(adj.data_ptr(), offsets.data_ptr(), ei.data_ptr(), ea.data_ptr(), cap, n * reps, reps, E,
+                                                    thr, 1 if strict else 0, self._stream()), 'fmarl_edge_fill')
         return ei, ea, offsets
 
     # name of every info key in env_infos, in the order process_infos fills the dict (base_runner.py:245-275)

@@ -85,6 +85,9 @@ typedef struct FmarlOutputs {
     float *reward;       /* (n, N)                                                            */
     uint8_t *done;       /* (n, N)           environment.py:237-247                           */
     float *info;         /* (FMARL_INFO_WIDTH, n, N) field-major records, FMARL_INFO_* order   */
+    int32_t *edge_nnz;   /* (n)              policy edges of the env's graph: entries of adj with 0 < d < max_edge_dist
+                                              (onpolicy/algorithms/utils/gnn.py:307-326 processAdj), counted by the adj
+                                              emission itself; needs adj.  See fmarl_edge_offsets / fmarl_edge_fill_state */
 } FmarlOutputs;
 
 #define FMARL_INFO_WIDTH 14
@@ -141,6 +144,10 @@ enum {
     FMARL_F_STAGE_GOAL_MATCH,  /* i32 (n, N)     ... including its fair assignment                         */
     FMARL_F_STAGE_VALID,       /* i32 (n)        1 = the staged data belongs to episode index `episode`    */
     FMARL_F_STAGE_NEED,        /* i32 (n)        internal: envs being staged                               */
+    FMARL_F_PLACE_FAILS,       /* i32 (n)        entities of the env's current episode that were placed although all
+                                                 10 000 rejection-sampling draws collided (the reference would loop forever,
+                                                 navigation_graph.py:389-457, :472-535): 0 unless the world is over-crowded */
+    FMARL_F_STAGE_PLACE_FAILS, /* i32 (n)        the same for the staged next episode (FMARL_FLAG_ASYNC_RESET)             */
     FMARL_F_MATCH_DUAL,        /* f64 (n, N)     internal (formation): column potentials of the last slot matching, the
                                                  warm start of the next one (any values are valid: the optimum is unique) */
     FMARL_NUM_FIELDS
@@ -241,6 +248,19 @@ int fmarl_edge_count(const float *adj, int32_t *nnz, int n_envs, int num_entitie
                      int strict, void *stream);
 int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_index, float *edge_attr, int64_t total,
                     int n_graphs, int graphs_per_env, int num_entities, double max_edge_dist, int strict, void *stream);
+
+/* processAdj fused with the step: the adj emission of fmarl_step / fmarl_reset counts every env's
+ * policy edges into FmarlOutputs.edge_nnz; the prefix sum and the edge list are built on the device from the WORLD STATE
+ * (the float32 entity positions adj was computed from), so adj is never read back and nothing synchronises with the host.
+ *   fmarl_edge_offsets: offsets i64 (n_envs * graphs_per_env + 1) = exclusive prefix sum of the per-graph counts
+ *       (graph b belongs to env b / graphs_per_env); offsets[last] = total number of edges.
+ *   fmarl_edge_fill_state: edge_index i64 (2, capacity) rows | cols with node ids b * E + r, edge_attr f32 (capacity), in
+ *       the row-major order of processAdj; edges beyond `capacity` are dropped (size the buffers with offsets[last], or
+ *       with an upper bound when the host must not wait).  Call it after the fmarl_step / fmarl_reset whose adj it
+ *       describes and before the next step.  edge_attr equals the adj entries bit for bit. */
+int fmarl_edge_offsets(const int32_t *nnz, int n_envs, int graphs_per_env, int64_t *offsets, void *stream);
+int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offsets, int64_t *edge_index, float *edge_attr,
+                          int64_t capacity, int graphs_per_env, void *stream);
 
 /* Cross-GPU hand-off of the graph observation (navigation_graph only).  The reference's workers pipe node_obs /
  * adj to the learner with every step (onpolicy/envs/env_wrappers.py:988-996).  Between GPUs only the compact

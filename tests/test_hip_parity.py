@@ -680,6 +680,32 @@ def test_captured_inserts_fill_masks_like_eager_inserts():
         cap.replay()
 
 
+def test_exhausted_rejection_sampling_is_reported():
+    """An over-crowded world: the reference's placement loops (navigation_graph.py:389-457, :472-535) would never end;
+    the device bounds them at 10 000 draws, keeps the last draw and COUNTS it (FMARL_F_PLACE_FAILS) -- through the
+    synchronous and the staged reset alike.  The accepted draw is the oracle's (same bound, same Philox stream)."""
+    cfg = fm.EnvConfig(num_agents=6, num_landmarks=6, num_obstacles=0, world_size=0.15)
+    n, seed = 3, 4
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    orc = no.OracleGraphVecEnv(ocfg, 1, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, e, ep))
+    orc.reset()
+    for async_reset in (False, True):
+        eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, async_reset=async_reset)
+        eng.reset()
+        fails = eng.placement_exhausted().cpu().numpy()
+        assert fails.shape == (n,) and (fails > 0).all() and (fails <= 12).all(), fails
+        st = eng.get_state()
+        assert np.array_equal(st['place_fails'], fails)
+        np.testing.assert_array_equal(st['agent_pos'][0], orc.st.agent_pos[0])
+        np.testing.assert_array_equal(st['landmark_pos'][0], orc.st.landmark_pos[0])
+        for t in range(cfg.episode_length + 2):     # through an auto-reset (staged: the commit carries the count over)
+            eng.step(torch.zeros(n, cfg.N, dtype=torch.int32, device=DEV))
+        assert (eng.placement_exhausted() > 0).all() and int(eng.get_state()['episode'].min()) == 3
+    roomy = fm.RolloutEngine(fm.EnvConfig(num_agents=6, num_landmarks=6, num_obstacles=3), 64, device=DEV, seed=seed)
+    roomy.reset()
+    assert int(roomy.placement_exhausted().abs().sum()) == 0
+
+
 def test_misaligned_output_buffers():
     """16-byte row shapes need 16-byte aligned node_obs / adj (refused otherwise); generic shapes take any float
     pointer and still produce the same values (aligned frames inside the kernels)."""

@@ -29,8 +29,23 @@ def test_engine_equals_the_reference_on_the_philox_stream(name):
     """No state injection anywhere: device resets (placement, assignment, reset observation) and steps against the
     reference's own outputs through every auto-reset of the run."""
     fx = load(name)
-    eng, cfg, args, n = engine_of(fx)
+    eng, cfg, args, n = engine_of(fx, count_edges=True)
     obs, ids, node, adj = eng.reset()
+    # f-3 fused: buffer slot s of episode ep holds the output of step ep * T + s - 1 (slot 0 of episode 0: the reset)
+    T = cfg.episode_length
+    padj_at = {}
+    for key in fx.files:
+        if '_padj' in key and key.endswith('_index'):
+            ep, slot = int(key[2:key.index('_')]), int(key[key.index('padj') + 4:key.rindex('_')])
+            padj_at[ep * T + slot - 1] = key
+
+    def check_fused_edges(t):
+        key = padj_at[t]
+        ei, ea, off = eng.process_adj(per_agent=True)            # counts from the emission, edges from the state
+        assert np.array_equal(ei.cpu().numpy(), fx[key]), key
+        np.testing.assert_allclose(ea.cpu().numpy(), fx[key.replace('_index', '_attr')], rtol=1e-6, atol=1e-6)
+        assert int(off[-1]) == fx[key].shape[1] and off.numel() == n * cfg.N + 1
+    check_fused_edges(-1)
     np.testing.assert_allclose(obs.cpu().numpy(), fx['ep0_obs'][0], **F32)
     np.testing.assert_allclose(node.cpu().numpy(), fx['ep0_node_obs'][0], **F32)
     np.testing.assert_allclose(adj[:, 0].cpu().numpy(), fx['ep0_adj'][0], **F32)
@@ -56,7 +71,9 @@ def test_engine_equals_the_reference_on_the_philox_stream(name):
         slot = dict(fm.infos.key_map(cfg.scenario_name))
         got = np.stack([info[..., slot[k]] for k in keys], axis=-1)
         np.testing.assert_allclose(got, fx['info'][t], err_msg=msg, **F32)
-    assert fx['reset_count'].sum() >= 2
+        if t in padj_at:
+            check_fused_edges(t)
+    assert fx['reset_count'].sum() >= 2 and len(padj_at) >= 4
 
 
 @pytest.mark.parametrize('name', RUNNER)
@@ -305,3 +322,59 @@ def test_non_graph_vec_envs_equal_the_reference(name):
     import argparse
     with pytest.raises(NotImplementedError):
         fm.MPEEnv(argparse.Namespace(**dict(args, scenario_name='fair_graph_formation')))
+
+
+@pytest.mark.parametrize('kw,n', [(dict(num_agents=32, num_landmarks=32, num_obstacles=8), 40),            # 16-byte adj path
+                                  (dict(num_agents=5, num_landmarks=5, num_obstacles=2, num_walls=2, max_edge_dist=0.6), 300),
+                                  (dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3), 77),
+                                  (dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3,
+                                        num_obstacles=2, min_dist_thresh=0.3), 200)],
+                         ids=['nav32', 'nav5w2', 'formation', 'fairnav'])
+def test_fused_process_adj_equals_the_two_pass_result(kw, n):
+    """SURVEY section 8 f-3 as specified: counts from the adj emission (step and reset, incl. envs that auto-reset
+    inside the step), prefix sum on the device, edges from the world state == processAdj of the emitted float32 matrix
+    (oracle.runner_oracle.process_adj, pinned by the reference's processAdj) -- bit for bit, with and without the one
+    host read that sizes the result."""
+    cfg = fm.EnvConfig(episode_length=7, **kw)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=13, count_edges=True)
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    eng.reset()
+    for t in range(17):   # crosses two episode ends
+        if t:
+            eng.step(torch.randint(0, 5, (n, cfg.N), device=DEV, generator=g, dtype=torch.int32))
+        adj = eng.adj_env.cpu().numpy()
+        for per_agent in (False, True):
+            batch = np.repeat(adj[:, None], cfg.N, axis=1).reshape(-1, cfg.E, cfg.E) if per_agent else adj
+            want_i, want_a = ro.process_adj(batch, cfg.max_edge_dist)
+            ei, ea, off = eng.process_adj(per_agent=per_agent)
+            assert np.array_equal(ei.cpu().numpy(), want_i) and np.array_equal(ea.cpu().numpy(), want_a), (t, per_agent)
+            counts = np.bincount(want_i[0] // cfg.E, minlength=batch.shape[0])
+            assert np.array_equal(off.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]))
+        if t % 5 == 0:    # no host read at all: a generous buffer, then a tight one that drops the overflow
+            cap = want_i.shape[1] + 100
+            ei, ea, off = eng.process_adj(per_agent=True, max_edges=cap)
+            k = int(off[-1])
+            assert k == want_i.shape[1] and np.array_equal(ei[:, :k].cpu().numpy(), want_i) and np.array_equal(ea[:k].cpu().numpy(), want_a)
+            ei, ea, off = eng.process_adj(per_agent=True, max_edges=k // 2)
+            assert int(off[-1]) == k and np.array_equal(ei.cpu().numpy(), want_i[:, :k // 2])
+    # an engine that does not count falls back to the two passes over adj: same result
+    plain, counting = fm.RolloutEngine(cfg, n, device=DEV, seed=13), fm.RolloutEngine(cfg, n, device=DEV, seed=13, count_edges=True)
+    plain.reset(); counting.reset()
+    a, b, c = plain.process_adj()
+    d, e, f = counting.process_adj()
+    assert plain.outs.edge_nnz is None and torch.equal(a, d) and torch.equal(b, e) and torch.equal(c, f)
+
+
+def test_edge_offsets_prefix_sum_at_scale():
+    """fmarl_edge_offsets across many chunks (2048 graphs each) and with replication."""
+    import ctypes as C
+    from fair_marl_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    for n, reps in ((1, 1), (2047, 1), (2048, 1), (2049, 3), (70001, 1), (5000, 32), (300000, 2)):
+        nnz = rs.randint(0, 5000, size=n).astype(np.int32)
+        d = torch.as_tensor(nnz, device=DEV)
+        off = torch.empty(n * reps + 1, dtype=torch.int64, device=DEV)
+        _lib.check(lib.fmarl_edge_offsets(d.data_ptr(), n, reps, off.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'offsets')
+        want = np.concatenate([[0], np.cumsum(np.repeat(nnz.astype(np.int64), reps))])
+        assert np.array_equal(off.cpu().numpy(), want), (n, reps)

@@ -206,3 +206,26 @@ def test_trajectory_gather_world_size_2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+def test_hot_kernels_keep_their_register_and_scratch_budget():
+    """Compiler remarks of the gfx950 build (tools/kres.sh, no GPU needed): the three step kernels must not spill the
+    kernel-argument block to scratch memory (a by-reference use of Params that is not inlined costs 776 bytes per lane and
+    a third of the throughput -- it happened once) and must keep the occupancy DESIGN.md section 4 counts on."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(['bash', os.path.join(root, 'tools', 'kres.sh')], capture_output=True, text=True, timeout=600).stdout
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r'(\S+)\s+vgpr\s+(\d+) scratch\s+(\d+) occ (\d+)', line)
+        if m:
+            rows[m.group(1)] = tuple(int(x) for x in m.groups()[1:])
+    def find(part):
+        hits = [v for k, v in rows.items() if part in k]
+        assert len(hits) == 1, (part, list(rows))
+        return hits[0]
+    for part, max_vgpr, max_scratch, min_occ in (('11step_kernel', 96, 32, 5), ('16formation_kernelILb1', 104, 0, 4),
+                                                 ('14fairnav_kernelILb1', 128, 96, 4), ('17reset_emit_kernel', 96, 32, 5)):
+        vgpr, scratch, occ = find(part)
+        assert vgpr <= max_vgpr and scratch <= max_scratch and occ >= min_occ, (part, vgpr, scratch, occ)
