@@ -200,16 +200,18 @@ def main():
         args.sync_reset = True
         ep_len = cfg.episode_length
         K, W = max(ep_len, K // ep_len * ep_len), (W + ep_len - 1) // ep_len * ep_len   # whole episodes
-    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
-                           tune_placement=0 if args.no_tune_placement else None)
     gather = (world > 1 or args.record_path) and not args.no_gather
+    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
+                           tune_placement=0 if args.no_tune_placement else None, emit_graph_record=gather)
     depth = 2
-    # navigation_graph: the learner rebuilds node_obs / adj from obs + a record gathered once per episode
-    episodes = cfg.scenario_name == 'navigation_graph'
+    # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for
+    # fair_graph_formation, a 36-byte-per-agent record of the step's scenario state (RolloutEngine.step_record_words)
+    episodes = cfg.scenario_name in ('navigation_graph', 'fair_graph_formation')
     tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
-                          episode_words=eng.episode_record_words if episodes else 0) if gather else None
+                          episode_words=eng.episode_record_words if episodes else 0,
+                          graph_words=eng.step_record_words if eng.emit_graph_record else 0) if gather else None
     if gather:
-        sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done) for r in tg.records]
+        sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done, graph_record=r.graph) for r in tg.records]
     else:
         sets = [eng.outs]
 
@@ -324,7 +326,7 @@ def main():
                                             if eng.placement_ms else 'first allocations'),
                        'exchange': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
                                      else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
-                                    % StepRecord.bytes_per_agent_step(cfg.obs_dim)
+                                    % StepRecord.bytes_per_agent_step(cfg.obs_dim, eng.step_record_words if eng.emit_graph_record else 0)
                                     + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'
                                        % (4 * eng.episode_record_words) if episodes else '')) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -37,7 +37,7 @@ class FmarlConfig(C.Structure):
 
 class FmarlOutputs(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('node_obs', C.c_void_p), ('adj', C.c_void_p), ('reward', C.c_void_p),
-                ('done', C.c_void_p), ('info', C.c_void_p), ('edge_nnz', C.c_void_p)]
+                ('done', C.c_void_p), ('info', C.c_void_p), ('edge_nnz', C.c_void_p), ('graph_record', C.c_void_p)]
 
 
 _SIGS = {
@@ -68,6 +68,8 @@ _SIGS = {
     'fmarl_edge_offsets': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'fmarl_edge_fill_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'fmarl_episode_record_words': (C.c_size_t, [C.POINTER(FmarlConfig)]),
+    'fmarl_step_record_words': (C.c_size_t, [C.POINTER(FmarlConfig)]),
+    'fmarl_rebuild_graph_rec': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fmarl_episode_started': (C.c_int, [C.c_void_p]),
     'fmarl_pack_episode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fmarl_rebuild_graph': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -171,6 +171,47 @@ __device__ __forceinline__ uint32_t branch_event(int near_e, int g_ego, uint32_t
     return 4u;
 }
 
+constexpr int kFormationRecordWords = 9;   // include/fmarl.h fmarl_step_record_words
+
+// node_obs rows of the envs [el0w, el0w + nenv_w) of the workgroup by one wave (ff:896-971): shared by the step / reset
+// kernels and the learner-side rebuild (formation_rebuild_kernel), which fills the same LDS tables from the records.
+__device__ __forceinline__ void formation_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int el0w,
+                                                    int nenv_w, int lane) {
+    const int N = p.N;
+    if (o.node_obs) {
+        // one lane per (ego, entity) row of F = 12 floats = three 16-byte stores: [dv dx] [goal flag dx.x] [dx.y dx type];
+        // the three chunks share the position loads and the index math; consecutive lanes write consecutive rows (ff:896-971)
+        // (each wave streams the rows of its own envs)
+        const uint32_t NE = N * p.E, total = nenv_w * NE, first_wall = N + p.L + p.O;
+        float4 *dst = (float4 *)(o.node_obs + ((size_t)env0 + el0w) * NE * 12);
+        for (uint32_t q = lane; q < total; q += 64) {
+            const uint32_t e_l = p.dNE.div(q), r = q - e_l * NE;
+            const FormLds te(p, lds, el0w + e_l);
+            if (te.skip()) continue;
+            const uint32_t a = p.dE.div(r), e = r - a * p.E;
+            // differences of the f32 roundings (as navigation_graph's rows): within 1.2e-7 of the rounded f64 difference
+            const float2 vi = te.velf()[a], pi = te.posf()[a], pe = te.posf()[e];
+            const float dx = pe.x - pi.x, dy = pe.y - pi.y;
+            float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
+            if (e < (uint32_t)N) {
+                const float2 ve = te.velf()[e];
+                vx = ve.x; vy = ve.y;
+                const double2 gl = te.graph_goal(a, e);
+                gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
+                fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
+            } else if (e >= first_wall) {
+                const float4 wc = te.wallf()[e - first_wall];   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
+                t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
+            }
+            const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
+            float4 *d = dst + (size_t)q * 3;
+            d[0] = make_float4(vx - vi.x, vy - vi.y, dx, dy);
+            d[1] = make_float4(gx, gy, fl, t7);
+            d[2] = make_float4(t8, t9, t10, type);
+        }
+    }
+}
+
 // mean and population std (two-pass, like np.mean / np.std) of the dists_to_goal vector seen by the agent loop: entry j
 // is this step's value for j < split -- the path length pd[j] while agent j is still under way (bit j of open), else
 // the value frozen at its arrival -- and the previous step's value (stale[j]) for j >= split.
@@ -358,6 +399,15 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             p.slot_occ[g] = (double)((t.words()[2] >> i) & 1u);
             p.match_dual[g] = t.theta()[i];   // column potentials of the matching on the current slots: next step's warm start
         }
+        if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
+            uint32_t *r = o.graph_record + g * kFormationRecordWords;
+            const float2 pf = t.posf()[i], vf = t.velf()[i];
+            const double2 sl = t.slot_new()[i];
+            r[0] = __float_as_uint(pf.x); r[1] = __float_as_uint(pf.y); r[2] = __float_as_uint(vf.x); r[3] = __float_as_uint(vf.y);
+            r[4] = __float_as_uint((float)sl.x); r[5] = __float_as_uint((float)sl.y);
+            r[6] = t.masks()[3 * i]; r[7] = t.masks()[3 * i + 1];
+            r[8] = (uint32_t)(uint8_t)t.near_new()[i] | ((uint32_t)(uint8_t)t.g_new()[i] << 8);
+        }
         if (STEP) {
             const bool open = Tr_old == -1.0;
             const double Dg_new = open ? pd : Dg_old;
@@ -413,38 +463,56 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     }
     // ---- emission: node_obs (16 bytes per lane) and adj
     if (FMARL_SKIP(p, 32)) return;
-    if (o.node_obs) {
-        // one lane per (ego, entity) row of F = 12 floats = three 16-byte stores: [dv dx] [goal flag dx.x] [dx.y dx type];
-        // the three chunks share the position loads and the index math; consecutive lanes write consecutive rows (ff:896-971)
-        // (each wave streams the rows of its own envs)
-        const uint32_t NE = N * p.E, total = nenv_w * NE, first_wall = N + p.L + p.O;
-        float4 *dst = (float4 *)(o.node_obs + ((size_t)env0 + el0w) * NE * 12);
-        for (uint32_t q = lane; q < total; q += 64) {
-            const uint32_t e_l = p.dNE.div(q), r = q - e_l * NE;
-            const FormLds te(p, lds, el0w + e_l);
-            if (te.skip()) continue;
-            const uint32_t a = p.dE.div(r), e = r - a * p.E;
-            // differences of the f32 roundings (as navigation_graph's rows): within 1.2e-7 of the rounded f64 difference
-            const float2 vi = te.velf()[a], pi = te.posf()[a], pe = te.posf()[e];
-            const float dx = pe.x - pi.x, dy = pe.y - pi.y;
-            float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
-            if (e < (uint32_t)N) {
-                const float2 ve = te.velf()[e];
-                vx = ve.x; vy = ve.y;
-                const double2 gl = te.graph_goal(a, e);
-                gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
-                fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
-            } else if (e >= first_wall) {
-                const float4 wc = te.wallf()[e - first_wall];   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
-                t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
-            }
-            const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
-            float4 *d = dst + (size_t)q * 3;
-            d[0] = make_float4(vx - vi.x, vy - vi.y, dx, dy);
-            d[1] = make_float4(gx, gy, fl, t7);
-            d[2] = make_float4(t8, t9, t10, type);
-        }
+    formation_emit_rows(p, o, lds, env0, el0w, nenv_w, lane);
+    emit_adj(p, o, lds, env0, el0w, el0w + nenv_w, lane, 64);
+}
+
+// Learner-side reconstruction of node_obs / adj of fair_graph_formation envs from the gathered records: the per-step
+// record written by formation_kernel (FmarlOutputs.graph_record) and the once-per-episode record of the static entities
+// (fmarl_rebuild.hip layout).  The LDS tables are filled with the float32 values the sender's emission read, then the
+// same emission code runs: node_obs and adj equal the sender's bit for bit.  n_envs is the caller's.
+__global__ __launch_bounds__(kThreads) void formation_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec,
+                                                                     const uint32_t *step_rec, int n_envs) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, N = p.N;
+    const int env0 = blockIdx.x * p.epb;
+    const int nenv = min(p.epb, n_envs - env0);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int elw = lane / N, i = lane - elw * N;
+    const int el0w = wave * p.epw;
+    const int nenv_w = max(0, min(p.epw, nenv - el0w));
+    const int el = el0w + elw;
+    const int LO = p.L + p.O, words = 2 * N + 2 * LO + 6 * p.W;   // episode_record_words (fmarl_rebuild.hip)
+    if (elw < nenv_w) {
+        const FormLds t(p, lds, el);
+        const uint32_t *r = step_rec + ((size_t)(env0 + el) * N + i) * kFormationRecordWords;
+        const float2 pf = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        t.posf()[i] = pf; t.pos()[i] = make_double2((double)pf.x, (double)pf.y);
+        t.velf()[i] = make_float2(__uint_as_float(r[2]), __uint_as_float(r[3]));
+        t.slot_new()[i] = make_double2((double)__uint_as_float(r[4]), (double)__uint_as_float(r[5]));
+        t.masks()[3 * i] = r[6]; t.masks()[3 * i + 1] = r[7]; t.masks()[3 * i + 2] = 0;
+        t.near_new()[i] = (int8_t)(r[8] & 0xff); t.g_new()[i] = (int8_t)((r[8] >> 8) & 0xff);
+        if (i == 0) *t.flag() = 0;
     }
+    for (int k = tid; k < nenv * LO; k += kThreads) {
+        const int e_l = k / LO, j = k - e_l * LO;
+        const float *sp = (const float *)(ep_rec + (size_t)(env0 + e_l) * words) + 2 * (N + j);
+        const FormLds t(p, lds, e_l);
+        t.pos()[N + j] = make_double2((double)sp[0], (double)sp[1]);
+        t.posf()[N + j] = make_float2(sp[0], sp[1]);
+    }
+    for (int k = tid; k < nenv * p.W; k += kThreads) {
+        const int e_l = k / p.W, w = k - e_l * p.W;
+        const FormLds t(p, lds, e_l);
+        const uint32_t *q = ep_rec + (size_t)(env0 + e_l) * words + 2 * (N + LO) + 6 * w;
+        const double axis = __longlong_as_double((long long)((unsigned long long)q[0] | ((unsigned long long)q[1] << 32)));
+        const float *qf = (const float *)q;
+        ((float4 *)(t.base + p.lds_wallf))[w] = make_float4(qf[2], (float)(axis + kWallWidth / 2), qf[3], (float)(axis - kWallWidth / 2));
+        t.pos()[N + LO + w] = qf[4] == 0.f ? make_double2(0.0, axis) : make_double2(axis, 0.0);
+        t.posf()[N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
+    }
+    __syncthreads();
+    formation_emit_rows(p, o, lds, env0, el0w, nenv_w, lane);
     emit_adj(p, o, lds, env0, el0w, el0w + nenv_w, lane, 64);
 }
 

@@ -23,6 +23,8 @@ __global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal
 template <bool STEP> __global__ void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                      const float *action_vec, int auto_reset);
 
+__global__ void formation_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec, const uint32_t *step_rec, int n_envs);
+
 // fmarl_fairnav.hip
 template <bool STEP> __global__ void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                    const float *action_vec, int auto_reset);

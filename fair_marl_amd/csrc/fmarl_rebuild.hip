@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void pack_episode_kernel(Params p, uint32_t *r
         uint32_t *r = rec + (size_t)env * words;
         if (k < p.N + LO) {
             double2 x;
-            if (k < p.N) x = p.landmark_pos[(size_t)env * p.L + p.goal_match[(size_t)env * p.N + k]];
+            if (k < p.N) x = p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH ? p.landmark_pos[(size_t)env * p.L + p.goal_match[(size_t)env * p.N + k]]
+                                                                         : make_double2(0.0, 0.0);   // (goals travel per step elsewhere)
             else if (k < p.N + p.L) x = p.landmark_pos[(size_t)env * p.L + (k - p.N)];
             else x = p.obstacle_pos[(size_t)env * p.O + (k - p.N - p.L)];
             ((float *)r)[2 * k] = (float)x.x;

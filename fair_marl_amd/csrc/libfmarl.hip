@@ -348,12 +348,21 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
     p.dE4.set(p.vec_adj ? p.E / 4 : 1);
     if (fnav) p.dC4.set(p.N * p.E);   // fairnav emission: (ego, entity) rows per env
+    {   // FastDiv (fmarl_dev.h) is exact only while dividend * divisor < 2^40: check every divisor against the largest
+        // dividend its call sites form (indices inside one workgroup's share of an output array)
+        const uint64_t E = p.E, N = p.N, F = p.F, EE = E * E, e = epb, lim = 1ull << 40;
+        const bool ok = (e * EE + 16) * EE < lim && EE * E < lim && (e * N * E) * (N * E) < lim && (E * F) * F < lim &&
+                        (e * N * E * F) * (E * F) < lim && (!p.vec_adj || (e * E * (E / 4)) * (E * (E / 4)) < lim) &&
+                        (!p.vec_node || (e * N * (E * F / 4)) * (N * (E * F / 4)) < lim);
+        if (!ok) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large (entity count beyond the index arithmetic of the emission)"); }
+    }
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)rebuild_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)fairnav_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)fairnav_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
@@ -640,8 +649,8 @@ int fmarl_pack_episode(void *handle, const void *state, void *record, void *stre
     Handle *h = (Handle *)handle;
     DeviceGuard on_device(h);
     if (!h || !state || !record) return fail(FMARL_EINVAL, "fmarl_pack_episode: null argument");
-    if (h->cfg.scenario != FMARL_SCENARIO_NAVIGATION_GRAPH)
-        return fail(FMARL_EINVAL, "fmarl_pack_episode: only navigation_graph has a rebuildable record");
+    if (h->cfg.scenario == FMARL_SCENARIO_FAIRNAV)
+        return fail(FMARL_EINVAL, "fmarl_pack_episode: nav_fairassign_fairrew_formation_graph has no rebuildable record");
     Params p = bind(h, (void *)state);
     const size_t total = (size_t)p.n_envs * (p.N + p.L + p.O + p.W);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -650,21 +659,39 @@ int fmarl_pack_episode(void *handle, const void *state, void *record, void *stre
     return FMARL_OK;
 }
 
-int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int n_envs, float *node_obs, float *adj,
-                        void *stream) {
+size_t fmarl_step_record_words(const FmarlConfig *cfg) {
+    const char *why;
+    if (!config_ok(cfg, &why)) { fail(FMARL_EINVAL, "fmarl_step_record_words: %s", why); return 0; }
+    return cfg->scenario == FMARL_SCENARIO_FORMATION ? (size_t)kFormationRecordWords : 0;
+}
+
+int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_record, const void *step_record, int n_envs,
+                            float *node_obs, float *adj, void *stream) {
     Handle *h = (Handle *)handle;
     DeviceGuard on_device(h);
-    if (!h || !obs || !record || n_envs < 1 || (!node_obs && !adj)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: bad argument");
-    if (h->cfg.scenario != FMARL_SCENARIO_NAVIGATION_GRAPH)
-        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: only navigation_graph has a rebuildable record");
+    if (!h || !episode_record || n_envs < 1 || (!node_obs && !adj)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph_rec: bad argument");
+    const int sc = h->cfg.scenario;
+    if (sc == FMARL_SCENARIO_FAIRNAV)
+        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: nav_fairassign_fairrew_formation_graph has no rebuildable record");
+    if (sc == FMARL_SCENARIO_NAVIGATION_GRAPH ? !obs : !step_record)
+        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: navigation_graph needs the obs rows, fair_graph_formation the step record");
     FmarlOutputs o = {};
     o.node_obs = node_obs; o.adj = adj;
     if (!outputs_aligned(h->base, &o)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: node_obs / adj must be 16-byte aligned for this shape");
     const int grid = (n_envs + h->base.epb - 1) / h->base.epb;
-    hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o, obs,
-                       (const uint32_t *)record, n_envs);
+    if (sc == FMARL_SCENARIO_FORMATION)
+        hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o,
+                           (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
+    else
+        hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o, obs,
+                           (const uint32_t *)episode_record, n_envs);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
+}
+
+int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int n_envs, float *node_obs, float *adj,
+                        void *stream) {
+    return fmarl_rebuild_graph_rec(handle, obs, record, nullptr, n_envs, node_obs, adj, stream);
 }
 
 }  // extern "C"

@@ -20,12 +20,12 @@ _TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32}
 
 class OutputSet(object):
     """obs / reward / done / info tensors of one step + the FmarlOutputs struct pointing at them."""
-    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'edge_nnz', 'c')
+    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'edge_nnz', 'graph_record', 'c')
 
 
 class RolloutEngine:
     def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True,
-                 emit_graph=True, tune_placement=None, count_edges=False):
+                 emit_graph=True, tune_placement=None, count_edges=False, emit_graph_record=False):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_args(cfg)
         cfg.validate()
@@ -54,6 +54,10 @@ class RolloutEngine:
         self.emit_info, self.emit_graph = emit_info, emit_graph
         # count_edges: the adj emission also counts every env's policy edges (process_adj then never reads adj back)
         self.count_edges = bool(count_edges and emit_graph)
+        # emit_graph_record: scenarios whose node features depend on per-step scenario state (fair_graph_formation) also
+        # write the compact per-step record a learner on another GPU rebuilds node_obs from (step_record_words per agent)
+        self.step_record_words = int(self.lib.fmarl_step_record_words(C.byref(self.c)))
+        self.emit_graph_record = bool(emit_graph_record and self.step_record_words)
         self.placement_ms = None
         if tune_placement is None:   # worth it once the graph outputs are GBs (the step is then bound by their store stream)
             tune_placement = 6 if emit_graph and cfg.scenario_name == 'navigation_graph' and n * N * E * F * 4 >= (1 << 30) else 0
@@ -121,7 +125,7 @@ class RolloutEngine:
             torch.cuda.empty_cache()   # hand the losing allocations back to the driver
         self.placement_ms = times
 
-    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None):
+    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None, graph_record=None):
         """A set of per-step output buffers.  By default node_obs / adj are shared by all sets (large,
         consumed before the next step) while obs / reward / done / info are per set, so a set can still
         be read (e.g. by an in-flight RCCL gather, see sharding.py) while the next step writes another.
@@ -139,6 +143,9 @@ class RolloutEngine:
             o.node_obs = node_obs if node_obs is not None else self._default_graph[0]
             o.adj_env = adj_env if adj_env is not None else self._default_graph[1]
             o.edge_nnz = torch.zeros(n, dtype=torch.int32, device=self.device) if self.count_edges else None
+            o.graph_record = graph_record
+            if o.graph_record is None and self.emit_graph_record:
+                o.graph_record = torch.zeros(n, N, self.step_record_words, dtype=torch.int32, device=self.device)
         E, F = self.cfg.E, self.cfg.node_feat
         for t, shape, dt in ((o.obs, (n, N, D), torch.float32), (o.reward, (n, N), torch.float32), (o.done, (n, N), torch.uint8),
                              (o.node_obs, (n, N, E, F), torch.float32), (o.adj_env, (n, E, E), torch.float32)):
@@ -150,14 +157,18 @@ class RolloutEngine:
                                 o.adj_env.data_ptr() if o.adj_env is not None else None,
                                 o.reward.data_ptr(), o.done.data_ptr(),
                                 o.info_planes.data_ptr() if o.info_planes is not None else None,
-                                o.edge_nnz.data_ptr() if o.edge_nnz is not None else None)
+                                o.edge_nnz.data_ptr() if o.edge_nnz is not None else None,
+                                o.graph_record.data_ptr() if o.graph_record is not None else None)
+        if o.graph_record is not None and (tuple(o.graph_record.shape) != (n, N, self.step_record_words) or o.graph_record.dtype != torch.int32
+                                           or not o.graph_record.is_contiguous()):
+            raise ValueError('graph_record must be a contiguous int32 tensor of shape %s' % ((n, N, self.step_record_words),))
         return o
 
     def use_outputs(self, out_set):
         """Select the output set the next reset / step calls write into."""
         self.outs = out_set
         self.obs, self.reward, self.done, self.info = out_set.obs, out_set.reward, out_set.done, out_set.info
-        self.node_obs, self.adj_env = out_set.node_obs, out_set.adj_env
+        self.node_obs, self.adj_env, self.graph_record = out_set.node_obs, out_set.adj_env, out_set.graph_record
 
     def _field_shapes(self):
         n, c = self.n_envs, self.cfg
@@ -435,22 +446,32 @@ class RolloutEngine:
                        'fmarl_pack_episode')
         return out
 
-    def rebuild_graph(self, obs, record, node_obs=None, adj_env=None, want_node_obs=True, want_adj=True):
-        """graph_observation (reference navigation_graph.py:941-1035) from gathered (obs (n, N, D) f32, episode record
-        (n, words)); n is the caller's.  Returns (node_obs (n, N, E, F) | None, adj_env (n, E, E) | None)."""
+    def rebuild_graph(self, obs, record, node_obs=None, adj_env=None, want_node_obs=True, want_adj=True, step_record=None):
+        """graph_observation (reference navigation_graph.py:941-1035, fair_graph_formation.py:810-971) from the gathered
+        records; n is the caller's.  navigation_graph: ``obs`` (n, N, D) f32 + the episode ``record`` (n, words).
+        fair_graph_formation: the per-step ``step_record`` (n, N, step_record_words) int32 written by the step kernel
+        (``emit_graph_record=True``) + the episode record; ``obs`` is not needed (may be None).
+        Returns (node_obs (n, N, E, F) | None, adj_env (n, E, E) | None), bit-identical to the sender's."""
         cfg = self.cfg
-        obs = torch.as_tensor(obs).to(self.device, torch.float32).contiguous()
-        n = obs.shape[0]
-        assert tuple(obs.shape[1:]) == (cfg.N, cfg.obs_dim) and record.is_contiguous() and record.device == obs.device
+        if step_record is not None:
+            step_record = step_record.to(self.device).contiguous()
+            n = step_record.shape[0]
+            assert tuple(step_record.shape[1:]) == (cfg.N, self.step_record_words) and step_record.dtype == torch.int32
+        if obs is not None:
+            obs = torch.as_tensor(obs).to(self.device, torch.float32).contiguous()
+            n = obs.shape[0]
+            assert tuple(obs.shape[1:]) == (cfg.N, cfg.obs_dim)
+        assert record.is_contiguous() and record.device == self.device
         assert record.numel() * record.element_size() == n * self.episode_record_words * 4
         if node_obs is None and want_node_obs:
             node_obs = torch.empty(n, cfg.N, cfg.E, cfg.node_feat, dtype=torch.float32, device=self.device)
         if adj_env is None and want_adj:
             adj_env = torch.empty(n, cfg.E, cfg.E, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fmarl_rebuild_graph(self.handle, obs.data_ptr(), record.data_ptr(), n,
-                                                    node_obs.data_ptr() if node_obs is not None else None,
-                                                    adj_env.data_ptr() if adj_env is not None else None, self._stream()),
+            _lib.check(self.lib.fmarl_rebuild_graph_rec(self.handle, obs.data_ptr() if obs is not None else None, record.data_ptr(),
+                                                        step_record.data_ptr() if step_record is not None else None, n,
+                                                        node_obs.data_ptr() if node_obs is not None else None,
+                                                        adj_env.data_ptr() if adj_env is not None else None, self._stream()),
                        'fmarl_rebuild_graph')
         return node_obs, adj_env
 

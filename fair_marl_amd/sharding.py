@@ -29,25 +29,38 @@ def shard_range(n_total, world_size, rank):
 
 
 class StepRecord(object):
-    """One flat byte buffer laid out as [obs f32 (n,N,D) | reward f32 (n,N) | done u8 (n,N) | pad]."""
+    """One flat byte buffer laid out as [obs f32 (n,N,D) | reward f32 (n,N) | graph record i32 (n,N,G) | done u8 (n,N) | pad].
+    ``graph_words`` = RolloutEngine.step_record_words (0 for navigation_graph: its obs rows are the record)."""
 
-    def __init__(self, n_envs, num_agents, obs_dim, device):
+    def __init__(self, n_envs, num_agents, obs_dim, device, graph_words=0):
         self.shape = (int(n_envs), int(num_agents), int(obs_dim))
+        self.graph_words = int(graph_words)
         n, N, D = self.shape
         self.obs_bytes, self.rew_bytes, self.done_bytes = n * N * D * 4, n * N * 4, n * N
-        total = (self.obs_bytes + self.rew_bytes + self.done_bytes + 15) // 16 * 16
+        self.graph_bytes = n * N * self.graph_words * 4
+        total = (self.obs_bytes + self.rew_bytes + self.graph_bytes + self.done_bytes + 15) // 16 * 16
         self.flat = torch.zeros(total, dtype=torch.uint8, device=device)
         self.obs, self.reward, self.done = self.views(self.flat)
+        self.graph = self.graph_view(self.flat)
 
     def views(self, flat):
         n, N, D = self.shape
         a, b = self.obs_bytes, self.obs_bytes + self.rew_bytes
+        c = b + self.graph_bytes
         return (flat[:a].view(torch.float32).view(n, N, D), flat[a:b].view(torch.float32).view(n, N),
-                flat[b:b + self.done_bytes].view(n, N))
+                flat[c:c + self.done_bytes].view(n, N))
+
+    def graph_view(self, flat):
+        """(n, N, graph_words) int32 view of the per-step graph record (None when the scenario has none)."""
+        if not self.graph_words:
+            return None
+        n, N, _ = self.shape
+        b = self.obs_bytes + self.rew_bytes
+        return flat[b:b + self.graph_bytes].view(torch.int32).view(n, N, self.graph_words)
 
     @staticmethod
-    def bytes_per_agent_step(obs_dim):
-        return obs_dim * 4 + 4 + 1
+    def bytes_per_agent_step(obs_dim, graph_words=0):
+        return obs_dim * 4 + 4 + 1 + 4 * graph_words
 
 
 class TrajectoryGather(object):
@@ -60,13 +73,13 @@ class TrajectoryGather(object):
     """
 
     def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0,
-                 force_collective=False):
+                 force_collective=False, graph_words=0):
         self.group, self.dst, self.depth = group, dst, depth
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # force_collective: issue the gathers even in a group of ONE rank (the RCCL path on a one-GPU box)
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
-        self.records = [StepRecord(n_envs, num_agents, obs_dim, device) for _ in range(depth)]
+        self.records = [StepRecord(n_envs, num_agents, obs_dim, device, graph_words) for _ in range(depth)]
         self.pending = [None] * depth
         self.recv = None
         if self.collective and self.rank == dst:
@@ -140,3 +153,12 @@ class TrajectoryGather(object):
             r = self.records[k]
             return [(r.obs, r.reward, r.done)]
         return [self.records[k].views(f) for f in self.recv[k]]
+
+    def gathered_graph(self, t):
+        """On the learner rank: list over ranks of the per-step graph records (n, N, graph_words) int32 of step t."""
+        k = t % self.depth
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+        if not self.collective:
+            return [self.records[k].graph]
+        return [self.records[k].graph_view(f) for f in self.recv[k]]

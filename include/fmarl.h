@@ -88,6 +88,9 @@ typedef struct FmarlOutputs {
     int32_t *edge_nnz;   /* (n)              policy edges of the env's graph: entries of adj with 0 < d < max_edge_dist
                                               (onpolicy/algorithms/utils/gnn.py:307-326 processAdj), counted by the adj
                                               emission itself; needs adj.  See fmarl_edge_offsets / fmarl_edge_fill_state */
+    uint32_t *graph_record; /* (n, N, fmarl_step_record_words) per-step part of the cross-GPU graph hand-off of the
+                                              scenarios whose node features depend on per-step scenario state
+                                              (fair_graph_formation); see fmarl_rebuild_graph_rec                   */
 } FmarlOutputs;
 
 #define FMARL_INFO_WIDTH 14
@@ -262,7 +265,7 @@ int fmarl_edge_offsets(const int32_t *nnz, int n_envs, int graphs_per_env, int64
 int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offsets, int64_t *edge_index, float *edge_attr,
                           int64_t capacity, int graphs_per_env, void *stream);
 
-/* Cross-GPU hand-off of the graph observation (navigation_graph only).  The reference's workers pipe node_obs /
+/* Cross-GPU hand-off of the graph observation (navigation_graph; fair_graph_formation: see fmarl_step_record_words).  The reference's workers pipe node_obs /
  * adj to the learner with every step (onpolicy/envs/env_wrappers.py:988-996).  Between GPUs only the compact
  * record travels: the per-step obs rows, which carry every agent's velocity and position
  * (navigation_graph.py:855-857), and once per episode the entities World.step never moves -- each agent's goal,
@@ -278,6 +281,15 @@ int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offset
  *       n_envs is the caller's (e.g. all ranks' envs), the handle supplies the entity counts.  node_obs equals the
  *       sender's bit for bit; adj is computed from the f32 positions (difference < 1e-6). */
 size_t fmarl_episode_record_words(const FmarlConfig *cfg);
+/* fair_graph_formation: the node features also depend on what the scenario's sequential agent loop left behind in this
+ * step (slots on the circle, the per-ego occupancy / goal-branch masks, fair_graph_formation.py:810-971), which the obs
+ * rows do not carry (obs = concat(v, x, goal - x) + flag, :740-741).  The step kernel therefore writes a compact record
+ * beside obs -- 32-bit words per agent: x, y, vx, vy, slot x, slot y (f32), branch mask, flag mask, nearest slot | matched
+ * slot << 8 -- 36 B per agent-step against 768 B of node_obs at BASELINE config 4; fmarl_rebuild_graph_rec expands it
+ * with the same emission code.  0 words for navigation_graph (obs + the episode record are enough). */
+size_t fmarl_step_record_words(const FmarlConfig *cfg);
+int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_record, const void *step_record, int n_envs,
+                            float *node_obs, float *adj, void *stream);
 int fmarl_episode_started(void *handle);
 int fmarl_pack_episode(void *handle, const void *state, void *record, void *stream);
 int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int n_envs, float *node_obs, float *adj,

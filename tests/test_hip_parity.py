@@ -314,12 +314,46 @@ def test_bench_fails_loudly_when_the_exchange_cannot_run():
     assert not [l for l in res.stdout.splitlines() if l.startswith('{"metric"')], res.stdout[-3000:]
 
 
-def test_rebuild_is_refused_for_other_scenarios():
-    cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=4, num_landmarks=1, num_obstacles=2, num_walls=2)
+def test_rebuild_is_refused_where_no_record_is_defined():
+    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=4, num_landmarks=4, num_obstacles=2)
     eng = fm.RolloutEngine(cfg, 8, device=DEV)
     eng.reset()
-    with pytest.raises(RuntimeError, match='navigation_graph'):
+    with pytest.raises(RuntimeError, match='no rebuildable record'):
         eng.pack_episode()
+    assert eng.step_record_words == 0
+
+
+@pytest.mark.parametrize('N,L,O,n', [(10, 1, 3, 130), (4, 1, 2, 300), (3, 3, 0, 64), (24, 1, 4, 10)])
+def test_learner_side_rebuild_of_the_formation_graph(N, L, O, n):
+    """Multi-GPU hand-off for fair_graph_formation (BASELINE config 4): the node features depend on what the scenario's
+    sequential agent loop did this step, so the step kernel writes a 36-byte-per-agent record beside obs; with the
+    once-per-episode record of the static entities the learner rebuilds node_obs / adj bit for bit."""
+    cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=N, num_landmarks=L, num_obstacles=O, episode_length=6,
+                       min_dist_thresh=0.3)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=5, emit_graph_record=True)
+    plain = fm.RolloutEngine(cfg, n, device=DEV, seed=5)
+    assert eng.step_record_words == 9 and plain.graph_record is None
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    eng.reset(); plain.reset()
+    rec, started = eng.pack_episode(), 1
+    for t in range(15):
+        node, adj = eng.rebuild_graph(None, rec, step_record=eng.graph_record)
+        assert torch.equal(node, eng.node_obs), 'node_obs step %d' % t
+        assert torch.equal(adj, eng.adj_env), 'adj step %d' % t
+        assert torch.equal(eng.node_obs, plain.node_obs) and torch.equal(eng.obs, plain.obs)   # the record costs nothing else
+        a = torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32)
+        eng.step(a); plain.step(a)
+        if eng.episode_started:
+            eng.pack_episode(out=rec); started += 1
+    assert started == 3
+    # several ranks' envs at once, through the byte layout the gather uses
+    from fair_marl_amd.sharding import StepRecord
+    sr = StepRecord(n, N, cfg.obs_dim, DEV, graph_words=eng.step_record_words)
+    sr.graph.copy_(eng.graph_record)
+    both = torch.cat([sr.graph_view(sr.flat), sr.graph_view(sr.flat).flip(0)])
+    node2, adj2 = eng.rebuild_graph(None, torch.cat([rec, rec.flip(0)]), step_record=both)
+    assert torch.equal(node2[:n], eng.node_obs) and torch.equal(node2[n:], eng.node_obs.flip(0)) and torch.equal(adj2[n:], eng.adj_env.flip(0))
+    assert StepRecord.bytes_per_agent_step(cfg.obs_dim, 9) == 6 * 4 + 4 + 1 + 36
 
 
 SHARD_CASES = [dict(num_agents=6, num_landmarks=6, num_obstacles=3, num_walls=1, episode_length=9),

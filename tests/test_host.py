@@ -164,7 +164,7 @@ def _gather_worker(rank, world, port, q):
     from fair_marl_amd.sharding import TrajectoryGather, shard_range
     n_total, N, D, T = 12, 3, 7, 5
     lo, hi = shard_range(n_total, world, rank)
-    tg = TrajectoryGather(hi - lo, N, D, 'cpu', dst=0, depth=2, episode_words=4)
+    tg = TrajectoryGather(hi - lo, N, D, 'cpu', dst=0, depth=2, episode_words=4, graph_words=9)
     ok = True
     for t in range(T):
         if t % 2 == 0:                           # a new 'episode' every second step: its record travels once
@@ -175,15 +175,18 @@ def _gather_worker(rank, world, port, q):
         rec.obs.copy_((env * 100 + t).expand(hi - lo, N, D))
         rec.reward.copy_((env[:, :, 0] + 0.5 * t).expand(hi - lo, N))
         rec.done.fill_(t % 2)
+        rec.graph.copy_((torch.arange(lo, hi, dtype=torch.int32).view(-1, 1, 1) * 1000 + t).expand(hi - lo, N, 9))
         tg.submit(t)
         if t >= 1:                               # consume step t-1 on the learner rank while t is in flight
-            tg.pending[(t - 1) % 2] and tg.pending[(t - 1) % 2].wait()
             if rank == 0:
                 for r, (obs, rew, done) in enumerate(tg.gathered(t - 1)):
                     l2, h2 = shard_range(n_total, world, r)
                     e = torch.arange(l2, h2, dtype=torch.float32)
                     ok &= bool((obs[:, 0, 0] == e * 100 + (t - 1)).all()) and bool((rew[:, 1] == e + 0.5 * (t - 1)).all())
                     ok &= bool((done == (t - 1) % 2).all()) and obs.shape == (h2 - l2, N, D)
+                for r, gr in enumerate(tg.gathered_graph(t - 1)):
+                    l2, h2 = shard_range(n_total, world, r)
+                    ok &= gr.shape == (h2 - l2, N, 9) and bool((gr[:, 2, 8] == torch.arange(l2, h2, dtype=torch.int32) * 1000 + t - 1).all())
                 for r, ep in enumerate(tg.gathered_episode()):     # the record of the episode step t belongs to
                     l2, h2 = shard_range(n_total, world, r)
                     ok &= ep.shape == (h2 - l2, 4) and bool((ep[:, 3] == torch.arange(l2, h2, dtype=torch.int32) * 10 + t // 2).all())
