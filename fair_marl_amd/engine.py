@@ -82,30 +82,39 @@ class RolloutEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fmarl_init_state(self.handle, self.state.data_ptr(), self._stream()), 'fmarl_init_state')
 
-    def _tune_output_placement(self, candidates, launches=5):
-        """Pick the fastest (node_obs allocation, adj allocation) pair out of a few.  How fast the store stream of the
-        emission runs depends on which physical pages the two allocations happened to get, and on the PAIR rather
-        than on either buffer: measured on MI355X at cfg 3 (tools/placement_pairs.py, one process) 1.34 to 1.54 ms per
-        emission launch over 6 x 6 pairs -- the same adj allocation is the best partner of one node_obs allocation and
-        the worst of another -- repeatable to 0.2 % for a given pair and independent of offsets of a few MB inside an
-        allocation (tools/placement_probe.py).  Every pair of 3 node_obs x ``candidates`` adj allocations is timed with
-        the pure emission kernel (fmarl_rebuild_graph: writes node_obs / adj only, touches no env state); the losers
-        are freed.  ``placement_ms`` keeps the timing matrix (row 0 / column 0 = the allocations the engine started with)."""
+    def _tune_output_placement(self, candidates, launches=5, min_spread=0.03):
+        """Pick the fastest (node_obs allocation, adj allocation) pair out of a few -- bounded, and only where it pays.
+
+        How fast the store stream of the emission runs depends, on SOME boxes, on which physical pages the two allocations
+        happened to get, and on the pair rather than on either buffer: 1.36 to 1.54 ms per emission launch over the pairs
+        of one process at BASELINE config 3, repeatable to 0.2 % for a given pair; on most boxes all pairs agree within 2 %.
+        ``profiles/r2_placement_tcc.md`` has the counters: the L2 -> fabric write requests are spread evenly over the 128
+        TCC channels for fast and slow pairs alike (no aliasing the kernel could undo); the slow pair back-pressures a few
+        channels harder (DRAM credit stalls, max over channels +12 %), a property of the physical page placement that
+        neither the kernel nor the caller controls.  So the remedy is to measure: every pair of 3 node_obs x ``candidates``
+        adj allocations is timed with the pure emission kernel (fmarl_rebuild_graph: writes node_obs / adj only, touches no
+        env state) and the losers are freed.  Bounds: the probe is skipped, with a log line, when its transient allocations
+        would not fit beside what already owns the HBM (e.g. a DeviceRolloutBuffer), and it stops after the first row of
+        pairs when those differ by less than ``min_spread`` (the common box).  ``placement_ms`` keeps the timing matrix (row 0
+        / column 0 = the allocations the engine started with)."""
+        import logging
+        log = logging.getLogger('fair_marl_amd')
         cfg, n, dev = self.cfg, self.n_envs, self.device
-        obs = torch.zeros(n, cfg.N, cfg.obs_dim, dtype=torch.float32, device=dev)
-        rec = torch.zeros(n, self.episode_record_words, dtype=torch.int32, device=dev)
+        node_bytes = self.node_obs.numel() * 4
+        adj_bytes = self.adj_env.numel() * 4
         with torch.cuda.device(dev):
-            nodes, adjs = [self.node_obs], [self.adj_env]
-            try:
-                for _ in range(candidates - 1):
-                    adjs.append(torch.empty_like(self.adj_env))
-                for _ in range(2):
-                    nodes.append(torch.empty_like(self.node_obs))
-            except torch.cuda.OutOfMemoryError:
-                pass
+            free, _ = torch.cuda.mem_get_info(dev)
+            first_row = (candidates - 1) * adj_bytes + (64 << 20)
+            if first_row > free // 2:   # never take more than half of what is left
+                log.info('output placement probe skipped: %.1f GB of candidates would not fit beside the %.1f GB in use',
+                         first_row / 1e9, (torch.cuda.mem_get_info(dev)[1] - free) / 1e9)
+                return
+            obs = torch.zeros(n, cfg.N, cfg.obs_dim, dtype=torch.float32, device=dev)
+            rec = torch.zeros(n, self.episode_record_words, dtype=torch.int32, device=dev)
+            nodes, adjs = [self.node_obs], [self.adj_env] + [torch.empty_like(self.adj_env) for _ in range(candidates - 1)]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            times = []
-            for node in nodes:
+
+            def time_row(node):
                 row = []
                 for adj in adjs:
                     for _ in range(2):
@@ -116,12 +125,23 @@ class RolloutEngine:
                     e1.record()
                     e1.synchronize()
                     row.append(e0.elapsed_time(e1) / launches)
-                times.append(row)
+                return row
+            times = [time_row(nodes[0])]
+            spread = max(times[0]) / min(times[0]) - 1.0
+            free, _ = torch.cuda.mem_get_info(dev)
+            if spread < min_spread:
+                log.info('output placement: the %d adj candidates differ by %.1f %% on this box, probe stopped', candidates, 100 * spread)
+            elif 2 * node_bytes > free // 2:
+                log.info('output placement: node_obs candidates (%.1f GB) skipped, %.1f GB free', 2 * node_bytes / 1e9, free / 1e9)
+            else:
+                for _ in range(2):
+                    nodes.append(torch.empty_like(self.node_obs))
+                    times.append(time_row(nodes[-1]))
             bi, bj = min(((i, j) for i in range(len(nodes)) for j in range(len(adjs))), key=lambda ij: times[ij[0]][ij[1]])
             self.node_obs, self.adj_env = nodes[bi], adjs[bj]
             self.node_obs.zero_()
             self.adj_env.zero_()
-            del nodes, adjs, node, adj, obs, rec
+            del nodes, adjs, obs, rec
             torch.cuda.empty_cache()   # hand the losing allocations back to the driver
         self.placement_ms = times
 

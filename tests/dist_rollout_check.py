@@ -28,14 +28,19 @@ def main():
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
     torch.cuda.set_device(device)
     dist.init_process_group('gloo')
-    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=3, num_walls=1, episode_length=6)
+    if 'formation' in sys.argv[1:]:   # BASELINE config 4's scenario: the node features need the per-step graph record too
+        cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=5, num_landmarks=1, num_obstacles=2, episode_length=6,
+                           min_dist_thresh=0.3)
+    else:
+        cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=3, num_walls=1, episode_length=6)
     per, T, seed = 96, 20, 11                      # three auto-resets inside T steps
     n_total = per * world
     lo, hi = shard_range(n_total, world, rank)
     assert hi - lo == per
-    eng = fm.RolloutEngine(cfg, per, device=device, seed=seed, env_offset=lo)
-    tg = TrajectoryGather(per, cfg.N, cfg.obs_dim, device, dst=0, depth=2, episode_words=eng.episode_record_words)
-    sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done) for r in tg.records]
+    eng = fm.RolloutEngine(cfg, per, device=device, seed=seed, env_offset=lo, emit_graph_record=True)
+    tg = TrajectoryGather(per, cfg.N, cfg.obs_dim, device, dst=0, depth=2, episode_words=eng.episode_record_words,
+                          graph_words=eng.step_record_words)
+    sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done, graph_record=r.graph) for r in tg.records]
     g = torch.Generator(device='cpu')
     g.manual_seed(5)
     tape = torch.randint(0, 5, (T, n_total, cfg.N), generator=g, dtype=torch.int32).to(device)   # same on every rank
@@ -65,12 +70,13 @@ def main():
         if rank == 0:
             torch.cuda.synchronize(device)
             episode = tg.gathered_episode()
+            graphs = tg.gathered_graph(t)
             for r, (obs, rew, done) in enumerate(tg.gathered(t)):
                 l2, h2 = shard_range(n_total, world, r)
                 assert torch.equal(obs, f_obs[l2:h2]), 'obs of rank %d at step %d' % (r, t)
                 assert torch.equal(rew, f_rew[l2:h2]) and torch.equal(done.bool(), f_done[l2:h2].bool())
                 # node_obs / adj never travel: rebuilt from the gathered rows + this episode's record
-                node, adj = eng.rebuild_graph(obs, episode[r])
+                node, adj = eng.rebuild_graph(obs, episode[r], step_record=graphs[r])
                 assert torch.equal(node, f_node[l2:h2]), 'rebuilt node_obs of rank %d at step %d' % (r, t)
                 assert torch.equal(adj, f_adj[l2:h2, 0]), 'rebuilt adj of rank %d at step %d' % (r, t)
                 checked += 1

@@ -258,6 +258,8 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
     one unsharded engine bit for bit (tests/dist_rollout_check.py)."""
     out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py')])
     assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
+    out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py'), 'formation'])   # + the per-step graph record
+    assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
 
 
 def test_bench_two_ranks_rehearsal():
@@ -738,6 +740,25 @@ def test_exhausted_rejection_sampling_is_reported():
     roomy = fm.RolloutEngine(fm.EnvConfig(num_agents=6, num_landmarks=6, num_obstacles=3), 64, device=DEV, seed=seed)
     roomy.reset()
     assert int(roomy.placement_exhausted().abs().sum()) == 0
+
+
+def test_placement_probe_is_bounded(monkeypatch, caplog):
+    """RolloutEngine's output-placement probe (profiles/r2_placement_tcc.md): runs on request, never changes results,
+    and steps aside -- with a log line -- when its candidate allocations would not fit beside what owns the HBM."""
+    import logging
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=4)
+    plain = fm.RolloutEngine(cfg, 512, device=DEV, seed=3, tune_placement=0)
+    tuned = fm.RolloutEngine(cfg, 512, device=DEV, seed=3, tune_placement=4)
+    assert plain.placement_ms is None and len(tuned.placement_ms[0]) == 4 and len(tuned.placement_ms) in (1, 3)
+    plain.reset(); tuned.reset()
+    a = torch.randint(0, 5, (512, 4), device=DEV, dtype=torch.int32)
+    ra, rb = plain.step(a), tuned.step(a)
+    assert torch.equal(ra[2], rb[2]) and torch.equal(plain.adj_env, tuned.adj_env)
+    real = torch.cuda.mem_get_info
+    monkeypatch.setattr(torch.cuda, 'mem_get_info', lambda dev=None: (1 << 20, real(dev)[1]))   # "1 MB left"
+    with caplog.at_level(logging.INFO, logger='fair_marl_amd'):
+        crowded = fm.RolloutEngine(cfg, 512, device=DEV, seed=3, tune_placement=4)
+    assert crowded.placement_ms is None and 'probe skipped' in caplog.text
 
 
 def test_misaligned_output_buffers():
