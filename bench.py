@@ -250,7 +250,7 @@ def main():
         torch.cuda.synchronize(device)
         kernel_ms_eager = eng.profile_read()
         eng.profile_enable(0)
-        episode_graph = eng.capture_steps(tape)
+        episode_graph = eng.capture_steps(tape, lockstep=True)   # whole episodes from phase 0: one reset per episode in the graph
 
         def run(first, count):   # noqa: F811 -- whole episodes, one launch each
             for _ in range(count // tape_len):

@@ -51,6 +51,8 @@ _SIGS = {
     'fmarl_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs), C.c_void_p]),
     'fmarl_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs),
                              C.c_int, C.c_void_p]),
+    'fmarl_get_phase': (C.c_int, [C.c_void_p]),
+    'fmarl_set_phase': (C.c_int, [C.c_void_p, C.c_int]),
     'fmarl_state_changed': (C.c_int, [C.c_void_p]),
     'fmarl_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'fmarl_set_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -472,11 +472,16 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
         // the staging stream and its events are not part of the caller's graph
         if (h->async) return fail(FMARL_EINVAL, "fmarl_step: stream capture needs a handle created without FMARL_FLAG_ASYNC_RESET");
-        // Nothing runs during capture and a replay can start at any phase of an episode, any number of times: the
-        // reset-or-not decision must not be baked from the host's mirror of the step counter.  Every captured step
-        // enqueues the auto-reset launches, which test cur_step per env on the device.
-        h->captured = true;
-        h->lockstep = false;
+        if (auto_reset == FMARL_RESET_LOCKSTEP) {
+            // the caller vouches for the replay phase (include/fmarl.h): decide from the host mirror like an eager step
+            if (!h->lockstep) return fail(FMARL_EINVAL, "fmarl_step: FMARL_RESET_LOCKSTEP capture needs envs in lockstep (fmarl_get_phase() >= 0)");
+        } else {
+            // Nothing runs during capture and a replay can start at any phase of an episode, any number of times: the
+            // reset-or-not decision must not be baked from the host's mirror of the step counter.  Every captured step
+            // enqueues the auto-reset launches, which test cur_step per env on the device.
+            h->captured = true;
+            h->lockstep = false;
+        }
     }
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
@@ -526,6 +531,18 @@ int fmarl_set_state(void *handle, void *state, int field, const void *src, void 
     int rc = copy_field((Handle *)handle, state, field, (void *)src, true, (hipStream_t)stream, "fmarl_set_state");
     if (rc == FMARL_OK) rc = fmarl_state_changed(handle);
     return rc;
+}
+
+int fmarl_get_phase(void *handle) {
+    Handle *h = (Handle *)handle;
+    return h && h->lockstep ? h->host_step : -1;
+}
+
+int fmarl_set_phase(void *handle, int phase) {
+    Handle *h = (Handle *)handle;
+    if (!h || !h->lockstep || phase < 0 || phase >= h->cfg.episode_length) return fail(FMARL_EINVAL, "fmarl_set_phase: envs not in lockstep or bad phase");
+    h->host_step = phase;
+    return FMARL_OK;
 }
 
 int fmarl_state_changed(void *handle) {

@@ -292,7 +292,7 @@ class RolloutEngine:
             vec_ptr = a.data_ptr()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fmarl_step(self.handle, self.state.data_ptr(), idx_ptr, vec_ptr,
-                                           C.byref(self.outs.c), 1 if auto_reset else 0, self._stream()), 'fmarl_step')
+                                           C.byref(self.outs.c), int(auto_reset), self._stream()), 'fmarl_step')
         self._last_actions = a  # keep alive until the stream has consumed it
         return self.obs, self.agent_id, self.node_obs, self.adj, self.reward, self.done, self.info
 
@@ -496,28 +496,45 @@ class RolloutEngine:
         return node_obs, adj_env
 
     # ------------------------------------------------------------------ launch-bound batches: one graph per episode
-    def capture_steps(self, action_tape, auto_reset=True):
-        """Capture ``len(action_tape)`` consecutive steps (e.g. one episode incl. the auto-reset that ends it) into a
-        hipGraph and return it; ``graph.replay()`` then runs them with one launch.  For small batches the step kernel
-        takes 10-20 us and the host-side launch path is the larger part of a step (BASELINE config 2: 25 -> 17 us per
-        step).  ``action_tape`` (T, n, N) int32 or (T, n, N, 5) float32 is read at replay time: refill it in place
-        between replays.  Each step writes the engine's current output set, so a consumer that wants every step of the
-        episode passes per-step sets of a DeviceRolloutBuffer via ``outputs`` of ``capture_rollout``.  Needs the
-        synchronous reset (``async_reset=False``): the staged reset owns a side stream (refused by the library)."""
-        return self.capture_rollout(action_tape, None, auto_reset)
+    @property
+    def phase(self):
+        """Steps since the last reset of all envs while they run in lockstep, else -1 (host-side, no device access)."""
+        return int(self.lib.fmarl_get_phase(self.handle))
 
-    def capture_rollout(self, action_tape, outputs=None, auto_reset=True):
+    def capture_steps(self, action_tape, auto_reset=True, lockstep=False):
+        """Capture ``len(action_tape)`` consecutive steps into a hipGraph and return it; ``graph.replay()`` then runs them
+        with one launch.  For small batches the step kernel takes 10-20 us and the host-side launch path is the larger
+        part of a step.  ``action_tape`` (T, n, N) int32 or (T, n, N, 5) float32 is read at replay time: refill it in place
+        between replays.  Each step writes the engine's current output set, so a consumer that wants every step passes
+        per-step sets of a DeviceRolloutBuffer via ``outputs`` of ``capture_rollout``.  Needs the synchronous reset
+        (``async_reset=False``): the staged reset owns a side stream (refused by the library).
+
+        By default every captured step carries the device-side auto-reset test, so the graph may hold any number of steps
+        and be replayed from any phase of an episode.  ``lockstep=True`` bakes the reset decision from the host's mirror of
+        the common step counter instead (one reset per episode in the graph instead of a test per step: BASELINE config 2,
+        20.5 -> 14.7 us per step); the returned object then refuses a replay from any other episode phase than the one it
+        was captured at."""
+        return self.capture_rollout(action_tape, None, auto_reset, lockstep)
+
+    def capture_rollout(self, action_tape, outputs=None, auto_reset=True, lockstep=False):
         """As ``capture_steps``; step t writes ``outputs[t]`` (an OutputSet, e.g. a time slot of a rollout buffer)."""
         tape = action_tape.to(self.device)
+        phase0 = self.phase
+        if lockstep and phase0 < 0:
+            raise RuntimeError('lockstep capture needs all envs in lockstep: reset() them first (phase is -1)')
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
+        mode = (2 if lockstep else 1) if auto_reset else 0
         with torch.cuda.device(self.device), torch.cuda.graph(graph):
             for t in range(tape.shape[0]):
                 if outputs is not None:
                     self.use_outputs(outputs[t])
-                self.step(tape[t], auto_reset=auto_reset)
+                self.step(tape[t], auto_reset=mode)
         graph._fmarl_keep = (tape, outputs)   # the captured launches point into these
-        return graph
+        if not lockstep:
+            return graph
+        _lib.check(self.lib.fmarl_set_phase(self.handle, phase0), 'fmarl_set_phase')   # nothing ran during the capture
+        return _LockstepGraph(self, graph, phase0, int(tape.shape[0]))
 
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, capacity):
@@ -545,3 +562,17 @@ class RolloutEngine:
             self.close()
         except Exception:
             pass
+
+
+class _LockstepGraph(object):
+    """A graph captured with the reset decisions baked from the host's step mirror: valid from one episode phase only."""
+
+    def __init__(self, engine, graph, phase0, steps):
+        self.engine, self.graph, self.phase0, self.steps = engine, graph, phase0, steps
+
+    def replay(self):
+        eng = self.engine
+        if eng.phase != self.phase0:
+            raise RuntimeError('graph captured at episode phase %d, the engine is at %d' % (self.phase0, eng.phase))
+        self.graph.replay()
+        _lib.check(eng.lib.fmarl_set_phase(eng.handle, (self.phase0 + self.steps) % eng.cfg.episode_length), 'fmarl_set_phase')

@@ -193,11 +193,24 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask,
  * are all done are reset and their obs / node_obs / adj are the reset observation while
  * reward / done / info stay those of the terminal step.
  * hipGraph capture: the call only enqueues work on `stream`, so a run of steps can be captured (handles without
- * FMARL_FLAG_ASYNC_RESET).  A captured step always enqueues the auto-reset launches, which test every env's step
- * counter on the device -- a graph may hold any number of steps and be replayed from any phase of an episode; the
- * handle stops mirroring the step counter on the host from then on. */
+ * FMARL_FLAG_ASYNC_RESET).  With auto_reset = FMARL_RESET_AUTO a captured step always enqueues the auto-reset launches,
+ * which test every env's step counter on the device -- a graph may hold any number of steps and be replayed from any
+ * phase of an episode; the handle stops mirroring the step counter on the host from then on.
+ * auto_reset = FMARL_RESET_LOCKSTEP is the lean variant for launch-bound batches: while all envs share one step counter
+ * (fmarl_get_phase() >= 0) a captured step takes the reset-or-not decision from the host's mirror, exactly like an eager
+ * step, so the graph holds one reset per episode instead of one test per step.  Such a graph is valid only when
+ * replayed from the episode phase it was captured at: after capturing T steps call fmarl_set_phase(handle, phase before
+ * the capture) (nothing ran), and after every replay fmarl_set_phase(handle, (phase + T) % episode_length).  Outside
+ * capture the two values behave the same. */
+#define FMARL_RESET_AUTO 1
+#define FMARL_RESET_LOCKSTEP 2
 int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
                const FmarlOutputs *outs, int auto_reset, void *stream);
+
+/* Host-side mirror of the envs' common step counter: steps since the last reset of all envs, or -1 when the envs are not
+ * known to be in lockstep (masked resets, fmarl_set_state, graphs captured with FMARL_RESET_AUTO, fairnav).  No device access. */
+int fmarl_get_phase(void *handle);
+int fmarl_set_phase(void *handle, int phase);
 
 /* Copy one state field (FMARL_F_*) out of / into the state buffer, in the field's own shape and dtype
  * (= the reference's attribute layout, e.g. agent.state.p_pos as f64 (n, N, 2)).  `dst` / `src` may be host

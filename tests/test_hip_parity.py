@@ -687,6 +687,44 @@ def test_graph_of_any_length_replays_across_episode_ends():
         assert torch.equal(ra[0], rb[0]) and torch.equal(ra[5], rb[5]), t
 
 
+def test_lockstep_graph_is_lean_and_refuses_another_phase():
+    """capture_steps(lockstep=True): reset decisions baked from the host's step mirror (one reset per episode in the
+    graph); bit-identical to eager stepping from the captured phase, refused from any other."""
+    cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=3, episode_length=6)
+    n, T = 96, 9
+    eager = fm.RolloutEngine(cfg, n, device=DEV, seed=2, async_reset=False)
+    graph = fm.RolloutEngine(cfg, n, device=DEV, seed=2, async_reset=False)
+    gen = torch.Generator(device=DEV); gen.manual_seed(4)
+    tape = torch.randint(0, 5, (T, n, 3), device=DEV, generator=gen, dtype=torch.int32)
+    eager.reset(); graph.reset()
+    a = torch.randint(0, 5, (n, 3), device=DEV, generator=gen, dtype=torch.int32)
+    eager.step(a); graph.step(a)
+    assert graph.phase == 1
+    g = graph.capture_steps(tape, lockstep=True)      # 9 steps from phase 1: resets inside at step 5 of the graph
+    assert graph.phase == 1
+    for rep in range(2):                               # phase 1 -> 4 -> (needs phase 1 again: 12 steps = 2 episodes later)
+        g.replay()
+        for t in range(T):
+            eager.step(tape[t])
+        torch.cuda.synchronize()
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+            assert torch.equal(getattr(eager, k), getattr(graph, k)), (rep, k)
+        sa, sb = eager.get_state(), graph.get_state()
+        assert all(np.array_equal(sa[k], sb[k]) for k in sa)
+        assert graph.phase == (1 + T) % 6
+        if rep == 0:
+            with pytest.raises(RuntimeError, match='captured at episode phase 1'):
+                g.replay()
+            for _ in range(3):                         # eager steps bring the phase back to 1
+                a = torch.randint(0, 5, (n, 3), device=DEV, generator=gen, dtype=torch.int32)
+                eager.step(a); graph.step(a)
+            assert graph.phase == 1
+    graph.set_state(graph.get_state())                 # the caller wrote the state: no lockstep knowledge left
+    assert graph.phase == -1
+    with pytest.raises(RuntimeError, match='lockstep'):
+        graph.capture_steps(tape, lockstep=True)
+
+
 def test_captured_inserts_fill_masks_like_eager_inserts():
     """DeviceRolloutBuffer.capture: the graph holds the mask / active_mask ops of insert too."""
     from fair_marl_amd.rollout_buffer import DeviceRolloutBuffer
