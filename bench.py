@@ -206,7 +206,7 @@ def main():
     depth = 2
     # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for
     # fair_graph_formation, a 36-byte-per-agent record of the step's scenario state (RolloutEngine.step_record_words)
-    episodes = cfg.scenario_name in ('navigation_graph', 'fair_graph_formation')
+    episodes = True
     tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
                           episode_words=eng.episode_record_words if episodes else 0,
                           graph_words=eng.step_record_words if eng.emit_graph_record else 0) if gather else None

@@ -33,6 +33,8 @@ struct FairNavLds {
     __device__ FairNavLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
     __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
     __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }   // (vx, vy, newly-stopped, -)
+    __device__ float2 *posf() const { return (float2 *)(base + p.lds_posf); }       // (float)pos of every entity
+    __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2)
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double *D() const { return (double *)(base + p.n_D); }               // [N][L] |x_a - goal_g|
@@ -48,8 +50,9 @@ struct FairNavLds {
     // [dv (2) | dx (2) | goal or dx (2) | occupancy, history / 1, index | dx or wall corners (4) | type]
     __device__ void node_row(uint32_t i, uint32_t e, float (&o)[13]) const {
         const uint32_t N = p.N, first_obst = p.N + p.L, first_wall = first_obst + p.O;
-        const double2 xi = pos()[i], xe = pos()[e];
-        const float dx = (float)(xe.x - xi.x), dy = (float)(xe.y - xi.y);
+        // differences of the f32 roundings (as the other two scenarios' rows): what a learner-side rebuild starts from
+        const float2 pi = posf()[i], pe = posf()[e];
+        const float dx = pe.x - pi.x, dy = pe.y - pi.y;
         // velocities as they stand when graph_observation(i) runs: reward(a <= i) may have stopped a
         const float4 ai = agentf()[i];
         const float vix = ai.z != 0.f ? 0.f : ai.x, viy = ai.z != 0.f ? 0.f : ai.y;
@@ -63,8 +66,8 @@ struct FairNavLds {
         o[2] = dx; o[3] = dy; o[4] = dx; o[5] = dy; o[8] = dx; o[9] = dy; o[10] = dx; o[11] = dy;
         if (e < N) {
             const NavRow r = rows()[i * N + e];
-            const double2 gl = r.code >= 0 ? pos()[N + r.code] : xe;
-            o[4] = (float)(gl.x - xi.x); o[5] = (float)(gl.y - xi.y);
+            const float2 gl = r.code >= 0 ? posf()[N + r.code] : pe;
+            o[4] = gl.x - pi.x; o[5] = gl.y - pi.y;
             o[6] = r.occ; o[7] = r.hist;
             o[12] = 0.f;
         } else {
@@ -73,9 +76,8 @@ struct FairNavLds {
             o[12] = e < first_obst ? 1.f : (e < first_wall ? 2.f : 3.f);
         }
         if (e >= first_wall) {   // corners (e0, axis + w/2), (e1, axis - w/2)
-            const double *wl = wall() + (e - first_wall) * 4;
-            o[8] = (float)(wl[1] - xi.x); o[9] = (float)(wl[0] + kWallWidth / 2 - xi.y);
-            o[10] = (float)(wl[2] - xi.x); o[11] = (float)(wl[0] - kWallWidth / 2 - xi.y);
+            const float4 wc = wallf()[e - first_wall];
+            o[8] = wc.x - pi.x; o[9] = wc.y - pi.y; o[10] = wc.z - pi.x; o[11] = wc.w - pi.y;
         }
     }
 };
@@ -144,6 +146,41 @@ __device__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool 
         for (int j = 0; j < G; ++j) c[j] = (lane < p.N && j < p.N) ? t.D()[lane * p.L + j] : 0.0;
         const int mc = lexifair_group<G>(c, p.N);
         if (lane < p.N) t.match()[lane] = mc;
+    }
+}
+
+// node_obs rows of the workgroup's envs (nf:1222-1334) from the LDS tables: shared by the step / reset passes and the
+// learner-side rebuild (fairnav_rebuild_kernel).
+__device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+    const int tid = threadIdx.x, N = p.N;
+    if (o.node_obs) {
+        // one lane per (ego, entity) row: the 13 features share their loads; the rows leave through the waves' LDS
+        // windows (fmarl_step.hip flush_rows) unless some env of the workgroup keeps its previous rows
+        const uint32_t NE = N * p.E, total = nenv * NE;
+        float *dst = o.node_obs + (size_t)env0 * NE * 13;
+        const bool some_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
+        if (!some_skip) {
+            for (uint32_t base = 0; base < total; base += kThreads) {
+                const uint32_t q = base + tid, w0 = base + (tid & ~63u);
+                float row[13];
+                if (q < total) {
+                    const uint32_t e_l = p.dC4.div(q), r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;   // dC4 = N * E
+                    FairNavLds(p, lds, e_l).node_row(a, e, row);
+                }
+                flush_rows<13>(p, lds, row, 13, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
+            }
+        } else {
+            for (uint32_t q = tid; q < total; q += kThreads) {
+                const uint32_t e_l = p.dC4.div(q);
+                const FairNavLds te(p, lds, e_l);
+                if (te.skip()) continue;
+                const uint32_t r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;
+                float row[13];
+                te.node_row(a, e, row);
+#pragma unroll
+                for (int f = 0; f < 13; ++f) dst[(size_t)q * 13 + f] = row[f];
+            }
+        }
     }
 }
 
@@ -253,6 +290,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             s_stat[3 * N + i] = Tr_old; s_stat[4 * N + i] = Tr_new;
         }
         t.agentf()[i] = make_float4((float)v.x, (float)v.y, newly ? 1.f : 0.f, 0.f);
+        t.posf()[i] = make_float2((float)x.x, (float)x.y);
     }
     __syncthreads();
     bool emit = false, ended = false;
@@ -314,6 +352,17 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             ob[8] = (float)(sec.x - x.x); ob[9] = (float)(sec.y - x.y); ob[10] = (float)og.second_occ;
         }
         if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
+        if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
+            uint32_t *r = o.graph_record + g * (size_t)(5 + 3 * N);
+            const float4 af = t.agentf()[i];
+            const float2 pf = t.posf()[i];
+            r[0] = __float_as_uint(pf.x); r[1] = __float_as_uint(pf.y); r[2] = __float_as_uint(af.x); r[3] = __float_as_uint(af.y);
+            r[4] = __float_as_uint(af.z);
+            for (int e = 0; e < N; ++e) {
+                const NavRow nr = t.rows()[i * N + e];
+                r[5 + 3 * e] = (uint32_t)nr.code; r[6 + 3 * e] = __float_as_uint(nr.occ); r[7 + 3 * e] = __float_as_uint(nr.hist);
+            }
+        }
         if (STEP) {
             double fairness, m, sd;   // nf:693-698, same stale / fresh rule as navigation_graph
             if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
@@ -370,36 +419,8 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     }
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
     if (FMARL_SKIP(p, 32)) return ended;
-    if (o.node_obs) {
-        // one lane per (ego, entity) row: the 13 features share their loads; the rows leave through the waves' LDS
-        // windows (fmarl_step.hip flush_rows) unless some env of the workgroup keeps its previous rows
-        const uint32_t NE = N * p.E, total = nenv * NE;
-        float *dst = o.node_obs + (size_t)env0 * NE * 13;
-        const bool some_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
-        if (!some_skip) {
-            for (uint32_t base = 0; base < total; base += kThreads) {
-                const uint32_t q = base + tid, w0 = base + (tid & ~63u);
-                float row[13];
-                if (q < total) {
-                    const uint32_t e_l = p.dC4.div(q), r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;   // dC4 = N * E
-                    FairNavLds(p, lds, e_l).node_row(a, e, row);
-                }
-                flush_rows<13>(p, lds, row, 13, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
-            }
-        } else {
-            for (uint32_t q = tid; q < total; q += kThreads) {
-                const uint32_t e_l = p.dC4.div(q);
-                const FairNavLds te(p, lds, e_l);
-                if (te.skip()) continue;
-                const uint32_t r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;
-                float row[13];
-                te.node_row(a, e, row);
-#pragma unroll
-                for (int f = 0; f < 13; ++f) dst[(size_t)q * 13 + f] = row[f];
-            }
-        }
-    }
-    emit_adj<false>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    fairnav_emit_rows(p, o, lds, env0, nenv);
+    emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
     return ended;
 }
 
@@ -429,6 +450,49 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
     __threadfence_block();   // the reset pass re-reads the state of the placed envs from global memory
     __syncthreads();
     fairnav_pass<false>(p, o, lds, nullptr, nullptr, 0, true, ended);
+}
+
+// Learner-side reconstruction of node_obs / adj of nav_fairassign_fairrew_formation_graph envs from the gathered records:
+// per agent and step [x, y, vx, vy, newly-stopped | (goal code, occupancy, history) x N] written by fairnav_kernel
+// (FmarlOutputs.graph_record) + the once-per-episode record of the static entities (fmarl_rebuild.hip layout).  Same LDS
+// tables, same emission code: bit-identical to the sender's.  n_envs is the caller's.
+__global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec,
+                                                                   const uint32_t *step_rec, int n_envs) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, N = p.N;
+    const int env0 = blockIdx.x * p.epb;
+    const int nenv = min(p.epb, n_envs - env0);
+    const int el = tid / N, i = tid - el * N;
+    const int LO = p.L + p.O, words = 2 * N + 2 * LO + 6 * p.W;   // episode_record_words (fmarl_rebuild.hip)
+    if (el < nenv) {
+        const FairNavLds t(p, lds, el);
+        const uint32_t *r = step_rec + ((size_t)(env0 + el) * N + i) * (size_t)(5 + 3 * N);
+        t.posf()[i] = make_float2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        t.agentf()[i] = make_float4(__uint_as_float(r[2]), __uint_as_float(r[3]), __uint_as_float(r[4]), 0.f);
+        for (int e = 0; e < N; ++e) {
+            NavRow nr;
+            nr.code = (int)r[5 + 3 * e]; nr.occ = __uint_as_float(r[6 + 3 * e]); nr.hist = __uint_as_float(r[7 + 3 * e]); nr.pad = 0;
+            t.rows()[i * N + e] = nr;
+        }
+        if (i == 0) *t.flag() = 0;
+    }
+    for (int k = tid; k < nenv * LO; k += kThreads) {
+        const int e_l = k / LO, j = k - e_l * LO;
+        const float *sp = (const float *)(ep_rec + (size_t)(env0 + e_l) * words) + 2 * (N + j);
+        FairNavLds(p, lds, e_l).posf()[N + j] = make_float2(sp[0], sp[1]);
+    }
+    for (int k = tid; k < nenv * p.W; k += kThreads) {
+        const int e_l = k / p.W, w = k - e_l * p.W;
+        const FairNavLds t(p, lds, e_l);
+        const uint32_t *q = ep_rec + (size_t)(env0 + e_l) * words + 2 * (N + LO) + 6 * w;
+        const double axis = __longlong_as_double((long long)((unsigned long long)q[0] | ((unsigned long long)q[1] << 32)));
+        const float *qf = (const float *)q;
+        ((float4 *)(t.base + p.lds_wallf))[w] = make_float4(qf[2], (float)(axis + kWallWidth / 2), qf[3], (float)(axis - kWallWidth / 2));
+        t.posf()[N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
+    }
+    __syncthreads();
+    fairnav_emit_rows(p, o, lds, env0, nenv);
+    emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
 }
 
 }  // namespace fmarl

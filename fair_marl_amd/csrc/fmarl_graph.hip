@@ -196,8 +196,7 @@ __global__ __launch_bounds__(256) void edge_scan_fill_kernel(const int32_t *nnz,
 }
 
 // processAdj from the world state: one wave per graph recomputes the env's adj entries exactly as
-// the emission did -- float32 roundings of the entity positions (navigation_graph, fair_graph_formation) or the float32
-// rounding of the float64 differences (fairnav) -- and compacts the policy edges 0 < d < max_edge_dist in row-major
+// the emission did -- differences of the float32 roundings of the entity positions -- and compacts the policy edges 0 < d < max_edge_dist in row-major
 // order behind offsets[b]: rows | cols with node ids b * E + r, edge_attr = the adj entry.  adj is not read.
 __global__ __launch_bounds__(256) void edge_fill_state_kernel(Params p, const int64_t *offsets, int64_t *edge_index,
                                                               float *edge_attr, int64_t capacity, int gpe) {
@@ -215,8 +214,7 @@ __global__ __launch_bounds__(256) void edge_fill_state_kernel(Params p, const in
         if (q < EE) {
             r = q / E; c = q - r * E;
             const double2 a = entity_pos(p, env, r), bb = entity_pos(p, env, c);
-            d = p.has_posf ? dist_f32((float)a.x - (float)bb.x, (float)a.y - (float)bb.y)
-                           : dist_f32((float)(a.x - bb.x), (float)(a.y - bb.y));
+            d = dist_f32((float)a.x - (float)bb.x, (float)a.y - (float)bb.y);
         }
         const bool on = q < EE && d > 0.f && d < p.edge_thr;
         const unsigned long long m = __ballot(on);

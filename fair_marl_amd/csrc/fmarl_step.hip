@@ -223,13 +223,8 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
                 const EnvLds t(p, lds, el);
                 if (t.skip()) { ok[j] = false; continue; }
                 const uint32_t r = q - elq * EE, a = p.dE.div(r), b = r - a * p.E;
-                if (p.has_posf) {   // the f32 position table (what a learner-side rebuild has)
-                    const float2 pa = t.posf()[a], pb = t.posf()[b];
-                    v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
-                } else {
-                    const double2 pa = t.pos()[a], pb = t.pos()[b];
-                    v[j] = dist_f32((float)(pa.x - pb.x), (float)(pa.y - pb.y));
-                }
+                const float2 pa = t.posf()[a], pb = t.posf()[b];   // the f32 position table (what a learner-side rebuild has)
+                v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
                 if (count) ec.add((int)el, v[j]);
             }
         }
@@ -244,8 +239,6 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
 
 // adj of the envs [el_begin, el_end) of the workgroup by `nthr` threads: the 16-byte path when E % 4 == 0 and the f32
 // position table exists, else the generic one; with FmarlOutputs.edge_nnz also every emitted env's policy-edge count.
-// CAN_VEC = false: the caller's scenario never has the float32 position table (fairnav), so the 16-byte path is not compiled in.
-template <bool CAN_VEC = true>
 __device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
                                          int el_end, uint32_t thr, uint32_t nthr) {
     if (!o.adj) return;
@@ -256,7 +249,7 @@ __device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o,
         for (int el = el_begin + (int)thr; el < el_end; el += nthr) *ec.slot(el) = 0;
         emit_sync(nthr);
     }
-    if (CAN_VEC && p.vec_adj) {
+    if (p.vec_adj) {
         // 16-byte path (E % 4 == 0): the threads stream the region front to back (a workgroup's four waves write one
         // 4 KiB window at a time); a lane computes |x_a - x_b| for four b from the f32 position table (the roundings
         // node_obs starts from; one 8-byte and two 16-byte LDS reads per chunk).
@@ -346,9 +339,9 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         int env = env0 + el;
         const double2 x = k < p.L ? p.landmark_pos[(size_t)env * p.L + k] : p.obstacle_pos[(size_t)env * p.O + (k - p.L)];
         pos[p.N + k] = x;
-        if (p.has_posf) ((float2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)x.x, (float)x.y);
+        ((float2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)x.x, (float)x.y);
     }
-    if (p.has_posf && p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH)
+    if (p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH)
         for (int t = threadIdx.x; t < nenv; t += kThreads)
             *(float4 *)(lds + (size_t)t * p.lds_env_bytes + p.lds_constf) = make_float4(0.f, 1.f, 2.f, 3.f);
     for (int t = threadIdx.x; t < nenv * p.W; t += kThreads) {
@@ -360,10 +353,10 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         double *wl = (double *)(base + p.lds_wall) + w * 4;
         wl[0] = axis; wl[1] = p.wall_e0[g]; wl[2] = p.wall_e1[g]; wl[3] = (double)orient;
         // wall "sphere" centre: (0, axis) for 'H', (axis, 0) for 'V' (navigation_graph.py:309-324)
-        if (p.has_posf) ((float4 *)(base + p.lds_wallf))[w] = make_float4((float)wl[1], (float)(axis + kWallWidth / 2), (float)wl[2], (float)(axis - kWallWidth / 2));
+        ((float4 *)(base + p.lds_wallf))[w] = make_float4((float)wl[1], (float)(axis + kWallWidth / 2), (float)wl[2], (float)(axis - kWallWidth / 2));
         const double2 c = orient == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
         ((double2 *)(base + p.lds_pos))[p.N + LO + w] = c;
-        if (p.has_posf) ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
+        ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
     }
 }
 

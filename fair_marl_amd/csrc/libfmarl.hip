@@ -288,10 +288,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 2 * p.N * 8 + 4 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 20);   // flag + three scenario words + the env's policy-edge counter
-    p.has_posf = !fnav;   // f32 copy of the entity positions: adj (and the formation scenario's node rows) start from it
+    p.has_posf = 1;   // f32 copy of the entity positions: adj and the node rows start from it (all three scenarios)
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     p.lds_wallf = off;  off = align16(off + (p.has_posf ? p.W * 16 : 0));
-    p.lds_constf = off; off = align16(off + (p.has_posf && !form ? 16 : 0));
+    p.lds_constf = off; off = align16(off + (!form && !fnav ? 16 : 0));
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
         p.f_slot_old = off; off = align16(off + p.N * 16);
@@ -363,6 +363,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)fairnav_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)fairnav_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)fairnav_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
@@ -666,8 +667,6 @@ int fmarl_pack_episode(void *handle, const void *state, void *record, void *stre
     Handle *h = (Handle *)handle;
     DeviceGuard on_device(h);
     if (!h || !state || !record) return fail(FMARL_EINVAL, "fmarl_pack_episode: null argument");
-    if (h->cfg.scenario == FMARL_SCENARIO_FAIRNAV)
-        return fail(FMARL_EINVAL, "fmarl_pack_episode: nav_fairassign_fairrew_formation_graph has no rebuildable record");
     Params p = bind(h, (void *)state);
     const size_t total = (size_t)p.n_envs * (p.N + p.L + p.O + p.W);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -679,7 +678,9 @@ int fmarl_pack_episode(void *handle, const void *state, void *record, void *stre
 size_t fmarl_step_record_words(const FmarlConfig *cfg) {
     const char *why;
     if (!config_ok(cfg, &why)) { fail(FMARL_EINVAL, "fmarl_step_record_words: %s", why); return 0; }
-    return cfg->scenario == FMARL_SCENARIO_FORMATION ? (size_t)kFormationRecordWords : 0;
+    if (cfg->scenario == FMARL_SCENARIO_FORMATION) return (size_t)kFormationRecordWords;
+    if (cfg->scenario == FMARL_SCENARIO_FAIRNAV) return (size_t)(5 + 3 * cfg->num_agents);
+    return 0;
 }
 
 int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_record, const void *step_record, int n_envs,
@@ -688,15 +689,16 @@ int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_
     DeviceGuard on_device(h);
     if (!h || !episode_record || n_envs < 1 || (!node_obs && !adj)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph_rec: bad argument");
     const int sc = h->cfg.scenario;
-    if (sc == FMARL_SCENARIO_FAIRNAV)
-        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: nav_fairassign_fairrew_formation_graph has no rebuildable record");
     if (sc == FMARL_SCENARIO_NAVIGATION_GRAPH ? !obs : !step_record)
-        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: navigation_graph needs the obs rows, fair_graph_formation the step record");
+        return fail(FMARL_EINVAL, "fmarl_rebuild_graph: navigation_graph needs the obs rows, the two formation scenarios the step record");
     FmarlOutputs o = {};
     o.node_obs = node_obs; o.adj = adj;
     if (!outputs_aligned(h->base, &o)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: node_obs / adj must be 16-byte aligned for this shape");
     const int grid = (n_envs + h->base.epb - 1) / h->base.epb;
-    if (sc == FMARL_SCENARIO_FORMATION)
+    if (sc == FMARL_SCENARIO_FAIRNAV)
+        hipLaunchKernelGGL(fairnav_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o,
+                           (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
+    else if (sc == FMARL_SCENARIO_FORMATION)
         hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o,
                            (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
     else

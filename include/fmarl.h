@@ -90,7 +90,7 @@ typedef struct FmarlOutputs {
                                               emission itself; needs adj.  See fmarl_edge_offsets / fmarl_edge_fill_state */
     uint32_t *graph_record; /* (n, N, fmarl_step_record_words) per-step part of the cross-GPU graph hand-off of the
                                               scenarios whose node features depend on per-step scenario state
-                                              (fair_graph_formation); see fmarl_rebuild_graph_rec                   */
+                                              (the two formation scenarios); see fmarl_rebuild_graph_rec                   */
 } FmarlOutputs;
 
 #define FMARL_INFO_WIDTH 14
@@ -299,7 +299,10 @@ size_t fmarl_episode_record_words(const FmarlConfig *cfg);
  * rows do not carry (obs = concat(v, x, goal - x) + flag, :740-741).  The step kernel therefore writes a compact record
  * beside obs -- 32-bit words per agent: x, y, vx, vy, slot x, slot y (f32), branch mask, flag mask, nearest slot | matched
  * slot << 8 -- 36 B per agent-step against 768 B of node_obs at BASELINE config 4; fmarl_rebuild_graph_rec expands it
- * with the same emission code.  0 words for navigation_graph (obs + the episode record are enough). */
+ * with the same emission code.  nav_fairassign_fairrew_formation_graph (occupancy / history walk,
+ * nav_fairassign_fairrew_formation_graph.py:1222-1334): 5 + 3 N words per agent -- x, y, vx, vy, newly-stopped (f32), then
+ * for every agent entity of the agent's row block (goal landmark index or -1, occupancy, history).  0 words for
+ * navigation_graph (obs + the episode record are enough). */
 size_t fmarl_step_record_words(const FmarlConfig *cfg);
 int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_record, const void *step_record, int n_envs,
                             float *node_obs, float *adj, void *stream);

@@ -31,6 +31,9 @@ def main():
     if 'formation' in sys.argv[1:]:   # BASELINE config 4's scenario: the node features need the per-step graph record too
         cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=5, num_landmarks=1, num_obstacles=2, episode_length=6,
                            min_dist_thresh=0.3)
+    elif 'fairnav' in sys.argv[1:]:   # episodes end env by env: the episode record travels with every step
+        cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3, num_obstacles=2,
+                           episode_length=6, min_dist_thresh=0.35)
     else:
         cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=3, num_walls=1, episode_length=6)
     per, T, seed = 96, 20, 11                      # three auto-resets inside T steps

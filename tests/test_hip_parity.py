@@ -258,8 +258,9 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
     one unsharded engine bit for bit (tests/dist_rollout_check.py)."""
     out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py')])
     assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
-    out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py'), 'formation'])   # + the per-step graph record
-    assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
+    for scenario in ('formation', 'fairnav'):    # + the per-step graph record
+        out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py'), scenario])
+        assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
 
 
 def test_bench_two_ranks_rehearsal():
@@ -316,13 +317,27 @@ def test_bench_fails_loudly_when_the_exchange_cannot_run():
     assert not [l for l in res.stdout.splitlines() if l.startswith('{"metric"')], res.stdout[-3000:]
 
 
-def test_rebuild_is_refused_where_no_record_is_defined():
-    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=4, num_landmarks=4, num_obstacles=2)
-    eng = fm.RolloutEngine(cfg, 8, device=DEV)
+@pytest.mark.parametrize('N,O,W,n', [(3, 3, 0, 200), (4, 2, 2, 150), (10, 3, 0, 40)])
+def test_learner_side_rebuild_of_the_fairnav_graph(N, O, W, n):
+    """Multi-GPU hand-off for nav_fairassign_fairrew_formation_graph: 5 + 3 N words per agent and step (positions,
+    velocities, the stop flag and the agent rows' goal / occupancy / history left by the sequential walk) + the episode
+    record -> node_obs / adj rebuilt bit for bit, through early episode ends (in-kernel resets) too."""
+    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=N, num_landmarks=N, num_obstacles=O,
+                       num_walls=W, episode_length=7, min_dist_thresh=0.35, min_obs_dist=0.6)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=5, emit_graph_record=True)
+    assert eng.step_record_words == 5 + 3 * N
+    g = torch.Generator(device=DEV); g.manual_seed(9)
     eng.reset()
-    with pytest.raises(RuntimeError, match='no rebuildable record'):
-        eng.pack_episode()
-    assert eng.step_record_words == 0
+    rec = eng.pack_episode()
+    episodes0 = eng.get_state()['episode'].copy()
+    for t in range(16):
+        node, adj = eng.rebuild_graph(None, rec, step_record=eng.graph_record)
+        assert torch.equal(node, eng.node_obs), 'node_obs step %d' % t
+        assert torch.equal(adj, eng.adj_env), 'adj step %d' % t
+        eng.step(torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32))
+        assert eng.episode_started          # this scenario's episodes end env by env: the record is re-packed every step
+        eng.pack_episode(out=rec)
+    assert (eng.get_state()['episode'] - episodes0).max() >= 2
 
 
 @pytest.mark.parametrize('N,L,O,n', [(10, 1, 3, 130), (4, 1, 2, 300), (3, 3, 0, 64), (24, 1, 4, 10)])
