@@ -194,7 +194,13 @@ __device__ __forceinline__ bool wall_box_hit(double2 p, double axis, double e0, 
 // Lane exchange inside a 16-lane DPP row (no LDS crossbar, a few cycles instead of a ds_bpermute round
 // trip): quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror.  For a symmetric reduction
 // (min / argmin) the mirrors do the job of xor 4 / xor 8: after the quad steps every quad is uniform.
-template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+// Permutations (quad_perm, row_mirror, row_half_mirror) give every lane a source: mov_dpp, whose destination needs no
+// seed.  Shifts and broadcasts leave some lanes without one: those keep their own value (update_dpp with old = v), which
+// costs a v_mov to seed the destination -- the scans rely on it.
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
+    if constexpr (CTRL <= 0xFF || CTRL == 0x140 || CTRL == 0x141) return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+    else return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
     return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
 }

@@ -117,6 +117,7 @@ struct FormLds {
     __device__ int8_t *near_old0() const { return (int8_t *)(base + p.f_g) + 3 * p.N; }
     __device__ uint32_t *masks() const { return (uint32_t *)(base + p.f_masks); }   // [N][3]: b, flag, obs code
     __device__ double *theta() const { return (double *)(base + p.f_theta); }
+    __device__ double *vdual() const { return (double *)(base + p.f_words); }   // column potentials the last matching left (state)
     __device__ uint32_t *words() const { return (uint32_t *)(base + p.lds_flag) + 1; }   // occ_old, occ_new, occ_final (behind the flag)
     __device__ uint32_t *openmask() const { return (uint32_t *)(base + p.lds_stat + 2 * p.N * 8); }   // bit j: agent j has not arrived yet
     __device__ bool skip() const { return *flag() != 0; }
@@ -143,7 +144,7 @@ __device__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, 
             const uint32_t full = p.N >= 32 ? ~0u : ((1u << p.N) - 1);
             if (*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0) continue;
         }
-        const double *vin = p.match_dual + (size_t)(env0 + el) * p.N;   // global: rewritten only after the matchings
+        const double *vin = t.vdual();   // the state's copy in LDS: nobody writes it during the matchings
         hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
                            which == 0 ? t.theta() : (const double *)t.masks(), vin, which == 0 ? t.theta() : nullptr);
     }
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
         t.pos()[i] = x;
         t.slot_old()[i] = p.slot_pos[g];
+        t.vdual()[i] = p.match_dual[g];
         if (i == 0) { t.words()[0] = 0; t.words()[1] = 0; *t.openmask() = 0; }
         step = p.cur_step[env] + (STEP ? 1 : 0);
         emit = STEP ? !(auto_reset && step >= p.episode_length) : p.reset_flag[env] != 0;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (active) {   // agent x slot distances (ff:650-655), nearest slot within thr, dist_left (ff:453)
         // row minima of c - v for the warm-started matchings (v: the potentials the previous matching of this env left;
         // for the previous slots they are the potentials of exactly those slots, one step of motion ago)
-        const double *vg = p.match_dual + (size_t)env * N;
+        const double *vg = t.vdual();   // (staged in LDS at kernel start: a global load per loop trip would stall every trip)
         double best = 1e300, best_old = 1e300, rbest = 1e300, rbest_old = 1e300;
         int kb = 0, kb_old = 0, rkb = 0, rkb_old = 0;
         for (int k = 0; k < N; ++k) {
