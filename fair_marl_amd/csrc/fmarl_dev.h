@@ -76,6 +76,13 @@ struct Params {
     int *place_fails, *st_place_fails;   // placements accepted after kMaxTries colliding draws (live / staged episode)
 };
 
+// Ordering point between phases of ONE wave that talk through LDS (kernels whose envs each live inside one wave): LDS
+// executes a wave's instructions in order, the fence keeps the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------- Philox4x32-10 (oracle/philox.py)
 constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;

@@ -157,12 +157,6 @@ __device__ __forceinline__ bool wall_box_hit_plain(double2 x, double axis, doubl
     return (axis - s / 2 <= pperp) && (pperp <= axis + s / 2) && (e0 - s / 2 <= ppar) && (ppar <= e1 + s / 2);
 }
 
-// Ordering point between phases of one wave that talk through LDS.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // One branch event of ff:707-739 / ff:916-943 on the occupancy mask.  Returns type (0 = near slot,
 // 1 = Hungarian slot of `ego`, 2 = own position) in bits 1..2 and the observed flag in bit 0.
 __device__ __forceinline__ uint32_t branch_event(int near_e, int g_ego, uint32_t full, uint32_t &occ) {

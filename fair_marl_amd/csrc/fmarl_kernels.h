@@ -9,6 +9,7 @@ __global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                             int auto_reset);
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv);
 __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
+__device__ void load_statics_range(const Params &p, char *lds, int env0, int el_begin, int el_end, int thr, int nthr);
 
 // fmarl_reset.hip
 enum ResetMode { kResetAll = 0, kResetMask = 1, kResetAuto = 2, kResetInit = 3, kResetStage = 4 };

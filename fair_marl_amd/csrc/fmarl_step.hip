@@ -330,11 +330,12 @@ __device__ __forceinline__ void store_agent_rows(const Params &p, char *base, in
     ((float2 *)(base + p.lds_posf))[i] = make_float2((float)x.x, (float)x.y);
 }
 
-// Loads landmarks / obstacles / walls of the workgroup's envs into the LDS entity table.
-__device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
-    const int LO = p.L + p.O;
-    for (int t = threadIdx.x; t < nenv * LO; t += kThreads) {
-        int el = t / LO, k = t - el * LO;
+// Loads landmarks / obstacles / walls of the envs [el_begin, el_end) of the workgroup into their LDS entity tables, by the
+// caller's `nthr` threads (index `thr`): the whole workgroup, or one wave for its own envs.
+__device__ void load_statics_range(const Params &p, char *lds, int env0, int el_begin, int el_end, int thr, int nthr) {
+    const int LO = p.L + p.O, cnt = el_end - el_begin;
+    for (int t = thr; t < cnt * LO; t += nthr) {
+        int el = el_begin + t / LO, k = t % LO;
         double2 *pos = (double2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_pos);
         int env = env0 + el;
         const double2 x = k < p.L ? p.landmark_pos[(size_t)env * p.L + k] : p.obstacle_pos[(size_t)env * p.O + (k - p.L)];
@@ -342,10 +343,10 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         ((float2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)x.x, (float)x.y);
     }
     if (p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH)
-        for (int t = threadIdx.x; t < nenv; t += kThreads)
-            *(float4 *)(lds + (size_t)t * p.lds_env_bytes + p.lds_constf) = make_float4(0.f, 1.f, 2.f, 3.f);
-    for (int t = threadIdx.x; t < nenv * p.W; t += kThreads) {
-        int el = t / p.W, w = t - el * p.W;
+        for (int t = thr; t < cnt; t += nthr)
+            *(float4 *)(lds + (size_t)(el_begin + t) * p.lds_env_bytes + p.lds_constf) = make_float4(0.f, 1.f, 2.f, 3.f);
+    for (int t = thr; t < cnt * p.W; t += nthr) {
+        int el = el_begin + t / p.W, w = t % p.W;
         char *base = lds + (size_t)el * p.lds_env_bytes;
         size_t g = (size_t)(env0 + el) * p.W + w;
         double axis = p.wall_axis[g];
@@ -358,6 +359,9 @@ __device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
         ((double2 *)(base + p.lds_pos))[p.N + LO + w] = c;
         ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
     }
+}
+__device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
+    load_statics_range(p, lds, env0, 0, nenv, threadIdx.x, kThreads);
 }
 
 // mean and population std of v[0..n) where entry j comes from `fresh` if j < split else from `stale`
