@@ -1048,6 +1048,33 @@ def test_formation_reset_and_rollout_vs_philox_oracle(N, L, O, thr, n):
             np.testing.assert_allclose(got[k], getattr(orc.st, k), err_msg='end ' + k, **STATE)
 
 
+def test_formation_matchings_do_not_depend_on_their_warm_start():
+    """The slot matchings start from the column potentials the previous step left in the state (FMARL_F_MATCH_DUAL).  Any
+    potentials are a valid start and the optimum is unique, so scrambling them before every step -- zeros, huge values,
+    noise -- must not change a single output bit or state bit (BASELINE config 4 shapes, 4 096 envs, 3 episodes)."""
+    cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3, episode_length=20)
+    n = 4096
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=21)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=21)
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    a.reset(); b.reset()
+    dual = b.field('internal_match_dual')
+    for t in range(60):
+        if t % 3 == 0:
+            dual.zero_()
+        elif t % 3 == 1:
+            dual.copy_(torch.randn(dual.shape, device=DEV, dtype=torch.float64, generator=g) * 0.3)
+        else:
+            dual.copy_(-torch.rand(dual.shape, device=DEV, dtype=torch.float64, generator=g) * 50.0)
+        act = torch.randint(0, 5, (n, 10), device=DEV, generator=g, dtype=torch.int32)
+        ra, rb = a.step(act), b.step(act)
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), 'step %d output %d' % (t, k)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+
+
 def test_formation_full_size_cfg4():
     """BASELINE config 4 shapes: 10 agents, E = 16, 65 536 envs; oracle parity on a strided sample."""
     cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3)
