@@ -47,7 +47,8 @@ struct Params {
     int feat_global;   // FMARL_FLAG_GLOBAL_FEATURES: node rows are [vel, pos, goal, type] without the ego part
     int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
     int lds_posf, has_posf;  // navigation_graph: f32 copy of the entity positions (adj is computed from it)
-    int lds_wallf, lds_constf;   // navigation_graph: f32 wall corner words (4 per wall) and the constants 0, 1, 2, 3
+    int lds_wallf, lds_constf;   // f32 wall corner words (4 per wall; not for the formation scenario) and, navigation_graph, the constants 0, 1, 2, 3
+    int has_wallf, lds_cnt;      // wall corner table present; byte offset of the env's policy-edge counter (fused processAdj count)
     double world_size, max_speed, collision_rew, goal_rew, thr, fair_rew, zeroshift;
     float edge_thr;          // (float)max_edge_dist: the policy-edge threshold of the fused processAdj count
     uint64_t seed;

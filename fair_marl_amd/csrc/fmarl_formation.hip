@@ -104,7 +104,6 @@ struct FormLds {
     __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
     __device__ float2 *velf() const { return (float2 *)(base + p.lds_agentf); }     // (vx, vy) in f32
     __device__ float2 *posf() const { return (float2 *)(base + p.lds_posf); }
-    __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2)
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
@@ -195,7 +194,8 @@ __device__ __forceinline__ void formation_emit_rows(const Params &p, const Fmarl
                 gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
                 fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
             } else if (e >= first_wall) {
-                const float4 wc = te.wallf()[e - first_wall];   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
+                const double *wl = te.wall() + (e - first_wall) * 4;   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
+                const float4 wc = make_float4((float)wl[1], (float)(wl[0] + kWallWidth / 2), (float)wl[2], (float)(wl[0] - kWallWidth / 2));
                 t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
             }
             const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
@@ -503,7 +503,8 @@ __global__ __launch_bounds__(kThreads) void formation_rebuild_kernel(Params p, F
         const uint32_t *q = ep_rec + (size_t)(env0 + e_l) * words + 2 * (N + LO) + 6 * w;
         const double axis = __longlong_as_double((long long)((unsigned long long)q[0] | ((unsigned long long)q[1] << 32)));
         const float *qf = (const float *)q;
-        ((float4 *)(t.base + p.lds_wallf))[w] = make_float4(qf[2], (float)(axis + kWallWidth / 2), qf[3], (float)(axis - kWallWidth / 2));
+        double *wl = t.wall() + w * 4;   // (float)e0 / (float)e1 travel: the sender's corner words are their float32 roundings too
+        wl[0] = axis; wl[1] = (double)qf[2]; wl[2] = (double)qf[3]; wl[3] = (double)qf[4];
         t.pos()[N + LO + w] = qf[4] == 0.f ? make_double2(0.0, axis) : make_double2(axis, 0.0);
         t.posf()[N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
     }

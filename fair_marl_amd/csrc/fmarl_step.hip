@@ -189,7 +189,7 @@ struct EdgeCount {   // plain values only (no reference to the kernel's Params: 
     int stride, cur, cnt;
     float thr;
     __device__ __forceinline__ EdgeCount(const Params &p, const char *lds)
-        : slots(lds + p.lds_flag + 16), stride(p.lds_env_bytes), cur(-1), cnt(0), thr(p.edge_thr) {}
+        : slots(lds + p.lds_cnt), stride(p.lds_env_bytes), cur(-1), cnt(0), thr(p.edge_thr) {}
     __device__ __forceinline__ int *slot(int el) const { return (int *)(slots + (size_t)el * stride); }
     __device__ __forceinline__ void add(int el, float d) {
         if (el != cur) { flush(); cur = el; }
@@ -354,7 +354,7 @@ __device__ void load_statics_range(const Params &p, char *lds, int env0, int el_
         double *wl = (double *)(base + p.lds_wall) + w * 4;
         wl[0] = axis; wl[1] = p.wall_e0[g]; wl[2] = p.wall_e1[g]; wl[3] = (double)orient;
         // wall "sphere" centre: (0, axis) for 'H', (axis, 0) for 'V' (navigation_graph.py:309-324)
-        ((float4 *)(base + p.lds_wallf))[w] = make_float4((float)wl[1], (float)(axis + kWallWidth / 2), (float)wl[2], (float)(axis - kWallWidth / 2));
+        if (p.has_wallf) ((float4 *)(base + p.lds_wallf))[w] = make_float4((float)wl[1], (float)(axis + kWallWidth / 2), (float)wl[2], (float)(axis - kWallWidth / 2));
         const double2 c = orient == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
         ((double2 *)(base + p.lds_pos))[p.N + LO + w] = c;
         ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
