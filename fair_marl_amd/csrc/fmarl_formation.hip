@@ -350,12 +350,35 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     }
     wave_sync();
 
+    // Entity sets of the walk below, built by the agent lanes in parallel (the potentials' LDS table is free again):
+    // sm[k] = agent entities sitting near slot k, sm[N] = all entities near some slot, sm[N + 1] = the slots they cover.
+    if (active) {
+        uint32_t *sm = (uint32_t *)t.vdual();
+        sm[i] = 0;
+        if (i < 2) sm[N + i] = 0;
+    }
+    wave_sync();
+    if (active) {
+        const int ne = t.near_new()[i];
+        if (ne >= 0) {
+            uint32_t *sm = (uint32_t *)t.vdual();
+            atomicOr(&sm[ne], 1u << i); atomicOr(&sm[N], 1u << i); atomicOr(&sm[N + 1], 1u << ne);
+        }
+    }
+    wave_sync();
+
     if (lane < nenv_w && !FMARL_SKIP(p, 128)) {
-        // Sequential walk of the occupancy mask: one lane per env, the wave's envs side by side in its first lanes
+        // Walk of the occupancy mask in the reference's call order, one lane per env (the wave's envs side by side in its
+        // first lanes): for every ego a, observation(a)'s event, then the N row events of graph_observation(a).  The row
+        // events of one ego have a closed form unless one of them can find every slot taken: near entities only add
+        // their slot, and a non-near entity e reads bit g_a of (S | slots of the near entities before e).  Only when
+        // S | (all near slots) is full -- agents holding the whole ring -- the events are walked one by one.
         const FormLds tw(p, lds, el0w + lane);
         uint32_t occ = tw.words()[0];
         uint32_t *m = tw.masks();
         const int8_t *gn = tw.g_new(), *nr = tw.near_new();
+        const uint32_t *sm = (const uint32_t *)tw.vdual();
+        const uint32_t NEAR = sm[N], PN = sm[N + 1], NN = full & ~NEAR;
         const int near0 = *tw.near_old0();
         for (int a = 0; a < N; ++a) {
             uint32_t code;
@@ -365,12 +388,21 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             } else {
                 code = branch_event(a == 0 ? near0 : nr[a], gn[a], full, occ);
             }
-            uint32_t mb = 0, mf = 0;
+            uint32_t mb, mf;
             const int ga = gn[a];
-            for (int e = 0; e < N; ++e) {
-                const uint32_t c = branch_event(nr[e], ga, full, occ);
-                mb |= ((c >> 1) & 1u) << e;
-                mf |= (c & 1u) << e;
+            if ((occ | PN) != full || NN == 0) {   // nobody can find every slot taken in this pass
+                const uint32_t smg = sm[ga];       // entities near the ego's matched slot: after the first one, bit g_a is set
+                const uint32_t later = smg ? ~((2u << __builtin_ctz(smg)) - 1u) : 0u;
+                mb = NN;
+                mf = NEAR | (NN & (((occ >> ga) & 1u) ? full : later));
+                occ |= PN;
+            } else {
+                mb = 0; mf = 0;
+                for (int e = 0; e < N; ++e) {
+                    const uint32_t c = branch_event(nr[e], ga, full, occ);
+                    mb |= ((c >> 1) & 1u) << e;
+                    mf |= (c & 1u) << e;
+                }
             }
             m[3 * a] = mb; m[3 * a + 1] = mf; m[3 * a + 2] = code;
         }

@@ -300,7 +300,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.f_g = off;        off = align16(off + 3 * p.N + 1);
         p.f_masks = off;    off = align16(off + (3 * p.N * 4 > p.N * 8 ? 3 * p.N * 4 : p.N * 8));
         p.f_theta = off;    off = align16(off + p.N * 8);
-        p.f_words = off;    off = align16(off + p.N * 8);   // column potentials of the last matching (the occupancy words sit behind the skip flag)
+        p.f_words = off;    off = align16(off + (p.N * 8 > (p.N + 2) * 4 ? p.N * 8 : (p.N + 2) * 4));   // column potentials of the last matching, then the walk's entity sets
     }
     if (fnav) {   // fmarl_fairnav.hip FairNavLds
         p.n_D = off;       off = align16(off + p.N * p.L * 8);
