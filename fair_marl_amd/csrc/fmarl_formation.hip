@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         // occupancy recomputed in reward(agent 0): any agent within thr of slot i (ff:660-661)
         bool occ = false;
         const double2 Pi = t.slot_new()[i];
-        for (int a = 0; a < N; ++a) occ |= dist2(t.pos()[a], Pi) < p.thr;
+        for (int a = 0; a < N; ++a) occ |= closer_than(t.pos()[a], Pi, p.thr);   // decided on the squares unless within an ulp of thr
         if (occ) atomicOr(&t.words()[1], 1u << i);
     }
     wave_sync();
