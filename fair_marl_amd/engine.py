@@ -35,6 +35,8 @@ class RolloutEngine:
             raise RuntimeError('fair_marl_amd needs an AMD GPU (torch.cuda.is_available() is False); '
                                'there is no CPU fallback for the rollout path')
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         # async_reset: stage the next episode (placement + fair assignment) on a side stream while the
         # current one runs; same results, the reset leaves the critical path (see include/fmarl.h)
         self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset, async_reset=async_reset)
@@ -46,6 +48,7 @@ class RolloutEngine:
         D, F = cfg.obs_dim, cfg.node_feat
         with torch.cuda.device(self.device):
             self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self._state_ptr = self.state.data_ptr()
             # emit_graph=False (the reference's non-graph MPEEnv, MPE_env.py:21-53): node_obs / adj are never
             # computed -- the kernels skip the whole emission when handed NULL pointers
             self.node_obs = torch.zeros(n, N, E, F, dtype=torch.float32, device=self.device) if emit_graph else None
@@ -187,6 +190,7 @@ class RolloutEngine:
     def use_outputs(self, out_set):
         """Select the output set the next reset / step calls write into."""
         self.outs = out_set
+        self._outs_ref = C.byref(out_set.c)   # (built once per set: the step path of a launch-bound batch counts microseconds)
         self.obs, self.reward, self.done, self.info = out_set.obs, out_set.reward, out_set.done, out_set.info
         self.node_obs, self.adj_env, self.graph_record = out_set.node_obs, out_set.adj_env, out_set.graph_record
 
@@ -281,18 +285,21 @@ class RolloutEngine:
         n, N = self.n_envs, self.cfg.N
         idx_ptr = vec_ptr = None
         if a.dim() == 2:
-            if tuple(a.shape) != (n, N):
+            if a.shape[0] != n or a.shape[1] != N:
                 raise ValueError('action index tensor must have shape (%d, %d), got %s' % (n, N, tuple(a.shape)))
-            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+            if a.dtype != torch.int32 or a.device != self.device or not a.is_contiguous():
+                a = a.to(device=self.device, dtype=torch.int32).contiguous()
             idx_ptr = a.data_ptr()
         else:
             if tuple(a.shape) != (n, N, 5):
                 raise ValueError('action tensor must have shape (%d, %d, 5), got %s' % (n, N, tuple(a.shape)))
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
             vec_ptr = a.data_ptr()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.fmarl_step(self.handle, self.state.data_ptr(), idx_ptr, vec_ptr,
-                                           C.byref(self.outs.c), int(auto_reset), self._stream()), 'fmarl_step')
+        # (the library switches to the handle's device itself; torch only supplies the stream of THAT device)
+        rc = self.lib.fmarl_step(self.handle, self._state_ptr, idx_ptr, vec_ptr, self._outs_ref, int(auto_reset),
+                                 torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _lib.check(rc, 'fmarl_step')
         self._last_actions = a  # keep alive until the stream has consumed it
         return self.obs, self.agent_id, self.node_obs, self.adj, self.reward, self.done, self.info
 
