@@ -420,7 +420,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
     if (FMARL_SKIP(p, 32)) return ended;
     fairnav_emit_rows(p, o, lds, env0, nenv);
-    emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
     return ended;
 }
 

@@ -204,6 +204,9 @@ __device__ __forceinline__ void emit_sync(uint32_t nthr) {
 }
 
 // The caller's `nthr` threads (index `thr`) emit the envs [el_begin, el_end) of the workgroup.
+// MODE 0: no policy-edge count, 1: count, 2: decided at run time (`count`; one copy of the loop -- for kernels that inline
+// this more than once and would run out of registers with two copies each, i.e. fairnav_kernel's two passes)
+template <int MODE>
 __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
                                                  int el_end, uint32_t thr, uint32_t nthr, EdgeCount &ec, bool count) {
     const uint32_t EE = p.E * p.E, total = (el_end - el_begin) * EE;
@@ -225,7 +228,7 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
                 const uint32_t r = q - elq * EE, a = p.dE.div(r), b = r - a * p.E;
                 const float2 pa = t.posf()[a], pb = t.posf()[b];   // the f32 position table (what a learner-side rebuild has)
                 v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
-                if (count) ec.add((int)el, v[j]);
+                if (MODE == 1 || (MODE == 2 && count)) ec.add((int)el, v[j]);
             }
         }
         if (ok[0] & ok[1] & ok[2] & ok[3]) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
@@ -239,6 +242,7 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
 
 // adj of the envs [el_begin, el_end) of the workgroup by `nthr` threads: the 16-byte path when E % 4 == 0 and the f32
 // position table exists, else the generic one; with FmarlOutputs.edge_nnz also every emitted env's policy-edge count.
+template <bool LEAN = false>
 __device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
                                          int el_end, uint32_t thr, uint32_t nthr) {
     if (!o.adj) return;
@@ -268,7 +272,10 @@ __device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o,
             if (count) { ec.add((int)el, d.x); ec.add((int)el, d.y); ec.add((int)el, d.z); ec.add((int)el, d.w); }
         }
     } else {
-        emit_adj_generic(p, o, lds, env0, el_begin, el_end, thr, nthr, ec, count);
+        if (!LEAN) {
+            if (count) emit_adj_generic<1>(p, o, lds, env0, el_begin, el_end, thr, nthr, ec, true);
+            else emit_adj_generic<0>(p, o, lds, env0, el_begin, el_end, thr, nthr, ec, false);
+        } else emit_adj_generic<2>(p, o, lds, env0, el_begin, el_end, thr, nthr, ec, count);
     }
     if (count) {
         ec.flush();

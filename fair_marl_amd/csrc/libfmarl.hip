@@ -287,8 +287,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
     p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 2 * p.N * 8 + 12 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
-    p.lds_flag = off;   off = align16(off + (form ? 16 : 20));   // flag + three scenario words (+ the env's policy-edge counter)
-    p.lds_cnt = form ? p.lds_stat + 2 * p.N * 8 + 8 : p.lds_flag + 16;   // formation: in the padding behind its statistics block
+    p.lds_flag = off;   off = align16(off + 16);   // flag, then the formation scenario's three occupancy words or the env's policy-edge counter
+    p.lds_cnt = form ? p.lds_stat + 2 * p.N * 8 + 8 : p.lds_flag + 4;   // formation: in the padding behind its statistics block
     p.has_posf = 1;   // f32 copy of the entity positions: adj and the node rows start from it (all three scenarios)
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     p.has_wallf = !form;   // the formation kernel converts the corners from the f64 wall table (LDS budget: five workgroups per CU)
