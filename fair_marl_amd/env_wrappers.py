@@ -67,6 +67,13 @@ class ShareVecEnv(ABC):
 
 
 class _EngineVecEnv(ShareVecEnv):
+    # adj as the reference shapes it, (n, N, E, E) float64 -- N identical copies of every env's matrix
+    # (navigation_graph.py:1033).  By default the copies are a read-only stride-0 NumPy view of ONE (n, E, E) array: equal
+    # values, shape and dtype, `adj.copy()` / indexing / np.concatenate as the runner uses them (graph_mpe_runner.py:200,
+    # :404, graph_buffer.py:229) behave the same, but N times fewer bytes cross PCIe and the host (784 MB -> 24.5 MB per
+    # step at 512 envs x 32 agents).  Set to True for N materialised, writable copies.
+    materialize_adj = False
+
     def __init__(self, env_fns, device='cuda:0', emit_graph=True):
         specs = [fn() for fn in env_fns]
         if not specs or not all(isinstance(s, EnvSpec) for s in specs):
@@ -171,15 +178,20 @@ class GraphSubprocVecEnv(_EngineVecEnv):
     def __init__(self, env_fns, spaces=None, device='cuda:0'):
         _EngineVecEnv.__init__(self, env_fns, device)
 
+    def _adj(self, adj_env):
+        n, N, E = self.engine.n_envs, self.spec.cfg.N, self.spec.cfg.E
+        view = np.broadcast_to(adj_env[:, None], (n, N, E, E))
+        return view.copy() if self.materialize_adj else view
+
     def step_wait(self):
         obs, ids, node, adj, rew, done, info = self._step_device()
-        obs, node, adj, rew, done, info = self._fetch(obs, node, adj, rew, done, info)
-        return obs, self._agent_ids(), node, adj, rew, done != 0, self._infos(info, self._infos_as_array)
+        obs, node, adj_env, rew, done, info = self._fetch(obs, node, self.engine.adj_env, rew, done, info)
+        return obs, self._agent_ids(), node, self._adj(adj_env), rew, done != 0, self._infos(info, self._infos_as_array)
 
     def reset(self):
         obs, ids, node, adj = self.engine.reset()
-        obs, node, adj = self._fetch(obs, node, adj)
-        return obs, self._agent_ids(), node, adj
+        obs, node, adj_env = self._fetch(obs, node, self.engine.adj_env)
+        return obs, self._agent_ids(), node, self._adj(adj_env)
 
 
 class GraphDummyVecEnv(GraphSubprocVecEnv):

@@ -209,7 +209,11 @@ def test_runner_loop_drops_in(name):
     D, E, F = fx['obs'].shape[-1], fx['node_obs'].shape[-2], fx['node_obs'].shape[-1]
     buf = ro.ReplayBuffer(T, n, N, D, E, F)
     obs, agent_id, node_obs, adj = envs.reset()                                  # warmup
-    assert obs.dtype == np.float64 and agent_id.dtype == np.int64 and adj.shape == (n, N, E, E)
+    assert obs.dtype == np.float64 and agent_id.dtype == np.int64 and adj.shape == (n, N, E, E) and adj.dtype == np.float64
+    # adj: N identical copies per env as a read-only stride-0 view by default (what the runner does with it -- copy(),
+    # indexing, concatenate -- is unaffected); materialize_adj gives the reference's N writable copies
+    assert not adj.flags.writeable and adj.strides[1] == 0 and adj.copy().flags.writeable
+    assert np.concatenate(adj).shape == (n * N, E, E)
     buf.warmup(obs, agent_id, node_obs, adj)
     keys = [str(k) for k in fx['info_keys']]
     for ep in range(fx['actions'].shape[0] // T):
@@ -254,6 +258,11 @@ def test_runner_loop_drops_in(name):
         assert list(infos[0][0].keys())[0] == 'individual_reward' and set(infos[0][0].keys()) == set(keys)
         buf.after_update()
     envs.close()
+    full = fm.GraphSubprocVecEnv(_env_fns(args, 2, seed, fm.GraphMPEEnv), device=DEV)
+    full.materialize_adj = True
+    a4 = full.reset()[3]
+    assert a4.flags.writeable and a4.strides[1] != 0 and np.array_equal(a4[:, 0], a4[:, 1])
+    full.close()
     # other seeds than seed + 1000 r cannot be honoured per env: say so
     fns = _env_fns(args, 3, seed, fm.GraphMPEEnv)
 
