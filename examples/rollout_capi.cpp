@@ -63,6 +63,7 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc((void **)&outs.reward, n_rew * 4));
     HIP_OK(hipMalloc((void **)&outs.done, n_rew));
     HIP_OK(hipMalloc((void **)&outs.info, (size_t)FMARL_INFO_WIDTH * n_rew * 4));
+    HIP_OK(hipMalloc((void **)&outs.edge_nnz, (size_t)n * 4));   // processAdj fused with the step (gnn.py:307-326)
 
     // action tape: the high bits of a 64-bit LCG, value % 5 per (step, env, agent)
     std::vector<int32_t> tape((size_t)steps * n * N);
@@ -76,7 +77,27 @@ int main(int argc, char **argv) {
     FMARL_OKAY(fmarl_reset(h, state, nullptr, &outs, st));      // envs.reset()
     for (int t = 0; t < steps; ++t)                             // envs.step(actions) incl. the workers' auto-reset
         FMARL_OKAY(fmarl_step(h, state, d_tape + (size_t)t * n * N, nullptr, &outs, 1, st));
+    // the policy's edge list of the last step: counts from the emission, prefix sum and COO fill on the device, sized by
+    // an upper bound so that nothing has to come back to the host in between
+    int64_t *offsets = nullptr, *edge_index = nullptr;
+    float *edge_attr = nullptr;
+    const int64_t cap = (int64_t)n * E * (E - 1);
+    HIP_OK(hipMalloc((void **)&offsets, ((size_t)n + 1) * 8));
+    HIP_OK(hipMalloc((void **)&edge_index, (size_t)2 * cap * 8));
+    HIP_OK(hipMalloc((void **)&edge_attr, (size_t)cap * 4));
+    FMARL_OKAY(fmarl_edge_offsets(outs.edge_nnz, n, 1, offsets, st));
+    FMARL_OKAY(fmarl_edge_fill_state(h, state, offsets, edge_index, edge_attr, cap, 1, st));
     HIP_OK(hipStreamSynchronize(st));
+    int64_t total = 0;
+    HIP_OK(hipMemcpy(&total, offsets + n, 8, hipMemcpyDeviceToHost));
+    std::vector<int64_t> rows((size_t)total), cols((size_t)total);
+    std::vector<float> attr((size_t)total);
+    HIP_OK(hipMemcpy(rows.data(), edge_index, (size_t)total * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(cols.data(), edge_index + cap, (size_t)total * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(attr.data(), edge_attr, (size_t)total * 4, hipMemcpyDeviceToHost));
+    printf("edges %lld edge_rows %016llx edge_cols %016llx edge_attr %016llx\n", (long long)total,
+           (unsigned long long)fnv1a(rows.data(), (size_t)total * 8), (unsigned long long)fnv1a(cols.data(), (size_t)total * 8),
+           (unsigned long long)fnv1a(attr.data(), (size_t)total * 4));
 
     std::vector<float> obs(n_obs), node(n_node), adj(n_adj), rew(n_rew);
     std::vector<uint8_t> done(n_rew);
@@ -92,7 +113,7 @@ int main(int argc, char **argv) {
 
     FMARL_OKAY(fmarl_destroy(h));
     for (void *p : {(void *)outs.obs, (void *)outs.node_obs, (void *)outs.adj, (void *)outs.reward, (void *)outs.done,
-                    (void *)outs.info, (void *)d_tape, state})
+                    (void *)outs.info, (void *)outs.edge_nnz, (void *)offsets, (void *)edge_index, (void *)edge_attr, (void *)d_tape, state})
         HIP_OK(hipFree(p));
     HIP_OK(hipStreamDestroy(st));
     return 0;

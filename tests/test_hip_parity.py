@@ -861,11 +861,13 @@ def test_c_abi_client_without_python_matches_the_engine():
         x = (x * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         tape.append((x >> 33) % 5)
     tape = torch.tensor(tape, dtype=torch.int32, device=DEV).view(steps, n, N)
-    eng = fm.RolloutEngine(fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=3), n, device=DEV, seed=seed)
+    eng = fm.RolloutEngine(fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=3), n, device=DEV, seed=seed, count_edges=True)
     eng.reset()
     for t in range(steps):
         eng.step(tape[t])
-    want = dict(obs=fnv1a(eng.obs), node_obs=fnv1a(eng.node_obs), adj=fnv1a(eng.adj_env), reward=fnv1a(eng.reward), done=fnv1a(eng.done))
+    ei, ea, off = eng.process_adj()     # the client builds the same edge list with fmarl_edge_offsets / fmarl_edge_fill_state
+    want = dict(obs=fnv1a(eng.obs), node_obs=fnv1a(eng.node_obs), adj=fnv1a(eng.adj_env), reward=fnv1a(eng.reward), done=fnv1a(eng.done),
+                edges=str(int(off[-1])), edge_rows=fnv1a(ei[0]), edge_cols=fnv1a(ei[1]), edge_attr=fnv1a(ea))
     assert got == want
 
 
