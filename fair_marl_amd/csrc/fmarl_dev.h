@@ -57,6 +57,7 @@ struct Params {
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
     int scan_stats;          // N is a power of two <= 64: the agent-loop statistics run as wave scans (seg_mixed_stats)
     int lds_stage, stage_wave_bytes;   // generic shapes: per-wave LDS window the rows go through (offset from the LDS base, bytes per wave)
+    int stat_stride;   // statistics block of env el: LDS base + lds_stat + el * stat_stride (lds_env_bytes, or 5 N doubles when the blocks share the emission windows' region)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
     double2 *slot_pos;

@@ -167,7 +167,7 @@ __device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOu
                     const uint32_t e_l = p.dC4.div(q), r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;   // dC4 = N * E
                     FairNavLds(p, lds, e_l).node_row(a, e, row);
                 }
-                flush_rows<13>(p, lds, row, 13, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
+                flush_rows<13, true>(p, lds, row, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
             }
         } else {
             for (uint32_t q = tid; q < total; q += kThreads) {

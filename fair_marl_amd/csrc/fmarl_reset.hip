@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOut
     const size_t g = (size_t)env * p.N + i;
     char *base = lds + (size_t)el * p.lds_env_bytes;
     double2 *s_pos = (double2 *)(base + p.lds_pos);
-    double *s_stat = (double *)(base + p.lds_stat);
+    double *s_stat = (double *)(lds + p.lds_stat + (size_t)el * p.stat_stride);
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double Dg = 0, pdist = 0;
     bool flagged = false;

@@ -35,29 +35,25 @@ struct EnvLds {
     __device__ const double *wall() const { return (const double *)(base + p.lds_wall); }
     __device__ bool skip() const { return *(const int *)(base + p.lds_flag) != 0; }
 
-    // whole row of entity e in the block of ego i: feat(e) - ego(i), both sides rounded to f32 first; returns F
-    __device__ int node_row(uint32_t i, uint32_t e, float (&o)[11]) const {
+    // whole row of entity e in the block of ego i: feat(e) - ego(i), both sides rounded to f32 first (the f32 tables the
+    // 16-byte path reads: posf, agentf, wallf).  GLOBAL: navigation_graph.py:1058-1077 (7 columns), else :1079-1124 (11)
+    template <bool GLOBAL>
+    __device__ __forceinline__ void node_row(uint32_t i, uint32_t e, float (&o)[GLOBAL ? 7 : 11]) const {
         const uint32_t N = p.N, first_wall = p.N + p.L + p.O;
-        const double2 xe = pos()[e];
-        const float pex = (float)xe.x, pey = (float)xe.y;
-        float vex = 0.f, vey = 0.f, gex = pex, gey = pey;
+        const float2 pe = posf()[e];
+        float vex = 0.f, vey = 0.f, gex = pe.x, gey = pe.y;
         if (e < N) { const float4 ae = agentf()[e]; vex = ae.x; vey = ae.y; gex = ae.z; gey = ae.w; }
         const float type = e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
-        if (p.feat_global) {   // navigation_graph.py:1058-1077
-            o[0] = vex; o[1] = vey; o[2] = pex; o[3] = pey; o[4] = gex; o[5] = gey; o[6] = type;
-            return 7;
+        if constexpr (GLOBAL) {
+            o[0] = vex; o[1] = vey; o[2] = pe.x; o[3] = pe.y; o[4] = gex; o[5] = gey; o[6] = type;
+        } else {
+            const float4 ai = agentf()[i];
+            const float2 xi = posf()[i];
+            float4 c = make_float4(pe.x, pe.y, pe.x, pe.y);
+            if (e >= first_wall) c = ((const float4 *)(base + p.lds_wallf))[e - first_wall];   // (e0, axis + w/2), (e1, axis - w/2): :1115-1116
+            o[0] = vex - ai.x; o[1] = vey - ai.y; o[2] = pe.x - xi.x; o[3] = pe.y - xi.y; o[4] = gex - xi.x; o[5] = gey - xi.y;
+            o[6] = c.x - xi.x; o[7] = c.y - xi.y; o[8] = c.z - xi.x; o[9] = c.w - xi.y; o[10] = type - 0.f;
         }
-        const float4 ai = agentf()[i];
-        const double2 xi = pos()[i];
-        const float vix = ai.x, viy = ai.y, xix = (float)xi.x, xiy = (float)xi.y;
-        float c0 = pex, c1 = pey, c2 = pex, c3 = pey;
-        if (e >= first_wall) {   // (e0, axis + w/2), (e1, axis - w/2): navigation_graph.py:1115-1116
-            const double *wl = wall() + (e - first_wall) * 4;
-            c0 = (float)wl[1]; c1 = (float)(wl[0] + kWallWidth / 2); c2 = (float)wl[2]; c3 = (float)(wl[0] - kWallWidth / 2);
-        }
-        o[0] = vex - vix; o[1] = vey - viy; o[2] = pex - xix; o[3] = pey - xiy; o[4] = gex - xix; o[5] = gey - xiy;
-        o[6] = c0 - xix; o[7] = c1 - xiy; o[8] = c2 - xix; o[9] = c3 - xiy; o[10] = type - 0.f;
-        return 11;
     }
 };
 
@@ -152,21 +148,40 @@ __device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const cha
 // whatever F and the alignment of gdst are (row-per-lane stores at a 4 F byte stride reach about half the
 // store bandwidth).  The window is private to the wave: LDS executes a wave's instructions in order, so a
 // wavefront-scope fence (no workgroup barrier) is all that separates the writes from the reads.
-template <int FMAX>
-__device__ __forceinline__ void flush_rows(const Params &p, char *lds, const float (&row)[FMAX], int F, int nrows, float *gdst) {
+// LOOP: copy the window chunk by chunk (kernels short of registers) instead of all LDS reads first, then the stores
+template <int F, bool LOOP = false>
+__device__ __forceinline__ void flush_rows(const Params &p, char *lds, const float (&row)[F], int nrows, float *gdst) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *buf = (float *)(lds + p.lds_stage + wave * p.stage_wave_bytes);
-    const uint32_t shift = (uint32_t)(((uintptr_t)gdst >> 2) & 3);   // dwords past the previous 16-byte boundary
+    // dwords past the previous 64-byte boundary: the copy below then stores whole 64-byte blocks per four lanes (the
+    // texture path forms its write requests per lane quad; quads that straddle a block leave as two partial requests each)
+    const uint32_t shift = (uint32_t)(((uintptr_t)gdst >> 2) & 15);
     if ((int)lane < nrows) {
 #pragma unroll
-        for (int f = 0; f < FMAX; ++f)
-            if (f < F) buf[shift + lane * F + f] = row[f];   // stride F dwords: conflict-free for odd F
+        for (int f = 0; f < F; ++f) buf[shift + lane * F + f] = row[f];   // stride F dwords: conflict-free for odd F
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t end = shift + nrows * F, first4 = (shift + 3) >> 2, last4 = end >> 2;
-    float *gal = gdst - shift;   // 16-byte aligned frame: dword k of the frame is buf[k]
-    for (uint32_t k = first4 + lane; k < last4; k += 64) ((float4 *)gal)[k] = ((const float4 *)buf)[k];
+    float *gal = gdst - shift;   // 64-byte aligned frame: dword k of the frame is buf[k]
+    if constexpr (LOOP) {
+        for (uint32_t k = first4 + lane; k < last4; k += 64) ((float4 *)gal)[k] = ((const float4 *)buf)[k];
+    } else {
+        constexpr int K = (64 * F + 15) / 4 / 64 + 1;   // 16-byte chunks per lane (at most 4 for F <= 13): the LDS reads first, then the stores
+        static_assert(K <= 4, "flush_rows: row width");
+        const float4 *b4 = (const float4 *)buf + first4 + lane;
+        float4 *g4 = (float4 *)gal + first4 + lane;
+        const uint32_t nk = last4 > first4 + lane ? last4 - first4 - lane : 0;   // chunks j with 64 j < nk are this lane's
+        float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+        if (nk > 0) c0 = b4[0];
+        if (K > 1 && nk > 64) c1 = b4[64];
+        if (K > 2 && nk > 128) c2 = b4[128];
+        if (K > 3 && nk > 192) c3 = b4[192];
+        if (nk > 0) g4[0] = c0;
+        if (K > 1 && nk > 64) g4[64] = c1;
+        if (K > 2 && nk > 128) g4[128] = c2;
+        if (K > 3 && nk > 192) g4[192] = c3;
+    }
     if (lane < 3) {            // at most 3 dwords before the first full chunk ...
         const uint32_t idx = shift + lane;
         if (idx < min(first4 * 4, end)) gal[idx] = buf[idx];
@@ -211,7 +226,7 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
                                                  int el_end, uint32_t thr, uint32_t nthr, EdgeCount &ec, bool count) {
     const uint32_t EE = p.E * p.E, total = (el_end - el_begin) * EE;
     float *dst = o.adj + ((size_t)env0 + el_begin) * EE;
-    const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 3), end = shift + total;
+    const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 15), end = shift + total;   // 64-byte aligned frame (lane quads = blocks)
     float *gal = dst - shift;
     for (uint32_t k = thr; k < ((end + 3) >> 2); k += nthr) {
         float v[4];
@@ -286,6 +301,39 @@ __device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o,
 }
 
 
+// node_obs rows of any shape (E F not a multiple of 4, or more than four 16-byte groups per ego block).
+template <bool GLOBAL>
+__device__ __forceinline__ void emit_node_rows_generic(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+    constexpr int F = GLOBAL ? 7 : 11;
+    const int tid = threadIdx.x;
+    const uint32_t NE = p.N * p.E, total = nenv * NE;
+    float *dst = o.node_obs + (size_t)env0 * NE * F;
+    const bool some_skip = __syncthreads_or(tid < nenv && EnvLds(p, lds, tid).skip());
+    if (!some_skip) {   // every env of the workgroup emits: rows leave through the LDS windows, 16 bytes per lane
+        for (uint32_t base = 0; base < total; base += kThreads) {
+            const uint32_t q = base + tid, w0 = base + (tid & ~63u);
+            float row[F];
+            if (q < total) {
+                const uint32_t el = p.dNE.div(q), r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
+                EnvLds(p, lds, el).node_row<GLOBAL>(i, e, row);
+            }
+            flush_rows<F>(p, lds, row, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * F);
+        }
+    } else {            // some envs keep their previous rows (reset in flight): per-lane stores of the rest
+        for (uint32_t q = tid; q < total; q += kThreads) {
+            const uint32_t el = p.dNE.div(q);
+            const EnvLds t(p, lds, el);
+            if (t.skip()) continue;
+            const uint32_t r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
+            float row[F];
+            t.node_row<GLOBAL>(i, e, row);
+            float *d = dst + (size_t)q * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) d[f] = row[f];
+        }
+    }
+}
+
 // Emission of the graph outputs of the workgroup's envs.
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x;
@@ -296,35 +344,11 @@ __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, in
         else if (groups <= 2) emit_node_rows<2>(p, o, lds, env0, nenv);
         else emit_node_rows<4>(p, o, lds, env0, nenv);
     } else if (o.node_obs) {
-        // any shape: one lane per (ego, entity) row -- the features of a row share their loads
-        const uint32_t NE = p.N * p.E, total = nenv * NE;
-        float *dst = o.node_obs + (size_t)env0 * NEF;
-        const bool some_skip = __syncthreads_or(tid < nenv && EnvLds(p, lds, tid).skip());
-        if (!some_skip) {   // every env of the workgroup emits: rows leave through the LDS windows, 16 bytes per lane
-            for (uint32_t base = 0; base < total; base += kThreads) {
-                const uint32_t q = base + tid, w0 = base + (tid & ~63u);
-                float row[11];
-                int F = p.F;
-                if (q < total) {
-                    const uint32_t el = p.dNE.div(q), r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
-                    F = EnvLds(p, lds, el).node_row(i, e, row);
-                }
-                flush_rows<11>(p, lds, row, F, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * F);
-            }
-        } else {            // some envs keep their previous rows (reset in flight): per-lane stores of the rest
-            for (uint32_t q = tid; q < total; q += kThreads) {
-                const uint32_t el = p.dNE.div(q);
-                const EnvLds t(p, lds, el);
-                if (t.skip()) continue;
-                const uint32_t r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
-                float row[11];
-                const int F = t.node_row(i, e, row);
-                float *d = dst + (size_t)q * F;
-#pragma unroll
-                for (int f = 0; f < 11; ++f)
-                    if (f < F) d[f] = row[f];
-            }
-        }
+        // any shape: one lane per (ego, entity) row -- the features of a row share their loads.  The row width is a
+        // compile-time constant of the two instances: a run-time width keeps part of the row in scratch memory, and a
+        // scratch load's s_waitcnt vmcnt(0) also waits for every global store of the previous window
+        if (p.feat_global) emit_node_rows_generic<true>(p, o, lds, env0, nenv);
+        else emit_node_rows_generic<false>(p, o, lds, env0, nenv);
     }
     emit_adj(p, o, lds, env0, 0, nenv, tid, kThreads);
 }
@@ -517,7 +541,7 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     const size_t g = (size_t)env * p.N + i;
     char *base = lds + (size_t)el * p.lds_env_bytes;
     double2 *s_pos = (double2 *)(base + p.lds_pos);
-    double *s_stat = (double *)(base + p.lds_stat);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
+    double *s_stat = (double *)(lds + p.lds_stat + (size_t)el * p.stat_stride);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0;

@@ -285,7 +285,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_agentf = off; off = align16(off + p.N * (form ? 8 : 16));   // formation: (vx, vy) only
     p.lds_ego = off;    off = align16(off + ((form || fnav) ? 0 : p.N * kEgoWidth * 4));
     p.scan_stats = !form && !fnav && p.N <= 64 && (p.N & (p.N - 1)) == 0;
-    p.lds_stat = off;   off = align16(off + (p.scan_stats ? 0 : (form ? 2 * p.N * 8 + 12 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
+    // generic row widths (everything but navigation_graph with E * F % 4 == 0 and the formation scenario's 48-byte
+    // rows) leave through one LDS window per wave: fmarl_step.hip flush_rows
+    const bool staged = fnav || (!form && (p.E * p.F) % 4 != 0) || (!form && !fnav && p.E * p.F / 4 > 64 * 4);
+    // navigation_graph: the statistics blocks are dead once the emission starts (a workgroup barrier apart), so they share
+    // the region of the emission windows instead of sitting in every env's table (one more workgroup per CU at N = 10)
+    const bool stat_shared = staged && !form && !fnav && !p.scan_stats;
+    p.lds_stat = off;   off = align16(off + ((p.scan_stats || stat_shared) ? 0 : (form ? 2 * p.N * 8 + 12 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 16);   // flag, then the formation scenario's three occupancy words or the env's policy-edge counter
     p.lds_cnt = form ? p.lds_stat + 2 * p.N * 8 + 8 : p.lds_flag + 4;   // formation: in the padding behind its statistics block
@@ -311,12 +317,11 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.n_words = off;   off = align16(off + 16);
     }
     p.lds_env_bytes = off;
-    // generic row widths (everything but navigation_graph with E * F % 4 == 0 and the formation scenario's 48-byte
-    // rows) leave through one LDS window per wave: fmarl_step.hip flush_rows
-    const bool staged = fnav || (!form && (p.E * p.F) % 4 != 0) || (!form && !fnav && p.E * p.F / 4 > 64 * 4);
-    p.stage_wave_bytes = staged ? align16(kStageRows * p.F * 4 + 16) : 0;
+    p.stage_wave_bytes = staged ? align16(kStageRows * p.F * 4 + 64) : 0;   // + the window's offset inside its 64-byte aligned frame
     int epb = kThreads / p.N;
-    const int budget = 48 * 1024 - (kThreads / 64) * p.stage_wave_bytes;
+    int shared_bytes = (kThreads / 64) * p.stage_wave_bytes;   // the windows' region (also holds the shared statistics blocks)
+    if (stat_shared && epb * 5 * p.N * 8 > shared_bytes) shared_bytes = epb * 5 * p.N * 8;
+    const int budget = 48 * 1024 - shared_bytes;
     if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
     if (epb < 1) epb = 1;
     if (form) {   // every env inside one wave (fmarl_formation.hip): 64 / N envs per wave, four waves
@@ -332,7 +337,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     p.lds_stage = align16(epb * p.lds_env_bytes);
-    h->lds_bytes = (size_t)p.lds_stage + (kThreads / 64) * p.stage_wave_bytes;
+    size_t stage_bytes = (size_t)(kThreads / 64) * p.stage_wave_bytes;
+    p.stat_stride = p.lds_env_bytes;
+    if (stat_shared) {
+        p.lds_stat = p.lds_stage; p.stat_stride = 5 * p.N * 8;
+        if ((size_t)epb * p.stat_stride > stage_bytes) stage_bytes = (size_t)epb * p.stat_stride;
+    }
+    h->lds_bytes = (size_t)p.lds_stage + stage_bytes;
 #ifdef FMARL_MEASURE
     if (const char *pad = getenv("FMARL_LDS_PAD")) h->lds_bytes += atoi(pad);   // lower occupancy
 #endif
