@@ -224,33 +224,48 @@ __device__ __forceinline__ void emit_sync(uint32_t nthr) {
 template <int MODE>
 __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
                                                  int el_end, uint32_t thr, uint32_t nthr, EdgeCount &ec, bool count) {
-    const uint32_t EE = p.E * p.E, total = (el_end - el_begin) * EE;
+    const uint32_t E = p.E, EE = E * E, total = (el_end - el_begin) * EE;
     float *dst = o.adj + ((size_t)env0 + el_begin) * EE;
     const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 15), end = shift + total;   // 64-byte aligned frame (lane quads = blocks)
     float *gal = dst - shift;
+    const char *tb0 = lds + (size_t)el_begin * p.lds_env_bytes;
     for (uint32_t k = thr; k < ((end + 3) >> 2); k += nthr) {
+        // (env, a, b) of the chunk's first entry inside the region by two divisions, of the others by stepping; the loads of
+        // the four entries carry no branches, so they are all in flight together
+        const uint32_t first = 4 * k > shift ? 4 * k - shift : 0;
+        uint32_t elq = p.dEE.div(first), r = first - elq * EE, a = p.dE.div(r), b = r - a * E;
         float v[4];
-        bool ok[4];
+        int el[4];
+        uint32_t okm = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t idx = 4 * k + j;
-            ok[j] = idx >= shift && idx < end;
-            v[j] = 0.f;
-            if (ok[j]) {
-                const uint32_t q = idx - shift, elq = p.dEE.div(q), el = el_begin + elq;
-                const EnvLds t(p, lds, el);
-                if (t.skip()) { ok[j] = false; continue; }
-                const uint32_t r = q - elq * EE, a = p.dE.div(r), b = r - a * p.E;
-                const float2 pa = t.posf()[a], pb = t.posf()[b];   // the f32 position table (what a learner-side rebuild has)
-                v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
-                if (MODE == 1 || (MODE == 2 && count)) ec.add((int)el, v[j]);
+            const bool in = idx >= shift && idx < end;
+            const char *tb = tb0 + (size_t)(in ? elq : 0u) * p.lds_env_bytes;
+            const float2 pa = ((const float2 *)(tb + p.lds_posf))[in ? a : 0u], pb = ((const float2 *)(tb + p.lds_posf))[in ? b : 0u];
+            const bool emit = in && *(const int *)(tb + p.lds_flag) == 0;   // the f32 position table (what a learner-side rebuild has)
+            v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
+            el[j] = el_begin + (int)elq;
+            okm |= (emit ? 1u : 0u) << j;
+            if (idx >= shift) {   // step to the next entry
+                const bool wb = ++b == E;
+                b = wb ? 0u : b;
+                a += wb ? 1u : 0u;
+                const bool wa = a == E;
+                a = wa ? 0u : a;
+                elq += wa ? 1u : 0u;
             }
         }
-        if (ok[0] & ok[1] & ok[2] & ok[3]) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
+        if (MODE == 1 || (MODE == 2 && count)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((okm >> j) & 1u) ec.add(el[j], v[j]);
+        }
+        if (okm == 15u) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
         else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (ok[j]) gal[4 * k + j] = v[j];
+                if ((okm >> j) & 1u) gal[4 * k + j] = v[j];
         }
     }
 }
