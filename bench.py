@@ -142,6 +142,9 @@ def main():
                     'the fastest pair of a few (RolloutEngine tune_placement)')
     ap.add_argument('--graph', action='store_true', help='N=1: capture one episode of steps in a hipGraph and replay it '
                     '(launch-bound small batches, e.g. --config cfg2; implies --sync-reset; --steps is rounded to whole episodes)')
+    ap.add_argument('--pipeline', type=int, default=1, help='step the env batch as this many sub-batches on their own streams '
+                    '(fair_marl_amd.PipelinedRollout: the tail of one sub-batch\'s step kernel overlaps the head of the next one\'s); '
+                    'no trajectory gather in this mode')
     ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
                     'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -201,8 +204,17 @@ def main():
         ep_len = cfg.episode_length
         K, W = max(ep_len, K // ep_len * ep_len), (W + ep_len - 1) // ep_len * ep_len   # whole episodes
     gather = (world > 1 or args.record_path) and not args.no_gather
-    eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
-                           tune_placement=0 if args.no_tune_placement else None, emit_graph_record=gather)
+    pipe = None
+    if args.pipeline > 1:
+        if args.graph or args.rccl_selftest:
+            raise SystemExit('bench.py: --pipeline does not combine with --graph / --rccl-selftest')
+        gather = False
+        pipe = fm.PipelinedRollout(cfg, n_envs, k=args.pipeline, device=device, seed=1, env_offset=rank * n_envs,
+                                   async_reset=not args.sync_reset, tune_placement=0)
+        eng = pipe.engines[0]
+    else:
+        eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
+                               tune_placement=0 if args.no_tune_placement else None, emit_graph_record=gather)
     depth = 2
     # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for
     # fair_graph_formation, a 36-byte-per-agent record of the step's scenario state (RolloutEngine.step_record_words)
@@ -224,6 +236,10 @@ def main():
     inject_error = bool(os.environ.get('FMARL_BENCH_INJECT_GATHER_ERROR'))   # test hook: tests/test_hip_parity.py
 
     def run(first, count):   # reads `gather` / `sets` at call time
+        if pipe is not None:
+            for t in range(first, first + count):
+                pipe.step(tape[t % tape_len], auto_reset=True)
+            return
         for t in range(first, first + count):
             if gather:
                 tg.record(t)
@@ -239,7 +255,10 @@ def main():
         if gather:
             tg.finish()
 
-    eng.reset()
+    if pipe is not None:
+        pipe.reset()
+    else:
+        eng.reset()
     if args.graph:
         # the per-kernel hipEvents cannot live inside a captured graph: the dominant kernel is timed in an eager pass
         # over whole episodes first, then the same steps run as graph replays inside the timed region
@@ -263,7 +282,8 @@ def main():
         print('bench.py: rank %d: rollout / trajectory gather failed: %s' % (rank, exc), file=sys.stderr, flush=True)
         sys.exit(1)
     if not args.graph:
-        eng.profile_enable(K)
+        for e in (pipe.engines if pipe is not None else [eng]):
+            e.profile_enable(K)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -290,7 +310,7 @@ def main():
             if len(got) != world or any(tuple(o.shape) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _ in got):
                 print('bench.py: gathered record has the wrong shape', file=sys.stderr, flush=True)
                 sys.exit(1)
-    kernel_ms = kernel_ms_eager if args.graph else eng.profile_read()
+    kernel_ms = kernel_ms_eager if args.graph else [v for e in (pipe.engines if pipe is not None else [eng]) for v in e.profile_read()]
 
     if rank == 0:
         agents = n_envs * cfg.N
@@ -298,12 +318,13 @@ def main():
         # (the reset path does), so their algorithmic bytes are the state + reward part only.
         ep = cfg.episode_length
         resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
-        bytes_per_launch = agents * (algorithmic_bytes(cfg) * (K - resets) + algorithmic_bytes(cfg, emit=False) * resets) / K
+        bytes_per_step = agents * (algorithmic_bytes(cfg) * (K - resets) + algorithmic_bytes(cfg, emit=False) * resets) / K
+        bytes_per_launch = bytes_per_step / max(1, args.pipeline)   # a launch steps one sub-batch
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and pipe is None:   # (the committed counters are per launch over ALL envs)
             with open(tpath) as f:
                 traffic = json.load(f).get(args.config, {}).get('hbm_bytes_per_launch')
         out = {
@@ -316,7 +337,9 @@ def main():
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
                        'launch': ('one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed '
-                                  'region)' % cfg.episode_length if args.graph else 'one fmarl_step call per step'),
+                                  'region)' % cfg.episode_length if args.graph else
+                                  ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
+                                   % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step')),
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed at episode end'),
                        'output_placement': ('fastest (node_obs, adj) allocation pair of %d x %d, emission-only launch ms %.3f '
@@ -338,6 +361,13 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
         }
+        if pipe is not None:
+            # launches of different sub-batches overlap: a launch's own duration (above) understates what the chip delivers;
+            # the whole-job figure is the algorithmic bytes of one step of ALL envs over the timed region's time per step
+            job = bytes_per_step / (elapsed / K) / 1e9
+            out['roofline']['overlap'] = {'sub_batches': args.pipeline, 'job_achieved': job, 'job_frac': job / HBM_PEAK_GBS,
+                                          'basis': 'algorithmic bytes per step of all envs / timed region per step; '
+                                                   'kernel_avg_ms is the duration of ONE sub-batch launch while others run'}
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if args.config in REFERENCE_CPU:

@@ -11,6 +11,7 @@ from .engine import RolloutEngine  # noqa: F401
 from .env_wrappers import (DummyVecEnv, GraphDummyVecEnv, GraphSubprocVecEnv,  # noqa: F401
                            ShareVecEnv, SubprocVecEnv)
 from .MPE_env import GraphMPEEnv, MPEEnv  # noqa: F401
+from .pipeline import PipelinedRollout  # noqa: F401
 from .rollout_buffer import DeviceRolloutBuffer  # noqa: F401
 from .sharding import StepRecord, TrajectoryGather, shard_range  # noqa: F401
 from .spaces import Box, Discrete  # noqa: F401

@@ -405,6 +405,37 @@ def test_shards_reproduce_the_unsharded_rollout(kw):
         same('step %d' % t)
 
 
+@pytest.mark.parametrize('kw', SHARD_CASES, ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
+@pytest.mark.parametrize('k', [2, 3])
+def test_pipelined_sub_batches_reproduce_the_single_engine(kw, k):
+    """PipelinedRollout: the env batch as k sub-batches on k streams (the tail of one step kernel overlaps the head of
+    another sub-batch's next one).  No join between the steps -- the sub-batches run ahead of each other -- and the
+    final state and outputs are the very bytes of one engine over all envs, async staged resets included."""
+    cfg = fm.EnvConfig(**kw)
+    n, N = 96, cfg.N
+    whole = fm.RolloutEngine(cfg, n, device=DEV, seed=23)
+    pipe = fm.PipelinedRollout(cfg, n, k=k, device=DEV, seed=23)
+    assert [e.n_envs for e in pipe.engines] == [n // k] * k
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    tape = torch.randint(0, 5, (24, n, N), device=DEV, generator=g, dtype=torch.int32)
+    whole.reset(); pipe.reset()
+    for t in range(24):
+        whole.step(tape[t])
+        pipe.step(tape[t])
+        if t in (7, 23):   # (a learner would join the sub-batch it is about to read)
+            pipe.join()
+            torch.cuda.current_stream().synchronize()
+            for name in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+                assert torch.equal(getattr(whole, name), torch.cat(pipe.outputs(name))), 'step %d %s' % (t, name)
+    pipe.synchronize()
+    sw, sp = whole.get_state(), [e.get_state() for e in pipe.engines]
+    for key in sw:
+        assert np.array_equal(sw[key], np.concatenate([s_[key] for s_ in sp])), 'state ' + key
+    assert torch.equal(pipe.gather('obs'), whole.obs)
+    with pytest.raises(ValueError):
+        fm.PipelinedRollout(cfg, 97, k=2, device=DEV)
+
+
 def test_index_math_beyond_2_to_the_32_elements():
     """300 000 envs of the cfg 3 shape on one GPU: node_obs has 7.6e9 elements (> 2^32).  The first and the last
     envs must equal small engines placed at the same global env indices."""
