@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (active) {
         uint32_t *sm = (uint32_t *)t.vdual();
         sm[i] = 0;
-        if (i < 2) sm[N + i] = 0;
+        if (i == 0) { sm[N] = 0; sm[N + 1] = 0; }   // (N = 1 has no second lane)
     }
     wave_sync();
     if (active) {

@@ -248,4 +248,10 @@ __global__ __launch_bounds__(256) void info_mean_kernel(const float *info, doubl
     if (threadIdx.x == 0) out[blockIdx.x] = part[0] / n_envs;
 }
 
+// test hook (fmarl_poison_lds): every workgroup writes 0xFF bytes over all the LDS it was given
+__global__ __launch_bounds__(256) void poison_lds_kernel(int words) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    for (int k = threadIdx.x; k < words; k += 256) ((volatile uint32_t *)lds)[k] = 0xFFFFFFFFu;
+}
+
 }  // namespace fmarl

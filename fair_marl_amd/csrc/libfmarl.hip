@@ -125,6 +125,7 @@ struct Handle {
     int device;         // HIP device the handle was created on (side stream, events, kernel attributes live there)
     bool async;         // FMARL_FLAG_ASYNC_RESET: next episode staged on `side`
     bool stage_dirty;   // staged data may be stale (caller wrote the state): next reset goes the synchronous way
+    bool stage_pending; // a reset has consumed the staged episode; the next one is staged by the next fmarl_step call
     hipStream_t side;
     hipEvent_t ev_commit, ev_staged;
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
@@ -203,6 +204,11 @@ int launch_stage(Handle *h, void *state, hipStream_t st) {
 int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const FmarlOutputs *outs, hipStream_t st) {
     Params p = bind(h, state);
     const bool form = p.scenario == FMARL_SCENARIO_FORMATION;
+    if (h->stage_pending) {   // two resets without a step in between: stage now, the commit below then waits for it
+        h->stage_pending = false;
+        int rc = launch_stage(h, state, st);
+        if (rc) return rc;
+    }
     const bool staged = h->async && !h->stage_dirty && mode != kResetInit;
     if (h->async) HIP_OK(hipStreamWaitEvent(st, h->ev_staged, 0));   // staging in flight must finish first
     if (staged) {   // commit the episode staged on the side stream
@@ -224,7 +230,10 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
         return fail(FMARL_EINVAL, "fmarl_reset: this scenario needs output buffers (its reset observation updates scenario state)");
     }
     HIP_OK(hipGetLastError());
-    if (h->async) return launch_stage(h, state, st);
+    // The next episode is staged by the NEXT fmarl_step call, not here: work enqueued now would sit behind the caller's
+    // "this step is done" synchronisation although it belongs to an episode that has not begun (a timed region that ends
+    // on an episode boundary would pay milliseconds of placement + assignment for steps it never ran).
+    if (h->async) h->stage_pending = true;
     return FMARL_OK;
 }
 
@@ -389,6 +398,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         h->place_lds = 0;
     h->async = (cfg->flags & FMARL_FLAG_ASYNC_RESET) && !form && !fnav;
     h->stage_dirty = true;   // nothing staged yet
+    h->stage_pending = false;
     h->side = nullptr; h->ev_commit = h->ev_staged = nullptr;
     if (h->async) {
         int prio_lo = 0, prio_hi = 0;   // lowest priority: staging only fills what the step kernels leave idle
@@ -497,6 +507,11 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
             h->lockstep = false;
         }
     }
+    if (h->stage_pending) {   // first step after a reset: stage the episode after this one on the side stream
+        h->stage_pending = false;
+        int rc = launch_stage(h, state, st);
+        if (rc) return rc;
+    }
     const bool prof = h->ev && h->ev_n < h->ev_cap;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     if (p.scenario == FMARL_SCENARIO_FAIRNAV)
@@ -545,6 +560,16 @@ int fmarl_set_state(void *handle, void *state, int field, const void *src, void 
     int rc = copy_field((Handle *)handle, state, field, (void *)src, true, (hipStream_t)stream, "fmarl_set_state");
     if (rc == FMARL_OK) rc = fmarl_state_changed(handle);
     return rc;
+}
+
+int fmarl_poison_lds(void *handle, void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h) return fail(FMARL_EINVAL, "fmarl_poison_lds: null handle");
+    DeviceGuard on_device(h);
+    const int bytes = 64 * 1024;   // two such workgroups fit the 160 KB of a CU; a few rounds of them reach every CU's whole LDS
+    hipLaunchKernelGGL(fmarl::poison_lds_kernel, dim3(256 * 8 * 4), dim3(256), bytes, (hipStream_t)stream, bytes / 4);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
 }
 
 int fmarl_get_phase(void *handle) {

@@ -543,6 +543,12 @@ class RolloutEngine:
         _lib.check(self.lib.fmarl_set_phase(self.handle, phase0), 'fmarl_set_phase')   # nothing ran during the capture
         return _LockstepGraph(self, graph, phase0, int(tape.shape[0]))
 
+    def poison_lds(self):
+        """Test hook: fill every CU's LDS with 0xFF bytes (a kernel that reads an LDS table before writing it then fails
+        at once instead of seeing its own values of the previous launch)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fmarl_poison_lds(self.handle, self._stream()), 'fmarl_poison_lds')
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, capacity):
         """Record a hipEvent pair around each of the next ``capacity`` step-kernel launches (0 = off)."""

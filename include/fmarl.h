@@ -36,7 +36,9 @@ extern "C" {
 
 /* FmarlConfig.flags.  ASYNC_RESET: the next episode's placement + fair assignment (a pure function of
  * seed, env and episode index) is computed ahead of time on a library-owned side stream while the current
- * episode runs; a reset then only commits the staged state and emits the observation.  Results are
+ * episode runs; a reset then only commits the staged state and emits the observation.  The staging launches are
+ * enqueued by the first fmarl_step call AFTER a reset (not by the reset itself: they belong to a later episode and
+ * would otherwise sit behind the caller's synchronisation on the step that ended this one).  Results are
  * identical to the synchronous path.  Leave it off when capturing steps into a hipGraph (the side-stream
  * work outlives the call): fmarl_step refuses a capturing stream on a handle that has it. */
 #define FMARL_FLAG_ASYNC_RESET 1
@@ -229,6 +231,12 @@ int fmarl_state_changed(void *handle);
  * must have synchronised the stream -- and restarts. */
 int fmarl_profile_enable(void *handle, int capacity);
 int fmarl_profile_read(void *handle, float *ms, int max_count, int *count);
+
+/* Test hook (tests/test_hip_parity.py): fill the LDS of every CU with 0xFF bytes (one launch of workgroups that take
+ * 64 KB each and write all of it).  LDS is not cleared between kernels, so a table a step kernel reads before writing
+ * holds whatever the previous kernel left there: usually its own earlier values (the bug stays invisible), after this
+ * call a NaN pattern / all-ones words (it shows at once). */
+int fmarl_poison_lds(void *handle, void *stream);
 
 /* --- pieces exported on their own -------------------------------------------------------- */
 
