@@ -27,15 +27,14 @@ def pytest_collection_modifyitems(config, items):
         return
     if getattr(RolloutEngine, '_poisoned', False):
         return
-    step, reset = RolloutEngine.step, RolloutEngine.reset
-
-    def poisoned_step(self, *a, **kw):
-        if not torch.cuda.is_current_stream_capturing():
-            self.poison_lds()
-        return step(self, *a, **kw)
-
-    def poisoned_reset(self, *a, **kw):
-        if not torch.cuda.is_current_stream_capturing():
-            self.poison_lds()
-        return reset(self, *a, **kw)
-    RolloutEngine.step, RolloutEngine.reset, RolloutEngine._poisoned = poisoned_step, poisoned_reset, True
+    def poisoned(fn):
+        def call(self, *a, **kw):
+            if not torch.cuda.is_current_stream_capturing():
+                self.poison_lds()
+            return fn(self, *a, **kw)
+        call.__name__, call.__doc__ = fn.__name__, fn.__doc__
+        return call
+    for name in ('step', 'reset', 'rebuild_graph', 'update_graph', 'process_adj', 'process_infos', 'lexifair', 'cost_matrix'):
+        if hasattr(RolloutEngine, name):
+            setattr(RolloutEngine, name, poisoned(getattr(RolloutEngine, name)))
+    RolloutEngine._poisoned = True

@@ -1051,7 +1051,8 @@ def test_formation_golden_trajectory(name):
             np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
 
 
-@pytest.mark.parametrize('N,L,O,thr,n', [(10, 1, 3, 0.05, 120), (3, 1, 3, 0.05, 200), (6, 2, 2, 0.45, 64), (24, 1, 4, 0.05, 9)])
+@pytest.mark.parametrize('N,L,O,thr,n', [(10, 1, 3, 0.05, 120), (3, 1, 3, 0.05, 200), (6, 2, 2, 0.45, 64), (24, 1, 4, 0.05, 9),
+                                           (16, 1, 2, 0.05, 8), (17, 2, 1, 0.3, 6), (32, 1, 0, 0.05, 4), (1, 1, 2, 0.3, 50)])
 def test_formation_reset_and_rollout_vs_philox_oracle(N, L, O, thr, n):
     seed = 99 + N
     cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_agents=N, num_landmarks=L, num_obstacles=O, min_dist_thresh=thr)
@@ -1163,7 +1164,8 @@ def test_fairnav_golden_trajectory(name):
 
 
 @pytest.mark.parametrize('N,O,W,thr,mod,n', [(3, 3, 0, 0.05, 0.5, 150), (10, 3, 0, 0.05, 0.5, 40), (5, 2, 2, 0.3, 0.6, 64),
-                                             (7, 1, 1, 0.4, 0.3, 33), (20, 2, 0, 0.1, 0.5, 6)])
+                                             (7, 1, 1, 0.4, 0.3, 33), (20, 2, 0, 0.1, 0.5, 6), (16, 1, 0, 0.05, 0.5, 5),
+                                             (17, 0, 1, 0.2, 0.5, 4), (32, 0, 0, 0.05, 0.5, 3), (2, 1, 0, 0.05, 0.5, 70)])   # (N = 2 with thr 0.3 fills both goals: the reference itself raises at nf:903, argmin of an empty list)
 def test_fairnav_reset_and_rollout_vs_philox_oracle(N, O, W, thr, mod, n):
     """Device reset + 40 steps; with the larger thresholds agents reach their goals, get `status`, and envs
     end their episodes early at different steps (per-env auto-reset)."""
