@@ -251,11 +251,25 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     double pd = 0;
     int step = 0;
     bool emit = false;   // this env's obs / node_obs / adj are written by this launch
+    // Every global load of the launch is issued here, in one batch: loads placed where their value is first used cost a
+    // memory round trip each (nine in a row at the head of every wave), and a load behind stores waits for those stores
+    // (one vmcnt counter orders both on gfx9).
+    double Dg_old = 0, Tr_old = 0, fdone = 0, socc = 0, mtime = 0;
+    int noc_old = 0, nac_old = 0, a_pre = -1;
     if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
+        const double2 so = p.slot_pos[g];
+        const double vd = p.match_dual[g];
+        socc = p.slot_occ[g];
+        if (STEP) {
+            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; fdone = p.formation_done[g];
+            noc_old = p.num_obst_coll[g]; nac_old = p.num_agent_coll[g];
+            if (o.info) mtime = p.min_time[g];
+            if (action_idx) a_pre = action_idx[g];
+        }
         t.pos()[i] = x;
-        t.slot_old()[i] = p.slot_pos[g];
-        t.vdual()[i] = p.match_dual[g];
+        t.slot_old()[i] = so;
+        t.vdual()[i] = vd;
         if (i == 0) { t.words()[0] = 0; t.words()[1] = 0; *t.openmask() = 0; }
         step = p.cur_step[env] + (STEP ? 1 : 0);
         emit = STEP ? !(auto_reset && step >= p.episode_length) : p.reset_flag[env] != 0;
@@ -265,12 +279,12 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (!STEP && !__syncthreads_or(active && p.reset_flag[env] != 0)) return;
     load_statics(p, lds, env0, nenv);
     __syncthreads();   // the only workgroup barrier: the entity tables are loaded by all four waves together
-    if (active && p.slot_occ[g] != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
+    if (active && socc != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
 
-    if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd);
+    if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, true, a_pre);
     wave_sync();   // every lane has finished reading the old positions
 
-    double Dg_old = 0, Tr_old = 0, Tr_new = 0, fdone = 0;
+    double Tr_new = 0;
     const double2 L0 = active ? t.pos()[N] : make_double2(0, 0);   // landmark 0
     if (active) {
         t.pos()[i] = x;
@@ -280,7 +294,6 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         if (th < 0) th += 2 * M_PI;
         t.theta()[i] = th;
         if (STEP) {
-            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; fdone = p.formation_done[g];
             const bool open = Tr_old == -1.0;
             const double fd = dist2(x, L0);   // ff:445-451 ring test
             const bool ring = fd < 1.05 * kTargetRadius && fd > 0.95 * kTargetRadius;
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             rew += p.fair_rew * tanh(fairness - 5.0);
             rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
-            const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
+            const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
             p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
             p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left;
             p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
                 inf[FMARL_INFO_FORMATION_DIST * plane] = (float)fdone;          // 'Formation_dist' (ff:495)
                 inf[FMARL_INFO_TIME_STDDEV * plane] = 0.f;
                 inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = 0.f;
-                inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
+                inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)mtime;
                 inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
             }
         }

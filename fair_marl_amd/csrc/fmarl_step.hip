@@ -431,11 +431,11 @@ __device__ __forceinline__ void mixed_stats(const double *fresh, const double *s
 // can leave velocity / path length in memory until integrate_agent (fewer live registers across the pair loop).
 __device__ __forceinline__ double2 agent_force(const Params &p, const char *base, int i, size_t g,
                                                const int32_t *action_idx, const float *action_vec,
-                                               const double2 x, bool agent_forces = true) {
+                                               const double2 x, bool agent_forces = true, int a_pre = -1) {
     const double2 *s_pos = (const double2 *)(base + p.lds_pos);
     double ux, uy;
     if (action_idx) {
-        int a = action_idx[g];
+        const int a = a_pre >= 0 ? a_pre : action_idx[g];   // (a_pre: the caller's early load of action_idx[g])
         ux = kSensitivity * (double)((a == 1) - (a == 2));
         uy = kSensitivity * (double)((a == 3) - (a == 4));
     } else {
@@ -539,8 +539,8 @@ __device__ __forceinline__ void integrate_agent(const Params &p, const double2 F
 // World.step for agent i: both halves.
 __device__ __forceinline__ void world_step_agent(const Params &p, const char *base, int i, size_t g,
                                                  const int32_t *action_idx, const float *action_vec,
-                                                 double2 &x, double2 &v, double &pd, bool agent_forces = true) {
-    const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x, agent_forces);
+                                                 double2 &x, double2 &v, double &pd, bool agent_forces = true, int a_pre = -1) {
+    const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x, agent_forces, a_pre);
     integrate_agent(p, F, x, v, pd);
 }
 
