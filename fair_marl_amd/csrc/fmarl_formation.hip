@@ -254,30 +254,35 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     // Every global load of the launch is issued here, in one batch: loads placed where their value is first used cost a
     // memory round trip each (nine in a row at the head of every wave), and a load behind stores waits for those stores
     // (one vmcnt counter orders both on gfx9).
-    double Dg_old = 0, Tr_old = 0, fdone = 0, socc = 0, mtime = 0;
-    int noc_old = 0, nac_old = 0, a_pre = -1;
+    double Dg_old = 0, Tr_old = 0, fdone = 0, socc = 0, mtime = 0, vd = 0;
+    double2 so = make_double2(0, 0);
+    int noc_old = 0, nac_old = 0, a_pre = -1, cs = 0, rf = 0;
     if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
-        const double2 so = p.slot_pos[g];
-        const double vd = p.match_dual[g];
+        so = p.slot_pos[g];
+        vd = p.match_dual[g];
         socc = p.slot_occ[g];
+        cs = p.cur_step[env];
+        if (!STEP) rf = p.reset_flag[env];
         if (STEP) {
             Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; fdone = p.formation_done[g];
             noc_old = p.num_obst_coll[g]; nac_old = p.num_agent_coll[g];
             if (o.info) mtime = p.min_time[g];
             if (action_idx) a_pre = action_idx[g];
         }
+    }
+    // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
+    if (!STEP && !__syncthreads_or(active && rf != 0)) return;
+    load_statics(p, lds, env0, nenv);   // (its loads join the batch: nothing above has waited for a value yet)
+    if (active) {
         t.pos()[i] = x;
         t.slot_old()[i] = so;
         t.vdual()[i] = vd;
         if (i == 0) { t.words()[0] = 0; t.words()[1] = 0; *t.openmask() = 0; }
-        step = p.cur_step[env] + (STEP ? 1 : 0);
-        emit = STEP ? !(auto_reset && step >= p.episode_length) : p.reset_flag[env] != 0;
+        step = cs + (STEP ? 1 : 0);
+        emit = STEP ? !(auto_reset && step >= p.episode_length) : rf != 0;
         if (i == 0) *t.flag() = emit ? 0 : 1;
     }
-    // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
-    if (!STEP && !__syncthreads_or(active && p.reset_flag[env] != 0)) return;
-    load_statics(p, lds, env0, nenv);
     __syncthreads();   // the only workgroup barrier: the entity tables are loaded by all four waves together
     if (active && socc != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
 
