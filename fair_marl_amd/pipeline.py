@@ -63,7 +63,12 @@ class PipelinedRollout:
         """One step of every sub-batch, each on its own stream (asynchronous; see ``join``).  ``actions``: one
         (n_envs, N) int32 / (n_envs, N, 5) float tensor, or a list of k per-sub-batch tensors."""
         parts = self._split(actions)
-        self._each(lambda j, e: e.step(parts[j], auto_reset=auto_reset))
+
+        def one(j, e):
+            if isinstance(parts[j], torch.Tensor) and parts[j].is_cuda:
+                parts[j].record_stream(self.streams[j])   # allocated on the caller's stream, read on this one
+            e.step(parts[j], auto_reset=auto_reset)
+        self._each(one)
 
     def join(self, j=None):
         """Order the caller's stream behind sub-batch j's last step (all sub-batches if None)."""
