@@ -342,6 +342,9 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     }
     // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
     if ((p.n_envs + epb - 1) / epb < 512) { int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb); }
+#ifdef FMARL_MEASURE
+    if (const char *e = getenv("FMARL_EPB")) { const int v = atoi(e); if (v >= 1 && v <= epb) epb = v; }   // envs per workgroup (experiments)
+#endif
     if (form) { p.epw = (epb + kThreads / 64 - 1) / (kThreads / 64); epb = p.epw * (kThreads / 64); }
     if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
