@@ -136,7 +136,7 @@ __device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *
 }
 
 template <int G>
-__device__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool only_flagged) {
+__device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool only_flagged) {
     const int group = threadIdx.x / G, ngroups = kThreads / G, lane = threadIdx.x % G;
     for (int el = group; el < nenv; el += ngroups) {
         const FairNavLds t(p, lds, el);

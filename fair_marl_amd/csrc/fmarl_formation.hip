@@ -94,7 +94,7 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int8_
 // All matchings of the workgroup's envs: task = (env, which) with which 0 = current slots, 1 = previous
 // slots (needed by observation(0) of a step); groups of G lanes take tasks round-robin.
 template <int G>
-__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env);
+__device__ __forceinline__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env);
 
 // Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
 struct FormLds {
@@ -131,7 +131,7 @@ struct FormLds {
 };
 
 template <int G>
-__device__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env) {
+__device__ __forceinline__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env) {
     // the wave's own envs only: its 64 / G lane groups take the tasks round-robin, no other wave is involved
     const int group = (threadIdx.x & 63) / G, ngroups = 64 / G;
     for (int task = group; task < nenv_w * per_env; task += ngroups) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t feature_src(const Params &p, uint32_t e, uin
 // environments: each lane builds the entity part of its CG column chunks once per env, then the wave
 // streams the N ego rows front to back (1 KiB per store instruction, rows back to back in memory).
 template <int CG>
-__device__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
+__device__ __forceinline__ void emit_node_rows(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int nenv) {
     // the wave index is uniform: say so, and the env / row addressing below stays in scalar registers
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = kThreads / 64;
     const uint32_t EF = p.E * p.F, C4 = EF >> 2;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void emit_node_rows_generic(const Params &p, const Fm
 }
 
 // Emission of the graph outputs of the workgroup's envs.
-__device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+__device__ __forceinline__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x;
     const uint32_t NEF = p.N * p.E * p.F, EF = p.E * p.F, EE = p.E * p.E;
     if (o.node_obs && p.vec_node) {
@@ -378,7 +378,7 @@ __device__ __forceinline__ void store_agent_rows(const Params &p, char *base, in
 
 // Loads landmarks / obstacles / walls of the envs [el_begin, el_end) of the workgroup into their LDS entity tables, by the
 // caller's `nthr` threads (index `thr`): the whole workgroup, or one wave for its own envs.
-__device__ void load_statics_range(const Params &p, char *lds, int env0, int el_begin, int el_end, int thr, int nthr) {
+__device__ __forceinline__ void load_statics_range(const Params &p, char *lds, int env0, int el_begin, int el_end, int thr, int nthr) {
     const int LO = p.L + p.O, cnt = el_end - el_begin;
     for (int t = thr; t < cnt * LO; t += nthr) {
         int el = el_begin + t / LO, k = t % LO;
@@ -406,7 +406,7 @@ __device__ void load_statics_range(const Params &p, char *lds, int env0, int el_
         ((float2 *)(base + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
     }
 }
-__device__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
+__device__ __forceinline__ void load_statics(const Params &p, char *lds, int env0, int nenv) {
     load_statics_range(p, lds, env0, 0, nenv, threadIdx.x, kThreads);
 }
 
