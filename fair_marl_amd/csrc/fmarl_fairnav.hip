@@ -135,12 +135,56 @@ __device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *
     return out;
 }
 
+// N <= 3 (the shipped FA+FR configuration): the lexicographic-fair assignment by enumeration -- the six permutations'
+// key vectors (key = (cost, row * G + col), the total order lexifair_group uses), each sorted descending, compared
+// lexicographically; every lane of the group evaluates all of them from the env's LDS cost table (broadcast reads) and
+// keeps its own row's column.  Same result as lexifair_group (the optimum under a total order is unique), a third of its
+// instructions at N = 3.  Rows / columns beyond N carry the same dummy key in every admissible permutation.
+template <int G>
+__device__ __forceinline__ int lexifair_upto3(const double *D, int L, int N, int lane) {
+    double c[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[r][j] = (r < N && j < N) ? D[r * L + j] : -1e300;
+    constexpr int P[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    double bk0 = 0, bk1 = 0, bk2 = 0;
+    int bi0 = 0, bi1 = 0, bi2 = 0, best = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const bool admissible = N >= 3 || (N == 2 && P[q][2] == 2) || q == 0;
+        double k0 = c[0][P[q][0]], k1 = c[1][P[q][1]], k2 = c[2][P[q][2]];
+        int i0 = P[q][0], i1 = G + P[q][1], i2 = 2 * G + P[q][2];
+        // sort the three keys descending: compare-exchange (0,1), (1,2), (0,1)
+#define FMARL_CX(ka, ia, kb, ib) { const bool sw = ka < kb || (ka == kb && ia < ib); const double tk = sw ? kb : ka; const int ti = sw ? ib : ia; \
+                                   kb = sw ? ka : kb; ib = sw ? ia : ib; ka = tk; ia = ti; }
+        FMARL_CX(k0, i0, k1, i1) FMARL_CX(k1, i1, k2, i2) FMARL_CX(k0, i0, k1, i1)
+#undef FMARL_CX
+        const bool lt0 = k0 < bk0 || (k0 == bk0 && i0 < bi0), eq0 = k0 == bk0 && i0 == bi0;
+        const bool lt1 = k1 < bk1 || (k1 == bk1 && i1 < bi1), eq1 = k1 == bk1 && i1 == bi1;
+        const bool lt2 = k2 < bk2 || (k2 == bk2 && i2 < bi2);
+        const bool take = q == 0 || (admissible && (lt0 || (eq0 && (lt1 || (eq1 && lt2)))));
+        bk0 = take ? k0 : bk0; bk1 = take ? k1 : bk1; bk2 = take ? k2 : bk2;
+        bi0 = take ? i0 : bi0; bi1 = take ? i1 : bi1; bi2 = take ? i2 : bi2;
+        best = take ? q : best;
+    }
+    // column of row `lane` in permutation `best`: 2 bits per row, 6 bits per permutation
+    constexpr unsigned long long codes = (0ull | 1ull << 2 | 2ull << 4) | (0ull | 2ull << 2 | 1ull << 4) << 6 | (1ull | 0ull << 2 | 2ull << 4) << 12 |
+                                         (1ull | 2ull << 2 | 0ull << 4) << 18 | (2ull | 0ull << 2 | 1ull << 4) << 24 | (2ull | 1ull << 2 | 0ull << 4) << 30;
+    return (int)((codes >> (6 * best + 2 * (lane < 3 ? lane : 0))) & 3ull);
+}
+
 template <int G>
 __device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool only_flagged) {
     const int group = threadIdx.x / G, ngroups = kThreads / G, lane = threadIdx.x % G;
     for (int el = group; el < nenv; el += ngroups) {
         const FairNavLds t(p, lds, el);
         if (only_flagged && t.skip()) continue;   // (group-uniform)
+        if (G == 4 && p.N <= 3) {
+            const int mc = lexifair_upto3<G>(t.D(), p.L, p.N, lane);
+            if (lane < p.N) t.match()[lane] = mc;
+            continue;
+        }
         double c[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) c[j] = (lane < p.N && j < p.N) ? t.D()[lane * p.L + j] : 0.0;

@@ -1163,6 +1163,41 @@ def test_fairnav_golden_trajectory(name):
             np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
 
 
+def test_fairnav_assignment_with_tied_costs_follows_the_total_order():
+    """nav_fairassign_fairrew_formation_graph re-assigns the goals every step (nf:704-721).  For N <= 3 the step kernel
+    enumerates the permutations instead of running the group solver: agents and goals on a lattice give exactly tied costs
+    (three agents 0.5 from one goal, pairs at sqrt(0.5) and sqrt(1.25)), where only the (cost, row, col) order decides.
+    The assignment after a no-op step must be the oracle's, for every relabelling of the agents and of the goals."""
+    import itertools
+    from oracle import lexifair as lf
+    fx = load('fnav_n3.npz')
+    ocfg = fnav_cfg_of(fx)
+    st = fnav_state_from(fx, ocfg)
+    n = st.agent_pos.shape[0]
+    A = np.array([[-0.5, 0.0], [0.5, 0.0], [0.0, 0.5]])
+    Gl = np.array([[0.0, 0.0], [0.0, -0.5], [0.0, 1.0]])
+    cases = [(pa, pg) for pa in itertools.permutations(range(3)) for pg in itertools.permutations(range(3))]
+    assert n >= 1
+    for c0 in range(0, len(cases), n):
+        chunk = cases[c0:c0 + n]
+        st2 = fnav_state_from(fx, ocfg)
+        for e, (pa, pg) in enumerate(chunk):
+            st2.agent_pos[e] = A[list(pa)]
+            st2.agent_vel[e] = 0.0
+            st2.landmark_pos[e] = Gl[list(pg)]
+            st2.obstacle_pos[e] = np.array([[0.9, 0.9], [-0.9, 0.9], [0.9, -0.9]])[:st2.obstacle_pos.shape[1]]
+        eng = fm.RolloutEngine(fnav_env_cfg(ocfg), n, device=DEV)
+        eng.set_state({k: getattr(st2, k) for k in fnv.State.FIELDS if k != 'time'})
+        eng.step(torch.zeros(n, 3, dtype=torch.int32, device=DEV), auto_reset=False)
+        got = eng.get_state()
+        for e, (pa, pg) in enumerate(chunk):
+            np.testing.assert_allclose(got['agent_pos'][e], st2.agent_pos[e], atol=1e-12)   # (softplus tails of far contacts: 1e-15)
+            d = got['agent_pos'][e][:, None, :] - st2.landmark_pos[e][None, :, :]
+            costs = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1])   # the costs of the positions the kernel assigned on
+            assert len(np.unique(costs)) < 9   # really tied
+            assert np.array_equal(got['goal_match'][e], lf.lexifair(costs)), (pa, pg, got['goal_match'][e], lf.lexifair(costs))
+
+
 @pytest.mark.parametrize('N,O,W,thr,mod,n', [(3, 3, 0, 0.05, 0.5, 150), (10, 3, 0, 0.05, 0.5, 40), (5, 2, 2, 0.3, 0.6, 64),
                                              (7, 1, 1, 0.4, 0.3, 33), (20, 2, 0, 0.1, 0.5, 6), (16, 1, 0, 0.05, 0.5, 5),
                                              (17, 0, 1, 0.2, 0.5, 4), (32, 0, 0, 0.05, 0.5, 3), (2, 1, 0, 0.05, 0.5, 70)])   # (N = 2 with thr 0.3 fills both goals: the reference itself raises at nf:903, argmin of an empty list)
