@@ -103,6 +103,9 @@ class RolloutEngine:
         import logging
         log = logging.getLogger('fair_marl_amd')
         cfg, n, dev = self.cfg, self.n_envs, self.device
+        if cfg.scenario_name != 'navigation_graph' or self.node_obs is None:
+            log.info('output placement probe skipped: it times the navigation_graph emission kernel (scenario %s)', cfg.scenario_name)
+            return
         node_bytes = self.node_obs.numel() * 4
         adj_bytes = self.adj_env.numel() * 4
         with torch.cuda.device(dev):
