@@ -38,6 +38,18 @@ struct FastDiv {
     __device__ __forceinline__ uint32_t div(uint32_t q) const { return (uint32_t)(((uint64_t)q * m) >> 40); }
 };
 
+// A wave-uniform value made opaque to the compiler.  Kernel arguments are "free to reload": when scalar registers run short
+// inside a loop the register allocator re-reads them from the kernel-argument block at every use (this build has no machine
+// LICM to hoist them back), and each s_load's s_waitcnt lgkmcnt(0) also waits for the LDS operations in flight.  A pinned
+// copy has to stay in an SGPR (or be spilled to a VGPR lane: one VALU move, no wait).
+__device__ __forceinline__ uint32_t pin_sgpr(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int pin_sgpr(int v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ uint64_t pin_sgpr(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // Kernel parameter block (passed by value).  State pointers follow include/fmarl.h FMARL_F_*.
 struct Params {
     int n_envs, N, L, O, W, E, D, F;

@@ -49,24 +49,32 @@ struct FairNavLds {
     // the 13 features of entity e in the row block of ego i (nf:1222-1334), ego part included:
     // [dv (2) | dx (2) | goal or dx (2) | occupancy, history / 1, index | dx or wall corners (4) | type]
     __device__ void node_row(uint32_t i, uint32_t e, float (&o)[13]) const {
-        const uint32_t N = p.N, first_obst = p.N + p.L, first_wall = first_obst + p.O;
+        node_row_at(base, p.N, p.L, p.O, p.lds_posf, p.lds_agentf, p.lds_wallf, p.n_rows, i, e, o);
+    }
+    // (the table offsets as arguments: the emission loop hands in copies pinned in scalar registers)
+    static __device__ __forceinline__ void node_row_at(const char *base, uint32_t N, uint32_t L, uint32_t O, uint32_t off_posf,
+                                                       uint32_t off_agentf, uint32_t off_wallf, uint32_t off_rows, uint32_t i,
+                                                       uint32_t e, float (&o)[13]) {
+        const uint32_t first_obst = N + L, first_wall = first_obst + O;
+        const float2 *posf_ = (const float2 *)(base + off_posf);
+        const float4 *agentf_ = (const float4 *)(base + off_agentf);
         // differences of the f32 roundings (as the other two scenarios' rows): what a learner-side rebuild starts from
-        const float2 pi = posf()[i], pe = posf()[e];
+        const float2 pi = posf_[i], pe = posf_[e];
         const float dx = pe.x - pi.x, dy = pe.y - pi.y;
         // velocities as they stand when graph_observation(i) runs: reward(a <= i) may have stopped a
-        const float4 ai = agentf()[i];
+        const float4 ai = agentf_[i];
         const float vix = ai.z != 0.f ? 0.f : ai.x, viy = ai.z != 0.f ? 0.f : ai.y;
         float vex = 0.f, vey = 0.f;
         if (e < N) {
-            const float4 ae = agentf()[e];
+            const float4 ae = agentf_[e];
             const bool stopped = e <= i && ae.z != 0.f;
             vex = stopped ? 0.f : ae.x; vey = stopped ? 0.f : ae.y;
         }
         o[0] = vex - vix; o[1] = vey - viy;
         o[2] = dx; o[3] = dy; o[4] = dx; o[5] = dy; o[8] = dx; o[9] = dy; o[10] = dx; o[11] = dy;
         if (e < N) {
-            const NavRow r = rows()[i * N + e];
-            const float2 gl = r.code >= 0 ? posf()[N + r.code] : pe;
+            const NavRow r = ((const NavRow *)(base + off_rows))[i * N + e];
+            const float2 gl = r.code >= 0 ? posf_[N + r.code] : pe;
             o[4] = gl.x - pi.x; o[5] = gl.y - pi.y;
             o[6] = r.occ; o[7] = r.hist;
             o[12] = 0.f;
@@ -76,7 +84,7 @@ struct FairNavLds {
             o[12] = e < first_obst ? 1.f : (e < first_wall ? 2.f : 3.f);
         }
         if (e >= first_wall) {   // corners (e0, axis + w/2), (e1, axis - w/2)
-            const float4 wc = wallf()[e - first_wall];
+            const float4 wc = ((const float4 *)(base + off_wallf))[e - first_wall];
             o[8] = wc.x - pi.x; o[9] = wc.y - pi.y; o[10] = wc.z - pi.x; o[11] = wc.w - pi.y;
         }
     }
@@ -204,12 +212,18 @@ __device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOu
         float *dst = o.node_obs + (size_t)env0 * NE * 13;
         const bool some_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
         if (!some_skip) {
+            // what the loop needs of the kernel arguments, pinned (fmarl_dev.h pin_sgpr)
+            const uint32_t kN = pin_sgpr((uint32_t)p.N), kL = pin_sgpr((uint32_t)p.L), kO = pin_sgpr((uint32_t)p.O), kE = pin_sgpr((uint32_t)p.E);
+            const uint32_t k_env = pin_sgpr((uint32_t)p.lds_env_bytes), k_posf = pin_sgpr((uint32_t)p.lds_posf), k_agentf = pin_sgpr((uint32_t)p.lds_agentf);
+            const uint32_t k_wallf = pin_sgpr((uint32_t)p.lds_wallf), k_rows = pin_sgpr((uint32_t)p.n_rows);
+            FastDiv dNE, dE;
+            dNE.m = pin_sgpr(p.dC4.m); dNE.d = p.dC4.d; dE.m = pin_sgpr(p.dE.m); dE.d = p.dE.d;
             for (uint32_t base = 0; base < total; base += kThreads) {
                 const uint32_t q = base + tid, w0 = base + (tid & ~63u);
                 float row[13];
                 if (q < total) {
-                    const uint32_t e_l = p.dC4.div(q), r = q - e_l * NE, a = p.dE.div(r), e = r - a * p.E;   // dC4 = N * E
-                    FairNavLds(p, lds, e_l).node_row(a, e, row);
+                    const uint32_t e_l = dNE.div(q), r = q - e_l * NE, a = dE.div(r), e = r - a * kE;   // dC4 = N * E
+                    FairNavLds::node_row_at(lds + (size_t)e_l * k_env, kN, kL, kO, k_posf, k_agentf, k_wallf, k_rows, a, e, row);
                 }
                 flush_rows<13, true>(p, lds, row, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
             }

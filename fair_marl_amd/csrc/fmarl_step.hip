@@ -224,16 +224,20 @@ __device__ __forceinline__ void emit_sync(uint32_t nthr) {
 template <int MODE>
 __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
                                                  int el_end, uint32_t thr, uint32_t nthr, EdgeCount &ec, bool count) {
-    const uint32_t E = p.E, EE = E * E, total = (el_end - el_begin) * EE;
+    // (what the loop needs of the kernel arguments is pinned in scalar registers: fmarl_dev.h pin_sgpr)
+    const uint32_t E = pin_sgpr((uint32_t)p.E), EE = E * E, total = (el_end - el_begin) * EE;
+    const uint32_t k_env = pin_sgpr((uint32_t)p.lds_env_bytes), k_posf = pin_sgpr((uint32_t)p.lds_posf), k_flag = pin_sgpr((uint32_t)p.lds_flag);
+    FastDiv dEE, dE;
+    dEE.m = pin_sgpr(p.dEE.m); dEE.d = p.dEE.d; dE.m = pin_sgpr(p.dE.m); dE.d = p.dE.d;
     float *dst = o.adj + ((size_t)env0 + el_begin) * EE;
     const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 15), end = shift + total;   // 64-byte aligned frame (lane quads = blocks)
     float *gal = dst - shift;
-    const char *tb0 = lds + (size_t)el_begin * p.lds_env_bytes;
+    const char *tb0 = lds + (size_t)el_begin * k_env;
     for (uint32_t k = thr; k < ((end + 3) >> 2); k += nthr) {
         // (env, a, b) of the chunk's first entry inside the region by two divisions, of the others by stepping; the loads of
         // the four entries carry no branches, so they are all in flight together
         const uint32_t first = 4 * k > shift ? 4 * k - shift : 0;
-        uint32_t elq = p.dEE.div(first), r = first - elq * EE, a = p.dE.div(r), b = r - a * E;
+        uint32_t elq = dEE.div(first), r = first - elq * EE, a = dE.div(r), b = r - a * E;
         float v[4];
         int el[4];
         uint32_t okm = 0;
@@ -241,9 +245,9 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
         for (int j = 0; j < 4; ++j) {
             const uint32_t idx = 4 * k + j;
             const bool in = idx >= shift && idx < end;
-            const char *tb = tb0 + (size_t)(in ? elq : 0u) * p.lds_env_bytes;
-            const float2 pa = ((const float2 *)(tb + p.lds_posf))[in ? a : 0u], pb = ((const float2 *)(tb + p.lds_posf))[in ? b : 0u];
-            const bool emit = in && *(const int *)(tb + p.lds_flag) == 0;   // the f32 position table (what a learner-side rebuild has)
+            const char *tb = tb0 + (size_t)(in ? elq : 0u) * k_env;
+            const float2 pa = ((const float2 *)(tb + k_posf))[in ? a : 0u], pb = ((const float2 *)(tb + k_posf))[in ? b : 0u];
+            const bool emit = in && *(const int *)(tb + k_flag) == 0;   // the f32 position table (what a learner-side rebuild has)
             v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
             el[j] = el_begin + (int)elq;
             okm |= (emit ? 1u : 0u) << j;
