@@ -208,6 +208,8 @@ def main():
     if args.pipeline > 1:
         if args.graph or args.rccl_selftest:
             raise SystemExit('bench.py: --pipeline does not combine with --graph / --rccl-selftest')
+        if world > 1 and not args.no_gather:   # never a multi-GPU number that silently dropped the exchange
+            raise SystemExit('bench.py: --pipeline has no trajectory gather; for N > 1 say so with --no-gather')
         gather = False
         pipe = fm.PipelinedRollout(cfg, n_envs, k=args.pipeline, device=device, seed=1, env_offset=rank * n_envs,
                                    async_reset=not args.sync_reset, tune_placement=0)
