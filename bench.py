@@ -179,6 +179,12 @@ def main():
         except Exception as exc:   # e.g. no process spawning on this host: fall back to one in-process worker
             print('bench.py: multi-process cpu baseline failed (%s); using one process' % exc, file=sys.stderr)
             cpu = cpu_baseline(spec['env'], spec['cpu_envs'], spec['cpu_episodes'], 1)
+    # stdout carries exactly one JSON line.  Libraries write there too -- the GPU boxes export NCCL_DEBUG=VERSION and RCCL
+    # prints a five-line version banner to stdout when the first communicator is created -- so from here on file descriptor 1
+    # is stderr, and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     device = torch.device('cuda', local_rank if args.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
@@ -374,7 +380,8 @@ def main():
             out['cpu_baseline'] = cpu
         if args.config in REFERENCE_CPU:
             out['reference_cpu'] = REFERENCE_CPU[args.config]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
