@@ -68,7 +68,8 @@ def fnav_state_from(fx, cfg, prefix='init_'):
     return st
 
 
-RUNNER = ['runner_nav.npz', 'runner_navw.npz', 'runner_form.npz', 'runner_fnav.npz']
+RUNNER = ['runner_nav.npz', 'runner_navw.npz', 'runner_form.npz', 'runner_fnav.npz', 'runner_nav10.npz', 'runner_form10.npz',
+          'runner_fnav6.npz']
 
 
 def runner_oracle_env(fx):
