@@ -68,7 +68,7 @@ def fnav_state_from(fx, cfg, prefix='init_'):
     return st
 
 
-RUNNER = ['runner_nav.npz', 'runner_navw.npz', 'runner_form.npz', 'runner_fnav.npz', 'runner_nav10.npz', 'runner_form10.npz',
+RUNNER = ['runner_nav.npz', 'runner_navw.npz', 'runner_form.npz', 'runner_fnav.npz', 'runner_nav10.npz', 'runner_nav32.npz', 'runner_form10.npz',
           'runner_fnav6.npz']
 
 
