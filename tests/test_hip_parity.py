@@ -1008,6 +1008,40 @@ def test_full_size_properties_cfg3():
     check_outputs((obs[s], ids[s], node[s], adj[s], rew[s], done[s], info[s]), out, 'cfg3 sample')
 
 
+def test_full_size_odd_row_widths_n10():
+    """The reference's own experiment scale at full batch: 10 agents, E = 23 (E F = 253, E E = 529: nothing is a multiple
+    of 4, every row goes through the per-wave LDS windows), 65 536 envs; properties + oracle parity on a strided sample."""
+    cfg = fm.EnvConfig(num_agents=10, num_landmarks=10, num_obstacles=3)
+    n, N = 65536, 10
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=13, count_edges=True)
+    eng.reset()
+    g = torch.Generator(device=DEV); g.manual_seed(2)
+    sample = torch.arange(0, n, 1531, device=DEV)
+    ocfg = no.Config(**{k: getattr(cfg, k) for k in no.Config.__dataclass_fields__})
+    for t in range(3):
+        a = torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32)
+        if t == 2:
+            st = no.State(ocfg, len(sample))
+            pre = eng.get_state()
+            for k in no.State.FIELDS:
+                if k != 'time':
+                    getattr(st, k)[...] = pre[k][sample.cpu().numpy()]
+            st.time[...] = (st.cur_step * no.DT)[:, None]
+        obs, ids, node, adj, rew, done, info = eng.step(a, auto_reset=False)
+    adj_env = eng.adj_env
+    assert torch.equal(adj_env, adj_env.transpose(1, 2)) and (torch.diagonal(adj_env, dim1=1, dim2=2) == 0).all()
+    assert torch.isfinite(node).all() and torch.isfinite(obs).all()
+    rel = node[:, :, :N, 2:4]
+    assert torch.allclose(rel, -rel.transpose(1, 2), atol=1e-6)
+    assert torch.allclose(rel.norm(dim=-1), adj_env[:, :N, :N], atol=1e-6)
+    assert (node[..., 10] == torch.tensor([0.] * 10 + [1.] * 10 + [2.] * 3, device=DEV)).all()
+    cnt = ((adj_env > 0) & (adj_env < cfg.max_edge_dist)).sum(dim=(1, 2)).to(torch.int32)
+    assert torch.equal(cnt, eng.outs.edge_nnz)   # the fused policy-edge count on the generic adj path
+    out = no.env_step(ocfg, st, a[sample].cpu().numpy())
+    s = sample
+    check_outputs((obs[s], ids[s], node[s], adj[s], rew[s], done[s], info[s]), out, 'n10 sample')
+
+
 # ------------------------------------------------------------------ fair_graph_formation (BASELINE config 4)
 from oracle import formation_oracle as fo  # noqa: E402
 from helpers import FORM, form_cfg_of, form_state_from  # noqa: E402
@@ -1233,3 +1267,33 @@ def test_fairnav_reset_and_rollout_vs_philox_oracle(N, O, W, thr, mod, n):
             np.testing.assert_allclose(got[k], getattr(orc.st, k), err_msg='end ' + k, **STATE)
     if thr >= 0.4:
         assert early > 0   # some envs did finish early
+
+
+def test_fairnav_full_size():
+    """The shipped FA+FR configuration at full batch (3 agents, E = 9, 65 536 envs): oracle parity on a strided sample after a
+    few steps (in-kernel resets, the N <= 3 assignment by enumeration, 13-float rows through the LDS windows)."""
+    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3, num_obstacles=3,
+                       goal_rew=30.0, collision_rew=30.0)   # bench.py's fnav config (a large min_dist_thresh can fill every goal,
+    n, N = 65536, 3                                         #  where the reference itself raises: nf:903)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=19)
+    eng.reset()
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    sample = np.arange(0, n, 769)
+    ocfg = fnv.Config(**{k: getattr(cfg, k) for k in fnv.Config.__dataclass_fields__})
+    for t in range(6):
+        a = torch.randint(0, 5, (n, N), device=DEV, generator=g, dtype=torch.int32)
+        if t == 5:
+            st = fnv.State(ocfg, len(sample))
+            pre = eng.get_state()
+            for k in fnv.State.FIELDS:
+                if k != 'time':
+                    getattr(st, k)[...] = pre[k][sample]
+        res = eng.step(a, auto_reset=False)
+    out = fnv.env_step(ocfg, st, a[torch.as_tensor(sample, device=DEV)].cpu().numpy())
+    s = torch.as_tensor(sample, device=DEV)
+    check_outputs(tuple(x[s] for x in res), out, 'fnav sample')
+    adj_env = eng.adj_env
+    assert torch.equal(adj_env, adj_env.transpose(1, 2)) and (torch.diagonal(adj_env, dim1=1, dim2=2) == 0).all()
+    assert torch.isfinite(eng.node_obs).all()
+    gm = torch.as_tensor(eng.get_state()['goal_match'])
+    assert bool((gm.sort(dim=1).values == torch.arange(N)).all())
