@@ -134,7 +134,7 @@ def test_constant_distance_vectors_keep_std_exactly_zero(N):
         check_outputs((obs, ids, node, adj, rew, done, info), want, 'N=%d step %d' % (N, t))
 
 
-@pytest.mark.parametrize('case', range(36))
+@pytest.mark.parametrize('case', range(int(os.environ.get('FMARL_FUZZ_CASES', '36'))))   # (more cases for a one-off hunt)
 def test_random_small_configs_vs_oracle(case):
     """Ragged / degenerate shapes and knobs: N = 1, no obstacles, walls, n_envs = 1, episode_length = 1,
     max_speed None, odd E (one-float-per-lane emission path), large thresholds (arrivals, occupied slots,
@@ -172,7 +172,12 @@ def test_random_small_configs_vs_oracle(case):
     for t in range(2 * ep + 1):
         a = rs.randint(0, 5, size=(n, N))
         res = eng.step(torch.as_tensor(a, device=DEV))
-        ref = orc.step(a)
+        try:
+            ref = orc.step(a)
+        except ValueError as exc:   # nf:888-903: every goal occupied -> the reference takes argmin of an empty list
+            if kind == 1 and 'empty sequence' in str(exc):
+                pytest.skip('the reference itself raises in this state')
+            raise
         want = dict(obs=ref[0], node_obs=ref[2], adj=ref[3][:, 0], reward=ref[4], done=ref[5], info=ref[6])
         check(res, want, 'case %d %s step %d' % (case, cfg, t))
 
