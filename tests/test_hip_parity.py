@@ -142,7 +142,7 @@ def test_random_small_configs_vs_oracle(case):
     from oracle import fairnav_oracle as fnv
     rs = np.random.RandomState(1000 + case)
     kind = case % 3   # 0 navigation_graph, 1 nav_fairassign_fairrew_formation_graph, 2 fair_graph_formation
-    N = int(rs.randint(2 if kind == 1 else 1, 10)); O = int(rs.randint(0, 5)); W = int(rs.randint(0, 3)); n = int(rs.choice([1, 2, 7, 33]))
+    N = int(rs.randint(2 if kind == 1 else 1, int(os.environ.get('FMARL_FUZZ_NMAX', '10')))); O = int(rs.randint(0, 5)); W = int(rs.randint(0, 3)); n = int(rs.choice([1, 2, 7, 33]))
     ep = int(rs.choice([1, 2, 5, 9]))
     kw = dict(num_agents=N, num_obstacles=O, episode_length=ep, max_speed=None if case % 5 == 4 else float(rs.choice([0.7, 2.0])),
               min_dist_thresh=float(rs.choice([0.05, 0.3, 0.6])), goal_rew=float(rs.choice([5, 2.5])), collision_rew=float(rs.choice([5, 1.0])))
