@@ -330,7 +330,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     int epb = kThreads / p.N;
     int shared_bytes = (kThreads / 64) * p.stage_wave_bytes;   // the windows' region (also holds the shared statistics blocks)
     if (stat_shared && epb * 5 * p.N * 8 > shared_bytes) shared_bytes = epb * 5 * p.N * 8;
-    const int budget = 48 * 1024 - shared_bytes;
+    // 40 KB per workgroup = four workgroups per CU (160 KB).  With 48 KB the shipped nav_fairassign configuration took 47 envs
+    // per workgroup at three per CU: 0.082 ms per launch against 0.078 with 36 envs at four per CU (tools/epb_probe.sh fnav);
+    // navigation_graph at 10 agents had gained 7 % from the same 3 -> 4 step.
+    const int budget = 40 * 1024 - shared_bytes;
     if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
     if (epb < 1) epb = 1;
     if (form) {   // every env inside one wave (fmarl_formation.hip): 64 / N envs per wave, four waves
