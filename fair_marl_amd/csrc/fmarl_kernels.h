@@ -7,6 +7,8 @@ namespace fmarl {
 // fmarl_step.hip
 __global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
                             int auto_reset);
+__global__ void step_end_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
+                                int auto_reset);
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv);
 __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
 __device__ void load_statics_range(const Params &p, char *lds, int env0, int el_begin, int el_end, int thr, int nthr);

@@ -548,8 +548,12 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
     integrate_agent(p, F, x, v, pd);
 }
 
-__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
-    Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
+// FOLD = false: the step.  FOLD = true: the step that ends an episode whose successor is already staged (asynchronous reset,
+// envs in lockstep): after the terminal reward / done / info the same launch commits the staged episode (reset_commit_kernel)
+// and emits its first observation (reset_emit_kernel) -- one launch instead of a non-emitting step, a commit and an emission.
+template <bool FOLD>
+__device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx, const float *action_vec,
+                                          int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int env0 = blockIdx.x * p.epb;
@@ -696,8 +700,81 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
             inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
         }
     }
+    if (FOLD) {
+        __syncthreads();   // the terminal state's LDS tables have served the last reader
+        // reset_commit_kernel (fmarl_reset.hip) for the envs that end here, by the same thread per (env, agent)
+        double2 nx = x;
+        int nm = match;
+        if (active && will_reset) {
+            nx = p.st_agent_pos[g];
+            nm = p.st_goal_match[g];
+            if (p.has_max_speed)   // navigation_graph.py:545-547: against the PREVIOUS goal_match
+                p.min_time[g] = dist2(nx, p.st_landmark_pos[(size_t)env * p.L + match]) / p.max_speed;
+            p.agent_pos[g] = nx; p.agent_vel[g] = make_double2(0.0, 0.0); p.p_dist[g] = 0.0;
+            p.goal_match[g] = nm;
+            p.times_required[g] = -1.0; p.dists_to_goal[g] = -1.0; p.dist_left[g] = -1.0;
+            p.num_obst_coll[g] = 0; p.num_agent_coll[g] = 0;
+            s_pos[i] = nx;
+            if (i == 0) {
+                p.cur_step[env] = 0; p.episode[env] += 1; p.stage_valid[env] = 0; p.place_fails[env] = p.st_place_fails[env];
+                p.reset_flag[env] = 1;
+            }
+        } else if (active && i == 0) p.reset_flag[env] = 0;
+        // static entities of the new episode: staged arrays -> live arrays and LDS tables in one pass
+        {
+            const int LO = p.L + p.O;
+            for (int t = tid; t < nenv * LO; t += kThreads) {
+                const int e_l = t / LO, k = t - e_l * LO, e_g = env0 + e_l;
+                if (*(const int *)(lds + (size_t)e_l * p.lds_env_bytes + p.lds_flag) == 0) continue;   // (flag 1 = ends here; 0 keeps its tables)
+                double2 *pos = (double2 *)(lds + (size_t)e_l * p.lds_env_bytes + p.lds_pos);
+                double2 sx;
+                if (k < p.L) { sx = p.st_landmark_pos[(size_t)e_g * p.L + k]; p.landmark_pos[(size_t)e_g * p.L + k] = sx; }
+                else { sx = p.st_obstacle_pos[(size_t)e_g * p.O + (k - p.L)]; p.obstacle_pos[(size_t)e_g * p.O + (k - p.L)] = sx; }
+                pos[p.N + k] = sx;
+                ((float2 *)(lds + (size_t)e_l * p.lds_env_bytes + p.lds_posf))[p.N + k] = make_float2((float)sx.x, (float)sx.y);
+            }
+            for (int t = tid; t < nenv * p.W; t += kThreads) {
+                const int e_l = t / p.W, w = t - e_l * p.W, e_g = env0 + e_l;
+                char *eb = lds + (size_t)e_l * p.lds_env_bytes;
+                if (*(const int *)(eb + p.lds_flag) == 0) continue;
+                const size_t gw = (size_t)e_g * p.W + w;
+                const double axis = p.st_wall_axis[gw], e0 = -p.wall_length[e_g], e1 = p.wall_length[e_g];
+                const int orient = p.st_wall_orient[gw];
+                p.wall_axis[gw] = axis; p.wall_orient[gw] = orient; p.wall_e0[gw] = e0; p.wall_e1[gw] = e1;
+                double *wl = (double *)(eb + p.lds_wall) + w * 4;
+                wl[0] = axis; wl[1] = e0; wl[2] = e1; wl[3] = (double)orient;
+                if (p.has_wallf) ((float4 *)(eb + p.lds_wallf))[w] = make_float4((float)e0, (float)(axis + kWallWidth / 2), (float)e1, (float)(axis - kWallWidth / 2));
+                const double2 c = orient == 0 ? make_double2(0.0, axis) : make_double2(axis, 0.0);
+                ((double2 *)(eb + p.lds_pos))[p.N + LO + w] = c;
+                ((float2 *)(eb + p.lds_posf))[p.N + LO + w] = make_float2((float)c.x, (float)c.y);
+            }
+        }
+        __syncthreads();
+        if (active && will_reset) {   // reset_emit_kernel: the first observation (environment.py:882-898); all path lengths are 0,
+            const double2 ngoal = s_pos[p.N + nm];   // dists_to_goal -1: the fairness scalar is 0 / (0 + 1e-4)
+            if (o.obs) {
+                float *ob = o.obs + g * p.D;
+                ob[0] = 0.f; ob[1] = 0.f; ob[2] = (float)nx.x; ob[3] = (float)nx.y;
+                ob[4] = (float)(ngoal.x - nx.x); ob[5] = (float)(ngoal.y - nx.y); ob[6] = 0.f;
+            }
+            store_agent_rows(p, base, i, nx, make_double2(0.0, 0.0), ngoal);
+        }
+        __syncthreads();   // every reader of the "ends here" flags is through
+        if (active && will_reset && i == 0) *(int *)(base + p.lds_flag) = 0;   // this env emits after all
+        __syncthreads();
+    }
     // emission only reads pos / agentf / wall / flag, all final since the barrier above
     if (!FMARL_SKIP(p, 32)) emit_graph(p, o, lds, env0, nenv);
+}
+
+__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
+    Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
+    step_body<false>(p, o, action_idx, action_vec, auto_reset);
+}
+
+__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
+    Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
+    step_body<true>(p, o, action_idx, action_vec, auto_reset);
 }
 
 }  // namespace fmarl

@@ -38,7 +38,9 @@ extern "C" {
  * seed, env and episode index) is computed ahead of time on a library-owned side stream while the current
  * episode runs; a reset then only commits the staged state and emits the observation.  The staging launches are
  * enqueued by the first fmarl_step call AFTER a reset (not by the reset itself: they belong to a later episode and
- * would otherwise sit behind the caller's synchronisation on the step that ended this one).  Results are
+ * would otherwise sit behind the caller's synchronisation on the step that ended this one).  navigation_graph with all envs
+ * in lockstep: the fmarl_step call that ends an episode commits the staged episode and emits its first observation in the same
+ * launch (step_end_kernel) instead of launching a commit and an emission kernel behind a step that emits nothing.  Results are
  * identical to the synchronous path.  Leave it off when capturing steps into a hipGraph (the side-stream
  * work outlives the call): fmarl_step refuses a capturing stream on a handle that has it. */
 #define FMARL_FLAG_ASYNC_RESET 1
