@@ -32,7 +32,7 @@ class FmarlConfig(C.Structure):
                 ('flags', C.c_int32), ('world_size', C.c_double), ('max_speed', C.c_double),
                 ('collision_rew', C.c_double), ('goal_rew', C.c_double), ('min_dist_thresh', C.c_double),
                 ('fair_rew', C.c_double), ('zeroshift', C.c_double), ('max_edge_dist', C.c_double), ('min_obs_dist', C.c_double),
-                ('seed', C.c_uint64)]
+                ('seed', C.c_uint64), ('envs_per_workgroup', C.c_int32), ('reserved0', C.c_int32)]
 
 
 class FmarlOutputs(C.Structure):
@@ -44,6 +44,7 @@ _SIGS = {
     'fmarl_create': (C.c_int, [C.POINTER(FmarlConfig), C.POINTER(C.c_void_p)]),
     'fmarl_destroy': (C.c_int, [C.c_void_p]),
     'fmarl_last_error': (C.c_char_p, []),
+    'fmarl_envs_per_workgroup': (C.c_int, [C.c_void_p]),
     'fmarl_state_bytes': (C.c_size_t, [C.POINTER(FmarlConfig)]),
     'fmarl_state_field': (C.c_int, [C.POINTER(FmarlConfig), C.c_int, C.POINTER(C.c_size_t),
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),

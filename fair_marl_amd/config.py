@@ -66,7 +66,7 @@ class EnvConfig:
             return 7
         return {'navigation_graph': 11, 'fair_graph_formation': 12}.get(self.scenario_name, 13)
 
-    def to_c(self, n_envs, seed=0, env_offset=0, async_reset=False):
+    def to_c(self, n_envs, seed=0, env_offset=0, async_reset=False, envs_per_workgroup=0):
         c = _lib.FmarlConfig()
         c.flags = (_lib.FLAG_ASYNC_RESET if async_reset else 0) | (_lib.FLAG_GLOBAL_FEATURES if self.graph_feat_type == 'global' else 0)
         c.scenario = _lib.SCENARIOS[self.scenario_name]
@@ -83,4 +83,5 @@ class EnvConfig:
         c.zeroshift, c.max_edge_dist = float(self.zeroshift), float(self.max_edge_dist)
         c.min_obs_dist = float(self.min_obs_dist)
         c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        c.envs_per_workgroup = int(envs_per_workgroup)
         return c

@@ -61,6 +61,7 @@ bool config_ok(const FmarlConfig *c, const char **why) {
     if (c->num_walls < 0 || c->num_walls > 2) { *why = "num_walls must be 0..2"; return false; }
     if (form && c->num_walls != 2) { *why = "fair_graph_formation always has 2 walls"; return false; }
     if (c->episode_length < 1) { *why = "episode_length < 1"; return false; }
+    if (c->envs_per_workgroup < 0 || c->reserved0 != 0) { *why = "envs_per_workgroup < 0 or reserved0 != 0 (zero-initialise FmarlConfig)"; return false; }
     if ((c->flags & FMARL_FLAG_GLOBAL_FEATURES) && (form || fnav || c->num_walls != 0)) {
         *why = "global node features: navigation_graph without walls only (the reference's _get_entity_feat_global knows no walls)";
         return false;
@@ -343,8 +344,12 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.epw = epw;
         epb = (kThreads / 64) * epw;
     }
-    // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
-    if ((p.n_envs + epb - 1) / epb < 512) { int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb); }
+    if (cfg->envs_per_workgroup > 0) {   // the caller's geometry (parity tests at the full-batch shape on a few envs)
+        if (cfg->envs_per_workgroup < epb) epb = cfg->envs_per_workgroup;
+    } else if ((p.n_envs + epb - 1) / epb < 512) {
+        // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
+        int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb);
+    }
 #ifdef FMARL_MEASURE
     if (const char *e = getenv("FMARL_EPB")) { const int v = atoi(e); if (v >= 1 && v <= epb) epb = v; }   // envs per workgroup (experiments)
 #endif
@@ -440,6 +445,11 @@ int fmarl_destroy(void *handle) {
     }
     delete h;
     return FMARL_OK;
+}
+
+int fmarl_envs_per_workgroup(void *handle) {
+    Handle *h = (Handle *)handle;
+    return h ? h->base.epb : 0;
 }
 
 int fmarl_profile_enable(void *handle, int capacity) {

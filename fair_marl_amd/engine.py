@@ -25,7 +25,7 @@ class OutputSet(object):
 
 class RolloutEngine:
     def __init__(self, cfg, n_envs, device='cuda:0', seed=0, env_offset=0, emit_info=True, async_reset=True,
-                 emit_graph=True, tune_placement=None, count_edges=False, emit_graph_record=False):
+                 emit_graph=True, tune_placement=None, count_edges=False, emit_graph_record=False, envs_per_workgroup=0):
         if not isinstance(cfg, EnvConfig):
             cfg = EnvConfig.from_args(cfg)
         cfg.validate()
@@ -39,7 +39,8 @@ class RolloutEngine:
             self.device = torch.device('cuda', torch.cuda.current_device())
         # async_reset: stage the next episode (placement + fair assignment) on a side stream while the
         # current one runs; same results, the reset leaves the critical path (see include/fmarl.h)
-        self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset, async_reset=async_reset)
+        # envs_per_workgroup: launch geometry override (0 = the library's choice); results never depend on it
+        self.c = cfg.to_c(n_envs, seed=seed, env_offset=env_offset, async_reset=async_reset, envs_per_workgroup=envs_per_workgroup)
         self.handle = C.c_void_p()
         with torch.cuda.device(self.device):   # the handle's side stream, events and kernel attributes belong to THIS device
             _lib.check(self.lib.fmarl_create(C.byref(self.c), C.byref(self.handle)), 'fmarl_create')
@@ -210,6 +211,11 @@ class RolloutEngine:
                     stage_obstacle_pos=(n, O, 2), stage_wall_axis=(n, W), stage_wall_orient=(n, W),
                     stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,), place_fails=(n,), stage_place_fails=(n,),
                     internal_match_dual=(n, N))
+
+    @property
+    def envs_per_workgroup(self):
+        """Envs per workgroup of this engine's step launches (FmarlConfig.envs_per_workgroup or the library's choice)."""
+        return int(self.lib.fmarl_envs_per_workgroup(self.handle))
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

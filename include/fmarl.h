@@ -72,6 +72,12 @@ typedef struct FmarlConfig {
     double max_edge_dist;
     double min_obs_dist;     /* FAIRNAV only (onpolicy/config.py:188) */
     uint64_t seed;           /* Philox key; env e, episode k draw from counter (i, env_offset+e, k, TAG) */
+    int32_t envs_per_workgroup; /* launch geometry: 0 = the library's choice (as many envs per 256-thread workgroup as LDS
+                                 * allows, fewer for batches too small to fill the chip otherwise); k > 0 = at most k, whatever
+                                 * the batch size (fair_graph_formation: rounded up to a multiple of 4, one env per wave at
+                                 * least).  Results never depend on it -- the parity tests run every fixture at 1, 2 and the
+                                 * full-batch geometry; fmarl_envs_per_workgroup() reports what a handle uses. */
+    int32_t reserved0;       /* 0 */
 } FmarlConfig;
 
 /* Output buffers of one step / reset, all caller-owned device memory, float32 unless noted.
@@ -169,6 +175,8 @@ enum {
 int fmarl_create(const FmarlConfig *cfg, void **handle);
 int fmarl_destroy(void *handle);
 const char *fmarl_last_error(void);
+/* Envs per workgroup of the handle's step / reset-emission launches (see FmarlConfig.envs_per_workgroup). */
+int fmarl_envs_per_workgroup(void *handle);
 
 /* Size and layout of the state buffer for cfg (0 / FMARL_EINVAL on a bad config). */
 size_t fmarl_state_bytes(const FmarlConfig *cfg);

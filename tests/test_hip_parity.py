@@ -31,6 +31,42 @@ def oracle_state_dict(st):
     return d
 
 
+# Launch geometry (FmarlConfig.envs_per_workgroup): 0 = the library's choice, which for the few envs of a fixture is ONE env per
+# workgroup; 2; 'full' = as many envs per workgroup as a 65 536-env batch gets (what bench.py times).  Results must not depend
+# on it, so every fixture runs at all three, its envs tiled until they fill more than two full-size workgroups plus a ragged one.
+GEOM = [0, 2, 'full']
+
+
+def geom_hint(geom, cfg=None):
+    if geom != 'full':
+        return int(geom)
+    # what a 65 536-env engine of this config runs at (LDS budget, and >= 512 workgroups for the chip)
+    return fm.RolloutEngine(cfg, 65536, device=DEV, emit_graph=False, emit_info=False, tune_placement=0).envs_per_workgroup
+
+
+def tile_reps(geom, n, N):
+    """How often the n envs of a fixture are repeated for this geometry (odd on purpose: fixture env j lands on different
+    positions inside the workgroups)."""
+    if geom != 'full':
+        return 3
+    reps = -(-int(2.3 * (256 // N) + 1) // n)
+    return reps + (reps % 2 == 0)
+
+
+def tiled(x, reps):
+    x = np.asarray(x)
+    return np.concatenate([x] * reps, axis=0) if reps > 1 else x
+
+
+def assert_geometry(eng, geom, N, form=False):
+    epb = eng.envs_per_workgroup
+    if geom == 'full':
+        assert epb == geom_hint(geom, eng.cfg) and epb > 1, epb   # the geometry of the benchmarked batch
+        assert eng.n_envs > 2 * epb
+    elif geom:
+        assert epb == (4 if form else geom)   # formation: one env per wave at least
+
+
 def check_outputs(got, want, msg=''):
     obs, ids, node, adj, rew, done, info = got
     np.testing.assert_allclose(obs.cpu().numpy(), want['obs'], err_msg=msg + ' obs', **OUT)
@@ -51,23 +87,26 @@ def check_state(eng, st, msg=''):
         np.testing.assert_allclose(got[k], getattr(st, k), err_msg=msg + ' state ' + k, **STATE)
 
 
+@pytest.mark.parametrize('geom', GEOM)
 @pytest.mark.parametrize('name', TRAJ)
-def test_golden_trajectory(name):
-    """Reference outputs (fixtures) vs HIP on the same initial state + action tape."""
+def test_golden_trajectory(name, geom):
+    """Reference outputs (fixtures) vs HIP on the same initial state + action tape, at every launch geometry."""
     fx = load(name)
     ocfg = cfg_of(fx)
     st = state_from(fx, ocfg)
-    n = st.agent_pos.shape[0]
-    eng = fm.RolloutEngine(env_cfg(ocfg), n, device=DEV)
-    eng.set_state(oracle_state_dict(st))
+    n0 = st.agent_pos.shape[0]
+    reps = tile_reps(geom, n0, ocfg.N)
+    eng = fm.RolloutEngine(env_cfg(ocfg), n0 * reps, device=DEV, envs_per_workgroup=geom_hint(geom, env_cfg(ocfg)))
+    assert_geometry(eng, geom, ocfg.N)
+    eng.set_state({k: tiled(v, reps) for k, v in oracle_state_dict(st).items()})
     for t in range(fx['actions'].shape[0]):
-        got = eng.step(fx['actions'][t], auto_reset=False)
-        want = {k: fx[k][t] for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
+        got = eng.step(tiled(fx['actions'][t], reps), auto_reset=False)
+        want = {k: tiled(fx[k][t], reps) for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
         check_outputs(got, want, '%s step %d' % (name, t))
     final = eng.get_state()
     for k in no.State.FIELDS:
         if k != 'time':
-            np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
+            np.testing.assert_allclose(final[k], tiled(fx['final_' + k], reps), err_msg=k, **STATE)
 
 
 @pytest.mark.parametrize('N,O,W,n,feat', [(3, 3, 0, 300, 'relative'), (32, 8, 0, 64, 'relative'), (10, 3, 2, 100, 'relative'),
@@ -1072,22 +1111,25 @@ def form_state_dict(st):
     return {k: getattr(st, k) for k in fo.State.FIELDS if k != 'time'}
 
 
+@pytest.mark.parametrize('geom', GEOM)
 @pytest.mark.parametrize('name', FORM)
-def test_formation_golden_trajectory(name):
+def test_formation_golden_trajectory(name, geom):
     fx = load(name)
     ocfg = form_cfg_of(fx)
     st = form_state_from(fx, ocfg)
-    n = st.agent_pos.shape[0]
-    eng = fm.RolloutEngine(form_env_cfg(ocfg), n, device=DEV)
-    eng.set_state(form_state_dict(st))
+    n0 = st.agent_pos.shape[0]
+    reps = tile_reps(geom, n0, ocfg.N)
+    eng = fm.RolloutEngine(form_env_cfg(ocfg), n0 * reps, device=DEV, envs_per_workgroup=geom_hint(geom, form_env_cfg(ocfg)))
+    assert_geometry(eng, geom, ocfg.N, form=True)
+    eng.set_state({k: tiled(v, reps) for k, v in form_state_dict(st).items()})
     for t in range(fx['actions'].shape[0]):
-        got = eng.step(fx['actions'][t], auto_reset=False)
-        want = {k: fx[k][t] for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
+        got = eng.step(tiled(fx['actions'][t], reps), auto_reset=False)
+        want = {k: tiled(fx[k][t], reps) for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
         check_form_outputs(got, want, '%s step %d' % (name, t))
     final = eng.get_state()
     for k in fo.State.FIELDS:
         if k != 'time':
-            np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
+            np.testing.assert_allclose(final[k], tiled(fx['final_' + k], reps), err_msg=k, **STATE)
 
 
 @pytest.mark.parametrize('N,L,O,thr,n', [(10, 1, 3, 0.05, 120), (3, 1, 3, 0.05, 200), (6, 2, 2, 0.45, 64), (24, 1, 4, 0.05, 9),
@@ -1184,22 +1226,25 @@ def fnav_env_cfg(ocfg):
     return fm.EnvConfig(**{k: getattr(ocfg, k) for k in fm.EnvConfig.__dataclass_fields__ if hasattr(ocfg, k)})
 
 
+@pytest.mark.parametrize('geom', GEOM)
 @pytest.mark.parametrize('name', FNAV)
-def test_fairnav_golden_trajectory(name):
+def test_fairnav_golden_trajectory(name, geom):
     fx = load(name)
     ocfg = fnav_cfg_of(fx)
     st = fnav_state_from(fx, ocfg)
-    n = st.agent_pos.shape[0]
-    eng = fm.RolloutEngine(fnav_env_cfg(ocfg), n, device=DEV)
-    eng.set_state({k: getattr(st, k) for k in fnv.State.FIELDS if k != 'time'})
+    n0 = st.agent_pos.shape[0]
+    reps = tile_reps(geom, n0, ocfg.N)
+    eng = fm.RolloutEngine(fnav_env_cfg(ocfg), n0 * reps, device=DEV, envs_per_workgroup=geom_hint(geom, fnav_env_cfg(ocfg)))
+    assert_geometry(eng, geom, ocfg.N)
+    eng.set_state({k: tiled(getattr(st, k), reps) for k in fnv.State.FIELDS if k != 'time'})
     for t in range(fx['actions'].shape[0]):
-        got = eng.step(fx['actions'][t], auto_reset=False)
-        want = {k: fx[k][t] for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
+        got = eng.step(tiled(fx['actions'][t], reps), auto_reset=False)
+        want = {k: tiled(fx[k][t], reps) for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info')}
         check_outputs(got, want, '%s step %d' % (name, t))
     final = eng.get_state()
     for k in fnv.State.FIELDS:
         if k != 'time':
-            np.testing.assert_allclose(final[k], fx['final_' + k], err_msg=k, **STATE)
+            np.testing.assert_allclose(final[k], tiled(fx['final_' + k], reps), err_msg=k, **STATE)
 
 
 def test_fairnav_assignment_with_tied_costs_follows_the_total_order():

@@ -24,12 +24,17 @@ def engine_of(fx, **kw):
     return fm.RolloutEngine(cfg, n, device=DEV, seed=int(fx['seed']), **kw), cfg, args, n
 
 
+@pytest.mark.parametrize('geom', [0, 2, 'full'])
 @pytest.mark.parametrize('name', RUNNER)
-def test_engine_equals_the_reference_on_the_philox_stream(name):
+def test_engine_equals_the_reference_on_the_philox_stream(name, geom):
     """No state injection anywhere: device resets (placement, assignment, reset observation) and steps against the
-    reference's own outputs through every auto-reset of the run."""
+    reference's own outputs through every auto-reset of the run -- at one env per workgroup (the library's choice for so
+    few envs), two, and all of the fixture's envs inside one workgroup of the full-batch shape (the staged episode's commit
+    and re-emission at env positions > 0, fairnav envs ending at different steps inside one workgroup)."""
     fx = load(name)
-    eng, cfg, args, n = engine_of(fx, count_edges=True)
+    eng, cfg, args, n = engine_of(fx, count_edges=True, envs_per_workgroup=4096 if geom == 'full' else geom)
+    if geom == 'full':
+        assert eng.envs_per_workgroup >= min(n, 8)
     obs, ids, node, adj = eng.reset()
     # f-3 fused: buffer slot s of episode ep holds the output of step ep * T + s - 1 (slot 0 of episode 0: the reset)
     T = cfg.episode_length
