@@ -34,25 +34,29 @@ from fair_marl_amd.sharding import StepRecord, TrajectoryGather  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
-CONFIGS = {
+CONFIGS = {   # workload: a format string, filled with the number of envs the run really uses (--n-envs)
     # BASELINE.json configs[2] (and configs[4] per GPU): the configuration the target is quoted on
-    'cfg3': dict(workload='navigation_graph, 32 agents + 8 obstacles (E=72), 65536 envs per GPU',
+    'cfg3': dict(workload='navigation_graph, 32 agents + 8 obstacles (E=72), %d envs per GPU',
                  env=dict(num_agents=32, num_landmarks=32, num_obstacles=8), n_envs=65536, cpu_envs=32, cpu_episodes=12),
     # BASELINE.json configs[3]
-    'cfg4': dict(workload='fair_graph_formation, 10 agents + 1 landmark + 3 obstacles + 2 walls (E=16), 65536 envs per GPU',
+    'cfg4': dict(workload='fair_graph_formation, 10 agents + 1 landmark + 3 obstacles + 2 walls (E=16), %d envs per GPU',
                  env=dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3),
                  n_envs=65536, cpu_envs=16, cpu_episodes=12),
     # the shipped FA+FR weights' configuration (model_weights/FA+FR/config.yaml)
-    'fnav': dict(workload='nav_fairassign_fairrew_formation_graph, 3 agents + 3 obstacles (E=9), 65536 envs per GPU',
+    'fnav': dict(workload='nav_fairassign_fairrew_formation_graph, 3 agents + 3 obstacles (E=9), %d envs per GPU',
                  env=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3,
                           num_obstacles=3, goal_rew=30.0, collision_rew=30.0), n_envs=65536, cpu_envs=32, cpu_episodes=4),
     # the reference's own experiment scale (10 agents): odd E, so the generic (row-per-lane) emission path
-    'n10': dict(workload='navigation_graph, 10 agents + 3 obstacles (E=23), 65536 envs per GPU',
+    'n10': dict(workload='navigation_graph, 10 agents + 3 obstacles (E=23), %d envs per GPU',
                 env=dict(num_agents=10, num_landmarks=10, num_obstacles=3), n_envs=65536, cpu_envs=64, cpu_episodes=3),
     # BASELINE.json configs[1]
-    'cfg2': dict(workload='navigation_graph, 3 agents + 3 obstacles (E=9), 4096 envs per GPU',
+    'cfg2': dict(workload='navigation_graph, 3 agents + 3 obstacles (E=9), %d envs per GPU',
                  env=dict(num_agents=3, num_landmarks=3, num_obstacles=3), n_envs=4096, cpu_envs=512, cpu_episodes=20),
 }
+KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}
+# every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
+# engines) and reported under `secondary`: (config, launch mode)
+SECONDARY = (('cfg2', 'eager'), ('cfg2', 'graph'), ('cfg4', 'eager'), ('fnav', 'eager'), ('n10', 'eager'))
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
@@ -76,6 +80,89 @@ def algorithmic_bytes(cfg, emit=True):
     if emit:
         words += cfg.obs_dim + cfg.node_feat * E + E * E / N + C / N
     return 4.0 * words
+
+
+def store_ceiling_ms(eng, launches=10):
+    """What the emission alone costs on THIS box and THESE buffers: the pure emission kernel (fmarl_rebuild_graph: writes
+    node_obs + adj of every env from obs + the episode record, touches no env state) timed on the engine's own output
+    buffers.  The step kernel cannot be faster than its own store stream; kernel_avg_ms against this figure separates the
+    kernel from the box (HBM write rates differ by 10 % between boxes).  navigation_graph only (the two
+    formation scenarios rebuild from a per-step record the engine does not write by default); call it after the timed region,
+    it overwrites node_obs / adj."""
+    if eng.cfg.scenario_name != 'navigation_graph' or eng.node_obs is None:
+        return None
+    rec = eng.pack_episode()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        eng.rebuild_graph(eng.obs, rec, node_obs=eng.node_obs, adj_env=eng.adj_env)
+    e0.record()
+    for _ in range(launches):
+        eng.rebuild_graph(eng.obs, rec, node_obs=eng.node_obs, adj_env=eng.adj_env)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / launches
+
+
+def launch_bytes(cfg, agents, counts0, counts1):
+    """Mean algorithmic bytes per step-kernel launch between two fmarl_launch_counts readings: a launch emits the full outputs
+    unless it is an episode-ending step whose reset observation is written by separate reset launches (counts[2])."""
+    launches = counts1[0] - counts0[0]
+    quiet = counts1[2] - counts0[2] if cfg.scenario_name != 'nav_fairassign_fairrew_formation_graph' else 0
+    return agents * (algorithmic_bytes(cfg) * (launches - quiet) + algorithmic_bytes(cfg, emit=False) * quiet) / max(1, launches)
+
+
+def secondary_line(name, mode, device, steps=300, warmup=50):
+    """One more BASELINE config on this GPU: fresh engine, `warmup` untimed steps (one episode end), `steps` timed steps
+    (whole episodes), synchronised on both sides.  mode 'graph' = RolloutEngine.rollout replaying one hipGraph per episode."""
+    spec = CONFIGS[name]
+    cfg = fm.EnvConfig(**spec['env'])
+    n = spec['n_envs']
+    ep = cfg.episode_length
+    steps, warmup = max(ep, steps // ep * ep), (warmup + ep - 1) // ep * ep
+    eng = fm.RolloutEngine(cfg, n, device=device, seed=1, tune_placement=0)
+    g = torch.Generator(device=device)
+    g.manual_seed(2000)
+    tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
+    eng.reset()
+    use_graph = mode == 'graph'
+    c0 = eng.launch_counts()
+    if use_graph:   # the per-kernel hipEvents cannot live inside a graph: kernel time from an eager pass over two episodes
+        eng.profile_enable(2 * ep)
+        for _ in range(2):
+            eng.rollout(tape, use_graph=False)
+        torch.cuda.synchronize(device)
+        kernel_ms = eng.profile_read()
+        c1 = eng.launch_counts()
+        eng.profile_enable(0)
+    for _ in range(warmup // ep):
+        eng.rollout(tape, use_graph=use_graph)
+    torch.cuda.synchronize(device)
+    if not use_graph:
+        eng.profile_enable(steps)
+        c0 = eng.launch_counts()
+    t0 = time.perf_counter()
+    for _ in range(steps // ep):
+        eng.rollout(tape, use_graph=use_graph)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if not use_graph:
+        kernel_ms = eng.profile_read()
+        c1 = eng.launch_counts()
+    k_avg = float(np.mean(kernel_ms))
+    per_launch = launch_bytes(cfg, n * cfg.N, c0, c1)
+    ceil_ms = store_ceiling_ms(eng)
+    folded = c1[1] - c0[1] > 0
+    out = dict(config=name, workload=spec['workload'] % n, launch=('one hipGraph replay per episode (kernel_avg_ms from an eager pass)'
+                                                                 if use_graph else 'one fmarl_step call per step'),
+               value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup, ms_per_step=elapsed / steps * 1e3,
+               kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel'),
+               kernel_avg_ms=k_avg, frac=per_launch / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               algorithmic_bytes_per_launch=per_launch, store_ceiling_ms=ceil_ms,
+               frac_of_box_ceiling=(ceil_ms / k_avg if ceil_ms else None))
+    eng.close()
+    del eng, tape
+    torch.cuda.empty_cache()
+    return out
 
 
 def _cpu_worker(job):
@@ -141,12 +228,17 @@ def main():
     ap.add_argument('--no-tune-placement', action='store_true', help='keep the first allocation of node_obs / adj instead of '
                     'the fastest pair of a few (RolloutEngine tune_placement)')
     ap.add_argument('--graph', action='store_true', help='N=1: capture one episode of steps in a hipGraph and replay it '
-                    '(launch-bound small batches, e.g. --config cfg2; implies --sync-reset; --steps is rounded to whole episodes)')
+                    '(launch-bound small batches, e.g. --config cfg2; --steps is rounded to whole episodes; with the staged reset the side stream '
+                    'is a forked branch of the graph)')
     ap.add_argument('--pipeline', type=int, default=1, help='step the env batch as this many sub-batches on their own streams '
                     '(fair_marl_amd.PipelinedRollout: the tail of one sub-batch\'s step kernel overlaps the head of the next one\'s); '
                     'no trajectory gather in this mode')
     ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
                     'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
+    ap.add_argument('--no-secondary', action='store_true', help='N=1: skip the other BASELINE configs after the headline region')
+    ap.add_argument('--learner-rebuild', type=int, default=0, metavar='K', help='rank 0 rebuilds node_obs / adj of K ranks\' gathered '
+                    'step (fmarl_rebuild_graph) inside the timed loop -- what a learner has to do with what arrives, since node_obs / '
+                    'adj never travel; reported separately in the line (needs the gather: N > 1, --record-path or --rccl-selftest)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
                          'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
@@ -203,10 +295,10 @@ def main():
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
+    workload = spec['workload'] % n_envs
     if args.graph:
         if world > 1:
             raise SystemExit('bench.py: --graph is a single-GPU mode')
-        args.sync_reset = True
         ep_len = cfg.episode_length
         K, W = max(ep_len, K // ep_len * ep_len), (W + ep_len - 1) // ep_len * ep_len   # whole episodes
     gather = (world > 1 or args.record_path) and not args.no_gather
@@ -229,7 +321,17 @@ def main():
     episodes = True
     tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
                           episode_words=eng.episode_record_words if episodes else 0,
-                          graph_words=eng.step_record_words if eng.emit_graph_record else 0) if gather else None
+                          graph_words=eng.step_record_words if eng.emit_graph_record else 0, timing=True) if gather else None
+    # --learner-rebuild K: the learner rank turns K ranks' gathered step back into node_obs / adj inside the timed loop
+    rebuild_ranks, rebuild_events, lr_node, lr_adj = [], [], None, None
+    if args.learner_rebuild:
+        if not gather:
+            raise SystemExit('bench.py: --learner-rebuild needs the trajectory gather (N > 1, --record-path or --rccl-selftest)')
+        if rank == 0:
+            peers = list(range(1, world)) + [0]          # the peers first; this rank's own record if K asks for more
+            rebuild_ranks = peers[:max(1, min(args.learner_rebuild, world))]
+            lr_node = torch.empty(n_envs, cfg.N, cfg.E, cfg.node_feat, dtype=torch.float32, device=device)
+            lr_adj = torch.empty(n_envs, cfg.E, cfg.E, dtype=torch.float32, device=device)
     if gather:
         sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done, graph_record=r.graph) for r in tg.records]
     else:
@@ -257,6 +359,17 @@ def main():
                 if inject_error and t == 1 and rank == world - 1:
                     raise RuntimeError('injected gather error (FMARL_BENCH_INJECT_GATHER_ERROR)')
                 tg.submit(t)
+                if rebuild_ranks and t > first:
+                    # step t - 1 has arrived (or is awaited here) while step t is in flight; its episode record is the latest
+                    # one submitted -- this step's, if it started an episode, goes out below
+                    got, graphs, epi = tg.gathered(t - 1), tg.gathered_graph(t - 1), tg.gathered_episode()
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record()
+                    for r in rebuild_ranks:
+                        eng.rebuild_graph(got[r][0], epi[r], node_obs=lr_node, adj_env=lr_adj,
+                                          step_record=graphs[r] if eng.emit_graph_record else None)
+                    eb.record()
+                    rebuild_events.append((ea, eb))
                 if episodes and eng.episode_started:   # same steps on every rank (lockstep episodes)
                     eng.pack_episode(out=tg.episode_record())
                     tg.submit_episode()
@@ -273,10 +386,12 @@ def main():
         tape_len = cfg.episode_length
         tape = tape[:tape_len].contiguous()
         eng.profile_enable(2 * tape_len)
+        c_before_eager = eng.launch_counts()
         run(0, 2 * tape_len)
         torch.cuda.synchronize(device)
         kernel_ms_eager = eng.profile_read()
         eng.profile_enable(0)
+        counts_eager = (c_before_eager, eng.launch_counts())
         episode_graph = eng.capture_steps(tape, lockstep=True)   # whole episodes from phase 0: one reset per episode in the graph
 
         def run(first, count):   # noqa: F811 -- whole episodes, one launch each
@@ -292,17 +407,33 @@ def main():
     if not args.graph:
         for e in (pipe.engines if pipe is not None else [eng]):
             e.profile_enable(K)
+    if tg is not None:   # the warm-up's waits do not count
+        tg.host_wait_s, tg.waits = 0.0, 0
+        tg.stream_wait_ms()
+    rebuild_events.clear()
+    counts0 = eng.launch_counts()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     run(W, K)
     torch.cuda.synchronize(device)
+    own_elapsed = time.perf_counter() - t0   # this rank's own K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    counts1 = eng.launch_counts()
     ranks_seen = 1
+    per_rank = None
+    if dist.is_initialized():   # one row per rank: [own ms per step, host ms blocked in gather waits, stream ms stalled in them]
+        row = torch.tensor([own_elapsed / K * 1e3, (tg.host_wait_s if tg else 0.0) / K * 1e3,
+                            (tg.stream_wait_ms() if tg else 0.0) / K], dtype=torch.float64, device=device)
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        per_rank = torch.stack(rows).cpu().numpy()
+    elif tg is not None:
+        per_rank = np.array([[own_elapsed / K * 1e3, tg.host_wait_s / K * 1e3, tg.stream_wait_ms() / K]])
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -322,30 +453,38 @@ def main():
 
     if rank == 0:
         agents = n_envs * cfg.N
-        # dominant kernel = step_kernel.  Launches on episode-end steps do not emit obs/node_obs/adj
-        # (the reset path does), so their algorithmic bytes are the state + reward part only.
+        # dominant kernel = the step kernel.  A launch on an episode-end step whose reset observation is written by separate
+        # reset launches emits nothing itself (state + reward bytes only); with the staged reset of navigation_graph the launch
+        # that ends an episode also commits the next one and emits its first observation (step_end_kernel), so every launch
+        # writes the full outputs.  Which of the two happened is read from the library's launch counters, not assumed.
         ep = cfg.episode_length
         resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
-        # navigation_graph with the staged reset: the launch that ends an episode also commits the next one and emits its first
-        # observation (step_end_kernel), so every launch writes the full outputs
-        folded = cfg.scenario_name == 'navigation_graph' and not args.sync_reset and not args.graph
-        quiet = 0 if folded else resets   # launches that do not emit
-        bytes_per_step = agents * (algorithmic_bytes(cfg) * (K - quiet) + algorithmic_bytes(cfg, emit=False) * quiet) / K
-        bytes_per_launch = bytes_per_step / max(1, args.pipeline)   # a launch steps one sub-batch
+        ca, cb = counts_eager if args.graph else (counts0, counts1)
+        if pipe is not None:
+            ca = (0, 0, 0, 0)   # sub-batch engines: their totals since creation
+            cb = tuple(sum(e.launch_counts()[i] for e in pipe.engines) for i in range(4))
+            bytes_per_launch = launch_bytes(cfg, agents // args.pipeline, ca, cb)   # (includes the warm-up's launches: same mix)
+        else:
+            bytes_per_launch = launch_bytes(cfg, agents, ca, cb)
+        folded = cb[1] - ca[1]
+        bytes_per_step = bytes_per_launch * max(1, args.pipeline)
         k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath) and pipe is None:   # (the committed counters are per launch over ALL envs)
+        if os.path.exists(tpath) and pipe is None:   # (the committed counters are per launch over ALL envs of the profiled run)
             with open(tpath) as f:
-                traffic = json.load(f).get(args.config, {}).get('hbm_bytes_per_launch')
+                entry = json.load(f).get(args.config, {})
+            if entry.get('n_envs', spec['n_envs']) == n_envs:
+                traffic = entry.get('hbm_bytes_per_launch')
+        ceiling_ms = store_ceiling_ms(eng) if pipe is None else None
         out = {
             'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), %s random-action rollout' % cfg.scenario_name,
             'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'n_ranks_seen': ranks_seen,
             'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': spec['workload'], 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
+            'config': {'workload': workload, 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
                        'launch': ('one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed '
@@ -353,7 +492,8 @@ def main():
                                   ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
                                    % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step')),
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
-                                 else 'next episode staged on a side stream, committed and observed by the launch that ends the episode'),
+                                 else 'next episode staged on a side stream, committed and observed by the launch that ends the episode'
+                                      ' (%d of %d episode ends folded)' % (folded, cb[1] - ca[1] + cb[2] - ca[2])),
                        'output_placement': ('fastest (node_obs, adj) allocation pair of %d x %d, emission-only launch ms %.3f '
                                             '(first allocations %.3f, slowest pair %.3f)'
                                             % (len(eng.placement_ms), len(eng.placement_ms[0]), min(map(min, eng.placement_ms)),
@@ -368,8 +508,12 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier '
                                             'run of this command, replayed here, not measured in this run') if traffic is not None else None,
-                         'kernel': {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}.get(cfg.scenario_name, 'step_kernel'),
+                         'kernel': KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel'),
                          'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),
+                         # the emission alone (node_obs + adj of every env, no env state) on the same buffers of the same box:
+                         # what this box's store stream allows; frac_of_box_ceiling = that time / the step kernel's
+                         'store_ceiling_ms': ceiling_ms,
+                         'frac_of_box_ceiling': (ceiling_ms / k_avg_ms if ceiling_ms else None),
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
         }
@@ -380,10 +524,43 @@ def main():
             out['roofline']['overlap'] = {'sub_batches': args.pipeline, 'job_achieved': job, 'job_frac': job / HBM_PEAK_GBS,
                                           'basis': 'algorithmic bytes per step of all envs / timed region per step; '
                                                    'kernel_avg_ms is the duration of ONE sub-batch launch while others run'}
+        if per_rank is not None:
+            # one run must explain itself: every rank's own time per step, what it waited for the exchange, what the learner
+            # rank receives and what it costs to turn that back into node_obs / adj
+            rec_bytes = tg.records[0].flat.numel() if tg is not None else 0
+            recv_bytes = rec_bytes * (world - 1)
+            out['multi_gpu'] = {
+                'per_rank_ms_per_step': [float(v) for v in per_rank[:, 0]],
+                'gather_wait_ms': {'host_blocked_per_step': [float(v) for v in per_rank[:, 1]],
+                                   'stream_stalled_per_step': [float(v) for v in per_rank[:, 2]],
+                                   'note': 'time inside TrajectoryGather waits (record / finish / episode_record): an RCCL wait '
+                                           'stalls the compute stream, a gloo wait blocks the host'},
+                'bytes_gathered_per_step': rec_bytes * world, 'bytes_received_by_rank0_per_step': recv_bytes,
+                'rank0_receive_GBps': recv_bytes / (elapsed / K) / 1e9,
+                'episode_record_bytes_per_rank': 4 * eng.episode_record_words * n_envs if episodes else 0}
+            if rebuild_ranks:
+                torch.cuda.synchronize(device)
+                ms = [a.elapsed_time(b) for a, b in rebuild_events]
+                out['multi_gpu']['learner_rebuild'] = {
+                    'ranks_rebuilt_per_step': rebuild_ranks, 'steps_rebuilt': len(ms),
+                    'ms_per_step': float(np.mean(ms)) if ms else None,
+                    'agent_steps_rebuilt_per_s': (len(rebuild_ranks) * agents / (np.mean(ms) * 1e-3)) if ms else None,
+                    'note': 'rank 0 rebuilds node_obs / adj of these ranks\' gathered step (fmarl_rebuild_graph) inside the timed loop, '
+                            'on the same stream as its own step kernels; the reference ships node_obs / adj instead '
+                            '(onpolicy/envs/env_wrappers.py:983-996)'}
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if args.config in REFERENCE_CPU:
             out['reference_cpu'] = REFERENCE_CPU[args.config]
+        if world == 1 and not args.no_secondary and pipe is None and not (args.graph or args.record_path or args.n_envs):
+            eng.close()
+            del eng, tape
+            if sets:
+                sets.clear()
+            torch.cuda.empty_cache()
+            t_sec = time.perf_counter()
+            out['secondary'] = [secondary_line(name, mode, device) for name, mode in SECONDARY if not (name == args.config and mode == 'eager')]
+            out['secondary_wall_s'] = time.perf_counter() - t_sec
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():

@@ -129,9 +129,12 @@ struct Handle {
     bool stage_pending; // a reset has consumed the staged episode; the next one is staged by the next fmarl_step call
     hipStream_t side;
     hipEvent_t ev_commit, ev_staged;
+    unsigned long long cap_id;        // id of the stream capture the current call runs in (0 = not capturing)
+    unsigned long long cap_stage_id;  // capture in which the staging of the next episode was last enqueued (0 = eagerly)
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int ev_cap, ev_n;
+    int64_t counts[4];  // fmarl_launch_counts
 };
 
 // Entry points that take a handle run on the handle's device whatever the caller's current device is
@@ -184,12 +187,19 @@ void launch_place(Handle *h, const Params &p, int mode, const uint8_t *mask, hip
 
 // Stage the next episode of every env without valid staged data: placement + fair assignment into the
 // staging fields, on the side stream, ordered after everything `st` has done so far.
+//
+// Inside a stream capture (FMARL_RESET_LOCKSTEP graphs) the same calls make the side stream a forked branch of the caller's
+// graph: the event recorded on the capturing stream pulls `side` into the capture, the staging kernels become nodes beside
+// the step kernels of the episode, and the episode-ending launch joins the branch through ev_staged.  A graph must not rely
+// on what the host knew about the staged data when it was captured, so a captured staging always clears the validity flags
+// first and leaves the host's own `stage_dirty` as it was (nothing ran).
 int launch_stage(Handle *h, void *state, hipStream_t st) {
     HIP_OK(hipEventRecord(h->ev_commit, st));
     HIP_OK(hipStreamWaitEvent(h->side, h->ev_commit, 0));
     Params p = bind(h, state);
-    if (h->stage_dirty) HIP_OK(hipMemsetAsync(p.stage_valid, 0, (size_t)p.n_envs * sizeof(int), h->side));
-    h->stage_dirty = false;
+    if (h->stage_dirty || h->cap_id) HIP_OK(hipMemsetAsync(p.stage_valid, 0, (size_t)p.n_envs * sizeof(int), h->side));
+    if (!h->cap_id) h->stage_dirty = false;
+    h->cap_stage_id = h->cap_id;
     Params q = p;   // same kernels, pointers bound to the staging fields
     q.agent_pos = p.st_agent_pos; q.landmark_pos = p.st_landmark_pos; q.obstacle_pos = p.st_obstacle_pos;
     q.wall_axis = p.st_wall_axis; q.wall_orient = p.st_wall_orient; q.goal_match = p.st_goal_match;
@@ -199,6 +209,7 @@ int launch_stage(Handle *h, void *state, hipStream_t st) {
     hipLaunchKernelGGL(stage_finish_kernel, dim3((p.n_envs + 255) / 256), dim3(256), 0, h->side, p);
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(h->ev_staged, h->side));
+    ++h->counts[3];
     return FMARL_OK;
 }
 
@@ -210,7 +221,10 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
         int rc = launch_stage(h, state, st);
         if (rc) return rc;
     }
-    const bool staged = h->async && !h->stage_dirty && mode != kResetInit;
+    if (h->async && h->cap_id && h->cap_stage_id != h->cap_id)
+        return fail(FMARL_EINVAL, "reset inside a stream capture: the staging of this episode is not part of the capture "
+                                  "(capture whole episodes, starting with the first step after a reset)");
+    const bool staged = h->async && (h->cap_id ? true : !h->stage_dirty) && mode != kResetInit;
     if (h->async) HIP_OK(hipStreamWaitEvent(st, h->ev_staged, 0));   // staging in flight must finish first
     if (staged) {   // commit the episode staged on the side stream
         hipLaunchKernelGGL(reset_commit_kernel, dim3(h->grid), dim3(kThreads), 0, st, p, mode, mask);
@@ -412,6 +426,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     h->stage_dirty = true;   // nothing staged yet
     h->stage_pending = false;
     h->side = nullptr; h->ev_commit = h->ev_staged = nullptr;
+    h->cap_id = h->cap_stage_id = 0;
     if (h->async) {
         int prio_lo = 0, prio_hi = 0;   // lowest priority: staging only fills what the step kernels leave idle
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -424,6 +439,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     }
     h->lockstep = false; h->host_step = 0; h->episode_started = false; h->captured = false;
     h->ev = nullptr; h->ev_cap = h->ev_n = 0;
+    memset(h->counts, 0, sizeof h->counts);
     *handle = h;
     return FMARL_OK;
 }
@@ -450,6 +466,13 @@ int fmarl_destroy(void *handle) {
 int fmarl_envs_per_workgroup(void *handle) {
     Handle *h = (Handle *)handle;
     return h ? h->base.epb : 0;
+}
+
+int fmarl_launch_counts(void *handle, int64_t *counts) {
+    Handle *h = (Handle *)handle;
+    if (!h || !counts) return fail(FMARL_EINVAL, "fmarl_launch_counts: null argument");
+    memcpy(counts, h->counts, sizeof h->counts);
+    return FMARL_OK;
 }
 
 int fmarl_profile_enable(void *handle, int capacity) {
@@ -481,6 +504,7 @@ int fmarl_init_state(void *handle, void *state, void *stream) {
     DeviceGuard on_device(h);
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_init_state: null argument");
     hipStream_t st = (hipStream_t)stream;
+    h->cap_id = 0;
     HIP_OK(hipMemsetAsync(state, 0, h->layout.total, st));
     int rc = launch_reset(h, state, kResetInit, nullptr, nullptr, st);
     if (rc == FMARL_OK && h->async && h->cfg.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH) {
@@ -504,6 +528,12 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask, const FmarlO
     DeviceGuard on_device(h);
     if (!h || !state) return fail(FMARL_EINVAL, "fmarl_reset: null argument");
     if (outs && !outputs_aligned(h->base, outs)) return fail(FMARL_EINVAL, "fmarl_reset: node_obs / adj must be 16-byte aligned for this shape");
+    h->cap_id = 0;
+    if (h->async) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(FMARL_EINVAL, "fmarl_reset: not capturable on a handle with FMARL_FLAG_ASYNC_RESET (reset first, capture the steps)");
+    }
     int rc = launch_reset(h, state, env_mask ? kResetMask : kResetAll, env_mask, outs, (hipStream_t)stream);
     if (env_mask || h->captured || h->cfg.scenario == FMARL_SCENARIO_FAIRNAV) h->lockstep = false; else { h->lockstep = true; h->host_step = 0; }
     h->episode_started = true;
@@ -521,18 +551,25 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     Params p = bind(h, state);
     if (!outputs_aligned(p, outs)) return fail(FMARL_EINVAL, "fmarl_step: node_obs / adj must be 16-byte aligned for this shape");
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-        // the staging stream and its events are not part of the caller's graph
-        if (h->async) return fail(FMARL_EINVAL, "fmarl_step: stream capture needs a handle created without FMARL_FLAG_ASYNC_RESET");
+    unsigned long long cap_id = 0;
+    h->cap_id = 0;
+    if (hipStreamGetCaptureInfo(st, &cs, &cap_id) == hipSuccess && cs != hipStreamCaptureStatusNone) {
         if (auto_reset == FMARL_RESET_LOCKSTEP) {
-            // the caller vouches for the replay phase (include/fmarl.h): decide from the host mirror like an eager step
+            // the caller vouches for the replay phase (include/fmarl.h): decide from the host mirror like an eager step.
+            // With the staged reset the side stream becomes a forked branch of the graph (launch_stage).
             if (!h->lockstep) return fail(FMARL_EINVAL, "fmarl_step: FMARL_RESET_LOCKSTEP capture needs envs in lockstep (fmarl_get_phase() >= 0)");
+            h->cap_id = cap_id ? cap_id : 1;
+            if (h->async && !h->stage_pending && h->cap_stage_id != h->cap_id)
+                return fail(FMARL_EINVAL, "fmarl_step: capture a handle with FMARL_FLAG_ASYNC_RESET from the first step after a reset "
+                                          "(the staging of the next episode must be part of the graph)");
         } else {
             // Nothing runs during capture and a replay can start at any phase of an episode, any number of times: the
             // reset-or-not decision must not be baked from the host's mirror of the step counter.  Every captured step
-            // enqueues the auto-reset launches, which test cur_step per env on the device.
+            // enqueues the auto-reset launches, which test cur_step per env on the device.  Those are the synchronous
+            // reset's launches: a handle with the staged reset becomes a synchronous one from here on (same results).
             h->captured = true;
             h->lockstep = false;
+            if (h->async) { h->async = false; h->stage_pending = false; h->stage_dirty = true; }
         }
     }
     if (h->stage_pending) {   // first step after a reset: stage the episode after this one on the side stream
@@ -542,10 +579,11 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     }
     // navigation_graph, envs in lockstep, the step that ends the episode, the next episode staged: one launch does the step,
     // the commit and the reset observation (step_end_kernel) instead of step + reset_commit + reset_emit
-    const bool fold = auto_reset && p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH && h->async && !h->stage_dirty && h->lockstep &&
+    const bool fold = auto_reset && p.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH && h->async && (h->cap_id ? h->cap_stage_id == h->cap_id : !h->stage_dirty) && h->lockstep &&
                       h->host_step + 1 >= h->cfg.episode_length && (outs->obs || outs->node_obs || outs->adj);
+    // (a captured step reaches this point only with the staging of this capture in place: the test above)
     if (fold) HIP_OK(hipStreamWaitEvent(st, h->ev_staged, 0));   // the staged episode must be complete
-    const bool prof = h->ev && h->ev_n < h->ev_cap;
+    const bool prof = h->ev && h->ev_n < h->ev_cap && !h->cap_id && cs == hipStreamCaptureStatusNone;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     if (p.scenario == FMARL_SCENARIO_FAIRNAV)
         hipLaunchKernelGGL(fairnav_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
@@ -560,6 +598,8 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
                            auto_reset ? 1 : 0);
     if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
     HIP_OK(hipGetLastError());
+    ++h->counts[0];
+    if (fold) ++h->counts[1];
     if (h->lockstep) ++h->host_step;
     h->episode_started = false;
     if (auto_reset && p.scenario == FMARL_SCENARIO_FAIRNAV) {
@@ -573,6 +613,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
         } else if (may_reset) {
             int rc = launch_reset(h, state, kResetAuto, nullptr, outs, st);
             if (rc) return rc;
+            ++h->counts[2];
             if (h->lockstep) h->host_step = 0;
             h->episode_started = true;
         }

@@ -522,22 +522,36 @@ class RolloutEngine:
         with one launch.  For small batches the step kernel takes 10-20 us and the host-side launch path is the larger
         part of a step.  ``action_tape`` (T, n, N) int32 or (T, n, N, 5) float32 is read at replay time: refill it in place
         between replays.  Each step writes the engine's current output set, so a consumer that wants every step passes
-        per-step sets of a DeviceRolloutBuffer via ``outputs`` of ``capture_rollout``.  Needs the synchronous reset
-        (``async_reset=False``): the staged reset owns a side stream (refused by the library).
+        per-step sets of a DeviceRolloutBuffer via ``outputs`` of ``capture_rollout``.
 
-        By default every captured step carries the device-side auto-reset test, so the graph may hold any number of steps
-        and be replayed from any phase of an episode.  ``lockstep=True`` bakes the reset decision from the host's mirror of
-        the common step counter instead (one reset per episode in the graph instead of a test per step: BASELINE config 2,
-        20.5 -> 14.7 us per step); the returned object then refuses a replay from any other episode phase than the one it
-        was captured at."""
+        ``lockstep=True`` bakes the reset decision from the host's mirror of the common step counter (one reset per episode
+        in the graph instead of a test per step: BASELINE config 2, 20.5 -> 14.7 us per step); the returned object refuses a
+        replay from any other episode phase than the one it was captured at.  With the staged reset (``async_reset=True``,
+        the default) the staging of every next episode becomes a forked branch of the graph, beside the episode's step
+        kernels, joined by the launch that ends the episode; such a graph holds whole episodes and starts with the first
+        step after a reset.  ``lockstep=False`` (default): every captured step carries the device-side auto-reset test, so the
+        graph may hold any number of steps and be replayed from any phase of an episode -- these are the synchronous reset's
+        launches, and an engine with the staged reset becomes a synchronous one for good.  ``lockstep=None`` picks the lean
+        form whenever it is valid (envs in lockstep; with the staged reset also phase 0 and whole episodes)."""
         return self.capture_rollout(action_tape, None, auto_reset, lockstep)
+
+    def _lean_capture_ok(self, steps):
+        if self.phase < 0:
+            return False
+        staged_nav = bool(self.c.flags & _lib.FLAG_ASYNC_RESET) and self.cfg.scenario_name == 'navigation_graph'
+        return not staged_nav or (self.phase == 0 and steps % self.cfg.episode_length == 0)
 
     def capture_rollout(self, action_tape, outputs=None, auto_reset=True, lockstep=False):
         """As ``capture_steps``; step t writes ``outputs[t]`` (an OutputSet, e.g. a time slot of a rollout buffer)."""
         tape = action_tape.to(self.device)
         phase0 = self.phase
+        if lockstep is None:
+            lockstep = bool(auto_reset) and self._lean_capture_ok(int(tape.shape[0]))
         if lockstep and phase0 < 0:
             raise RuntimeError('lockstep capture needs all envs in lockstep: reset() them first (phase is -1)')
+        if lockstep and not self._lean_capture_ok(int(tape.shape[0])):
+            raise RuntimeError('lockstep capture with the staged reset holds whole episodes from the first step after a reset '
+                               '(phase %d, %d steps, episode_length %d)' % (phase0, tape.shape[0], self.cfg.episode_length))
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         mode = (2 if lockstep else 1) if auto_reset else 0
@@ -551,6 +565,28 @@ class RolloutEngine:
             return graph
         _lib.check(self.lib.fmarl_set_phase(self.handle, phase0), 'fmarl_set_phase')   # nothing ran during the capture
         return _LockstepGraph(self, graph, phase0, int(tape.shape[0]))
+
+    # a step kernel over fewer agents than this is shorter than the host-side launch path of one fmarl_step call
+    GRAPH_BELOW_AGENTS = 1 << 16
+
+    def rollout(self, action_tape, use_graph=None):
+        """Run ``len(action_tape)`` auto-resetting steps from a persistent device tape (T, n, N) int32: the random-action
+        rollout of the reference's throughput runs, or a scripted tape.  Launch-bound batches (``n_envs * N`` below
+        ``GRAPH_BELOW_AGENTS``) are replayed from a hipGraph captured on first use and cached per (tape storage, length,
+        output set) -- valid while the caller refills the same tensor in place; larger batches, or a phase / length the lean
+        capture does not cover, step eagerly.  Outputs of the last step are in the engine's current output set."""
+        T = int(action_tape.shape[0])
+        if use_graph is None:
+            use_graph = self.n_envs * self.cfg.N < self.GRAPH_BELOW_AGENTS
+        if use_graph and self._lean_capture_ok(T):
+            key = (action_tape.data_ptr(), T, id(self.outs), self.phase)
+            cache = self.__dict__.setdefault('_rollout_graphs', {})
+            if key not in cache:
+                cache[key] = self.capture_rollout(action_tape, None, True, True)
+            cache[key].replay()
+            return
+        for t in range(T):
+            self.step(action_tape[t], auto_reset=True)
 
     def poison_lds(self):
         """Test hook: fill every CU's LDS with 0xFF bytes (a kernel that reads an LDS table before writing it then fails
@@ -572,6 +608,12 @@ class RolloutEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.fmarl_profile_read(self.handle, buf, self._prof_cap, C.byref(cnt)), 'fmarl_profile_read')
         return [buf[i] for i in range(cnt.value)]
+
+    def launch_counts(self):
+        """(step launches, of which folded episode ends, steps followed by separate auto-reset launches, stagings) so far."""
+        buf = (C.c_int64 * 4)()
+        _lib.check(self.lib.fmarl_launch_counts(self.handle, buf), 'fmarl_launch_counts')
+        return tuple(int(v) for v in buf)
 
     def close(self):
         if getattr(self, 'handle', None) is not None and self.handle.value:

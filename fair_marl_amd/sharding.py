@@ -73,8 +73,14 @@ class TrajectoryGather(object):
     """
 
     def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0,
-                 force_collective=False, graph_words=0):
+                 force_collective=False, graph_words=0, timing=False):
         self.group, self.dst, self.depth = group, dst, depth
+        # timing: how long the rollout is held up by the exchange.  Two clocks, because an RCCL work's wait() only makes the
+        # current STREAM wait (the host returns at once) while a gloo work's wait() blocks the HOST: ``host_wait_s``
+        # accumulates the host time inside wait(), ``stream_wait_ms()`` the time the compute stream sat between an event
+        # recorded before the wait and one recorded after it (read it after a device synchronisation).
+        self.timing = bool(timing) and torch.device(device).type == 'cuda'
+        self.host_wait_s, self._wait_events, self.waits = 0.0, [], 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # force_collective: issue the gathers even in a group of ONE rank (the RCCL path on a one-GPU box)
@@ -91,10 +97,29 @@ class TrajectoryGather(object):
         if self.collective and self.rank == dst:
             self.ep_recv = [[torch.zeros_like(b) for _ in range(self.world)] for b in self.ep_send]
 
+    def _wait(self, work):
+        import time
+        self.waits += 1
+        if self.timing:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        t0 = time.perf_counter()
+        work.wait()
+        self.host_wait_s += time.perf_counter() - t0
+        if self.timing:
+            b.record()
+            self._wait_events.append((a, b))
+
+    def stream_wait_ms(self):
+        """Total time [ms] the compute stream spent inside the waits so far (synchronise the device first); restarts."""
+        total = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        self._wait_events = []
+        return total
+
     def record(self, t):
         k = t % self.depth
         if self.pending[k] is not None:
-            self.pending[k].wait()
+            self._wait(self.pending[k])
             self.pending[k] = None
         return self.records[k]
 
@@ -110,11 +135,11 @@ class TrajectoryGather(object):
     def finish(self):
         for k in range(self.depth):
             if self.pending[k] is not None:
-                self.pending[k].wait()
+                self._wait(self.pending[k])
                 self.pending[k] = None
         for k in range(2):
             if self.ep_pending[k] is not None:
-                self.ep_pending[k].wait()
+                self._wait(self.ep_pending[k])
                 self.ep_pending[k] = None
 
     # -- once per episode (every rank at the same steps: ``RolloutEngine.episode_started`` after reset / step)
@@ -123,7 +148,7 @@ class TrajectoryGather(object):
         ``submit_episode()``."""
         k = self.ep_count % 2
         if self.ep_pending[k] is not None:
-            self.ep_pending[k].wait()
+            self._wait(self.ep_pending[k])
             self.ep_pending[k] = None
         return self.ep_send[k]
 
@@ -134,9 +159,10 @@ class TrajectoryGather(object):
             self.ep_pending[k] = dist.gather(self.ep_send[k], self.ep_recv[k] if self.rank == self.dst else None,
                                              dst=self.dst, group=self.group, async_op=True)
 
-    def gathered_episode(self):
-        """On the learner rank: list over ranks of the most recently submitted episode record (n_envs, words)."""
-        k = (self.ep_count - 1) % 2
+    def gathered_episode(self, back=0):
+        """On the learner rank: list over ranks of the most recently submitted episode record (n_envs, words); ``back=1``:
+        the one before it (a step gathered just before an episode ended still belongs to that episode)."""
+        k = (self.ep_count - 1 - back) % 2
         if self.ep_pending[k] is not None:
             self.ep_pending[k].wait()
             self.ep_pending[k] = None

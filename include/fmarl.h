@@ -41,8 +41,11 @@ extern "C" {
  * would otherwise sit behind the caller's synchronisation on the step that ended this one).  navigation_graph with all envs
  * in lockstep: the fmarl_step call that ends an episode commits the staged episode and emits its first observation in the same
  * launch (step_end_kernel) instead of launching a commit and an emission kernel behind a step that emits nothing.  Results are
- * identical to the synchronous path.  Leave it off when capturing steps into a hipGraph (the side-stream
- * work outlives the call): fmarl_step refuses a capturing stream on a handle that has it. */
+ * identical to the synchronous path.  hipGraph capture (see fmarl_step): with FMARL_RESET_LOCKSTEP the side stream becomes a
+ * forked branch of the caller's graph -- capture whole episodes, starting with the first step after a reset, so that every
+ * staging is joined by the episode end inside the graph; with FMARL_RESET_AUTO the handle turns into a synchronous-reset
+ * handle for good (the device-checked resets of such a graph are the synchronous launches).  fmarl_reset itself is not
+ * capturable on such a handle. */
 #define FMARL_FLAG_ASYNC_RESET 1
 /* GLOBAL_FEATURES: --graph_feat_type global (navigation_graph.py:981-1009, 1058-1077): node_obs rows are the
  * 7 absolute columns [vel, pos, goal, type], identical for every ego agent (F = 7).  navigation_graph without
@@ -204,8 +207,8 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask,
  * auto_reset != 0 adds the vec-env worker's behaviour (env_wrappers.py:859-865): envs whose agents
  * are all done are reset and their obs / node_obs / adj are the reset observation while
  * reward / done / info stay those of the terminal step.
- * hipGraph capture: the call only enqueues work on `stream`, so a run of steps can be captured (handles without
- * FMARL_FLAG_ASYNC_RESET).  With auto_reset = FMARL_RESET_AUTO a captured step always enqueues the auto-reset launches,
+ * hipGraph capture: the call only enqueues work on `stream` (and, with FMARL_FLAG_ASYNC_RESET + FMARL_RESET_LOCKSTEP, on the
+ * handle's side stream forked from it and joined back), so a run of steps can be captured.  With auto_reset = FMARL_RESET_AUTO a captured step always enqueues the auto-reset launches,
  * which test every env's step counter on the device -- a graph may hold any number of steps and be replayed from any
  * phase of an episode; the handle stops mirroring the step counter on the host from then on.
  * auto_reset = FMARL_RESET_LOCKSTEP is the lean variant for launch-bound batches: while all envs share one step counter
@@ -240,6 +243,11 @@ int fmarl_state_changed(void *handle);
  * (0 = off); read() returns the per-launch durations [ms] recorded since then -- the caller
  * must have synchronised the stream -- and restarts. */
 int fmarl_profile_enable(void *handle, int capacity);
+/* What fmarl_step has enqueued on this handle so far (host-side counters, no device access): counts[0] step-kernel launches,
+ * counts[1] of those that also committed the staged episode and emitted its first observation (the folded episode end,
+ * FMARL_FLAG_ASYNC_RESET above), counts[2] step calls followed by separate auto-reset launches, counts[3] stagings of a next
+ * episode on the side stream.  bench.py derives the bytes a launch writes from these instead of from the configuration. */
+int fmarl_launch_counts(void *handle, int64_t *counts);
 int fmarl_profile_read(void *handle, float *ms, int max_count, int *count);
 
 /* Test hook (tests/test_hip_parity.py): fill the LDS of every CU with 0xFF bytes (one launch of workgroups that take

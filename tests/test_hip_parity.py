@@ -307,18 +307,34 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
         assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
 
 
-def test_bench_two_ranks_rehearsal():
+@pytest.mark.parametrize('world,extra', [(2, []), (4, ['--learner-rebuild', '2'])])
+def test_bench_multi_rank_rehearsal(world, extra):
     """bench.py's own multi-rank loop (record rotation, gathers inside the timed region, max over ranks, one JSON
-    line from rank 0) with two ranks sharing the GPU over gloo."""
+    line from rank 0) with two / four ranks sharing the GPU over gloo; the line of an N > 1 run explains itself: every
+    rank's own time per step, what each waited for the exchange, what rank 0 receives, and -- with --learner-rebuild --
+    what it costs rank 0 to turn two peers' gathered step back into node_obs / adj inside the timed loop."""
     import json
-    out = _run_ranks([os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--n-envs', '512',
-                      '--steps', '30', '--warmup', '5'])
+    out = _run_ranks([os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', str(world), '--backend', 'gloo', '--n-envs', '512',
+                      '--steps', '30', '--warmup', '5'] + extra, world=world)
     lines = [l for l in out.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out[-4000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
-    assert d['value'] == pytest.approx(2 * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
-    assert 'cpu_baseline' not in d and d['roofline']['kernel_launches'] == 30 and d['n_ranks_seen'] == 2
+    assert d['n_gpus'] == world and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
+    assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
+    assert 'cpu_baseline' not in d and d['roofline']['kernel_launches'] == 30 and d['n_ranks_seen'] == world
+    assert '512 envs per GPU' in d['config']['workload'] and d['roofline']['traffic'] is None   # --n-envs: no replayed 65 536-env counters
+    assert 'secondary' not in d
+    m = d['multi_gpu']
+    assert len(m['per_rank_ms_per_step']) == world and all(0 < v <= d['ms_per_step'] * 1.001 for v in m['per_rank_ms_per_step'])
+    assert len(m['gather_wait_ms']['host_blocked_per_step']) == world and len(m['gather_wait_ms']['stream_stalled_per_step']) == world
+    rec = 512 * 32 * 33   # obs 28 + reward 4 + done 1 bytes per agent-step
+    assert m['bytes_gathered_per_step'] == world * rec and m['bytes_received_by_rank0_per_step'] == (world - 1) * rec
+    assert m['rank0_receive_GBps'] == pytest.approx((world - 1) * rec / (d['ms_per_step'] * 1e-3) / 1e9, rel=1e-6)
+    if extra:
+        lr = m['learner_rebuild']
+        assert lr['ranks_rebuilt_per_step'] == [1, 2] and lr['steps_rebuilt'] == 29 and lr['ms_per_step'] > 0
+    else:
+        assert 'learner_rebuild' not in m
 
 
 def test_bench_exchange_through_rccl_with_one_rank():
@@ -336,8 +352,10 @@ def test_bench_exchange_through_rccl_with_one_rank():
     assert len(lines) == 1, res.stdout[-4000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1 and d['config']['exchange'].startswith('RCCL (process group of one rank')
-    assert d['roofline']['traffic_source'] is None or 'replayed' in d['roofline']['traffic_source']
+    assert d['roofline']['traffic'] is None and d['roofline']['traffic_source'] is None and '2048 envs' in d['config']['workload']
     assert d['reference_cpu']['value'] == 1662.0
+    assert d['multi_gpu']['bytes_received_by_rank0_per_step'] == 0 and d['multi_gpu']['bytes_gathered_per_step'] == 2048 * 32 * 33
+    assert d['roofline']['store_ceiling_ms'] > 0 and 0 < d['roofline']['frac_of_box_ceiling'] < 1.2
 
 
 def test_bench_fails_loudly_when_the_exchange_cannot_run():
@@ -691,14 +709,29 @@ def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
         for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
             assert torch.equal(getattr(eager, k), getattr(graph, k)), 'episode %d %s' % (ep, k)
     assert int(eager.get_state()['episode'].min()) >= 3   # three auto-resets happened inside the replays
-    # the staged-reset mode owns a side stream and events: capturing it is refused, not silently mis-captured
+    # a handle with the staged reset captured this way (device-checked resets) turns into a synchronous one: same results
     staged = fm.RolloutEngine(cfg, n, device=DEV, seed=3, async_reset=True)
-    staged.reset()
+    eager = fm.RolloutEngine(cfg, n, device=DEV, seed=3, async_reset=False)
+    staged.reset(); eager.reset()
+    for t in range(3):   # some eager steps first: a staging is in flight / done when the capture begins
+        staged.step(tape[t]); eager.step(tape[t])
     torch.cuda.synchronize()
     g2 = torch.cuda.CUDAGraph()
-    with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='FMARL_FLAG_ASYNC_RESET'):
-        with torch.cuda.graph(g2):
-            staged.step(tape[0])
+    with torch.cuda.graph(g2):
+        for t in range(T):
+            staged.step(tape[t])
+    for ep in range(2):
+        g2.replay()
+        for t in range(T):
+            eager.step(tape[t])
+        torch.cuda.synchronize()
+        sa, sb = eager.get_state(), staged.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), 'staged handle, replay %d %s' % (ep, k)
+        assert torch.equal(eager.node_obs, staged.node_obs) and torch.equal(eager.obs, staged.obs)
+    for t in range(T + 2):   # and eager steps afterwards
+        ra, rb = eager.step(tape[t % T]), staged.step(tape[t % T])
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[2], rb[2]) and torch.equal(ra[5], rb[5]), t
 
 
 def test_capture_rollout_fills_the_rollout_buffer_from_one_graph():
@@ -723,17 +756,72 @@ def test_capture_rollout_fills_the_rollout_buffer_from_one_graph():
         for name in ('obs', 'node_obs', 'adj_env', 'rewards', 'dones'):
             assert torch.equal(getattr(buf_a, name), getattr(buf_b, name)), 'episode %d %s' % (ep, name)
         buf_a.after_update(); buf_b.after_update()
-    # capture_steps: same thing into the engine's current output set; the staged reset is refused
+    # capture_steps: same thing into the engine's current output set
     g2 = b.capture_steps(tape)
     g2.replay()
     for t in range(T):
         a.step(tape[t])
     torch.cuda.synchronize()
     assert torch.equal(a.obs, b.obs) and torch.equal(a.node_obs, b.node_obs)
-    staged = fm.RolloutEngine(cfg, n, device=DEV, seed=4, async_reset=True)
-    staged.reset()
-    with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='FMARL_FLAG_ASYNC_RESET'):
-        staged.capture_steps(tape)
+
+
+@pytest.mark.parametrize('N,O,W,n,T', [(3, 3, 0, 257, 25), (5, 2, 1, 64, 8), (32, 8, 0, 20, 6)])
+def test_staged_reset_is_captured_as_a_forked_branch(N, O, W, n, T):
+    """Lean (lockstep) capture on an engine with the staged reset -- the default engine: the placement + fair assignment of
+    the next episode run on the library's side stream, which the capture pulls in as a forked branch beside the episode's
+    step kernels; the launch that ends the episode joins it, commits and re-emits (step_end_kernel).  Two whole episodes
+    per graph; replays with fresh actions, eager steps in between, all bit-identical to an eager engine; captures that
+    could not join their staging are refused."""
+    cfg = fm.EnvConfig(num_agents=N, num_landmarks=N, num_obstacles=O, num_walls=W, episode_length=T)
+    eager = fm.RolloutEngine(cfg, n, device=DEV, seed=9, async_reset=True)
+    graph = fm.RolloutEngine(cfg, n, device=DEV, seed=9, async_reset=True)
+    gen = torch.Generator(device=DEV); gen.manual_seed(12)
+    tape = torch.randint(0, 5, (2 * T, n, N), device=DEV, generator=gen, dtype=torch.int32)
+    eager.reset(); graph.reset()
+    counts0 = graph.launch_counts()
+    g = graph.capture_steps(tape, lockstep=True)
+    c = graph.launch_counts()
+    assert c[0] - counts0[0] == 2 * T and c[1] - counts0[1] == 2 and c[2] == counts0[2] and c[3] - counts0[3] == 2   # two folded ends, two stagings, no separate reset
+    assert graph.phase == 0
+
+    def same(msg):
+        torch.cuda.synchronize()
+        sa, sb = eager.get_state(), graph.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), '%s state %s' % (msg, k)
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done', 'info'):
+            assert torch.equal(getattr(eager, k), getattr(graph, k)), '%s %s' % (msg, k)
+    for rep in range(3):
+        tape.copy_(torch.randint(0, 5, (2 * T, n, N), device=DEV, generator=gen, dtype=torch.int32))
+        g.replay()
+        for t in range(2 * T):
+            eager.step(tape[t])
+        same('replay %d' % rep)
+        assert graph.phase == 0
+        if rep == 1:   # a whole eager episode between replays (its own staging, eagerly)
+            for t in range(T):
+                a = torch.randint(0, 5, (n, N), device=DEV, generator=gen, dtype=torch.int32)
+                eager.step(a); graph.step(a)
+            same('eager episode')
+    assert int(eager.get_state()['episode'].min()) >= 2 + 7
+    # RolloutEngine.rollout: launch-bound batches replay a cached graph, others step eagerly -- same results
+    for rep in range(2):
+        tape.copy_(torch.randint(0, 5, (2 * T, n, N), device=DEV, generator=gen, dtype=torch.int32))
+        graph.rollout(tape)
+        eager.rollout(tape, use_graph=False)
+        same('rollout %d' % rep)
+    assert len(graph._rollout_graphs) == (1 if n * N < graph.GRAPH_BELOW_AGENTS else 0)
+    # refused: not from the first step after a reset / not whole episodes (their staging could not be joined inside the graph)
+    graph.step(tape[0]); eager.step(tape[0])
+    with pytest.raises(RuntimeError, match='whole episodes'):
+        graph.capture_steps(tape, lockstep=True)
+    with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='first step after a reset'):
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3):
+            graph.step(tape[1], auto_reset=2)
+    for t in range(1, T + 1):
+        ra, rb = eager.step(tape[t]), graph.step(tape[t])
+    same('after the refused captures')
 
 
 def test_graph_of_any_length_replays_across_episode_ends():

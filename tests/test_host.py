@@ -158,11 +158,11 @@ def test_shard_range_partitions_exactly():
         assert max(sizes) - min(sizes) <= 1
 
 
-def _gather_worker(rank, world, port, q):
+def _gather_worker(rank, world, port, q, n_total=12, N=3, D=7):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from fair_marl_amd.sharding import TrajectoryGather, shard_range
-    n_total, N, D, T = 12, 3, 7, 5
+    T = 5
     lo, hi = shard_range(n_total, world, rank)
     tg = TrajectoryGather(hi - lo, N, D, 'cpu', dst=0, depth=2, episode_words=4, graph_words=9)
     ok = True
@@ -172,7 +172,7 @@ def _gather_worker(rank, world, port, q):
             tg.submit_episode()
         rec = tg.record(t)                       # waits for the gather that used this buffer (t - 2)
         env = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
-        rec.obs.copy_((env * 100 + t).expand(hi - lo, N, D))
+        rec.obs.copy_((env + 0.25 * t).expand(hi - lo, N, D))   # (exact in float32 up to 2^19 envs)
         rec.reward.copy_((env[:, :, 0] + 0.5 * t).expand(hi - lo, N))
         rec.done.fill_(t % 2)
         rec.graph.copy_((torch.arange(lo, hi, dtype=torch.int32).view(-1, 1, 1) * 1000 + t).expand(hi - lo, N, 9))
@@ -182,11 +182,11 @@ def _gather_worker(rank, world, port, q):
                 for r, (obs, rew, done) in enumerate(tg.gathered(t - 1)):
                     l2, h2 = shard_range(n_total, world, r)
                     e = torch.arange(l2, h2, dtype=torch.float32)
-                    ok &= bool((obs[:, 0, 0] == e * 100 + (t - 1)).all()) and bool((rew[:, 1] == e + 0.5 * (t - 1)).all())
+                    ok &= bool((obs[:, 0, D - 1] == e + 0.25 * (t - 1)).all()) and bool((rew[:, N - 1] == e + 0.5 * (t - 1)).all())
                     ok &= bool((done == (t - 1) % 2).all()) and obs.shape == (h2 - l2, N, D)
                 for r, gr in enumerate(tg.gathered_graph(t - 1)):
                     l2, h2 = shard_range(n_total, world, r)
-                    ok &= gr.shape == (h2 - l2, N, 9) and bool((gr[:, 2, 8] == torch.arange(l2, h2, dtype=torch.int32) * 1000 + t - 1).all())
+                    ok &= gr.shape == (h2 - l2, N, 9) and bool((gr[:, N - 1, 8] == torch.arange(l2, h2, dtype=torch.int32) * 1000 + t - 1).all())
                 for r, ep in enumerate(tg.gathered_episode()):     # the record of the episode step t belongs to
                     l2, h2 = shard_range(n_total, world, r)
                     ok &= ep.shape == (h2 - l2, 4) and bool((ep[:, 3] == torch.arange(l2, h2, dtype=torch.int32) * 10 + t // 2).all())
@@ -207,6 +207,26 @@ def test_trajectory_gather_world_size_2_gloo():
     ok = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_trajectory_gather_world_size_8_with_the_layout_of_config_5():
+    """BASELINE config 5's partition: 524 288 envs over 8 ranks = shard_range(524288, 8, r), 65 536 contiguous envs each,
+    every step's record and every episode's record gathered to rank 0 and checked there against the GLOBAL env index
+    (gloo on the CPU; one agent with a one-float obs keeps eight ranks' buffers small -- the exchange code does not
+    depend on the row width)."""
+    from fair_marl_amd.sharding import shard_range
+    assert [shard_range(524288, 8, r) for r in (0, 1, 7)] == [(0, 65536), (65536, 131072), (458752, 524288)]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 8, port, q, 524288, 1, 1)) for r in range(8)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert ok
 
