@@ -4,14 +4,16 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'csrc', 'libfmarl.so')
+# FMARL_LIB: measurement aid (tools/mkvariant.sh, tools/abrun.sh) -- another build of the SAME sources / C-ABI, e.g. a
+# -DFMARL_MEASURE build or an experiment's variant, selected per process instead of overwriting the shipped library
+LIB_PATH = os.environ.get('FMARL_LIB') or os.path.join(HERE, 'csrc', 'libfmarl.so')
 
 INFO_WIDTH = 14
 (F_AGENT_POS, F_AGENT_VEL, F_P_DIST, F_LANDMARK_POS, F_OBSTACLE_POS, F_WALL_AXIS, F_WALL_E0, F_WALL_E1,
  F_WALL_ORIENT, F_WALL_LENGTH, F_GOAL_MATCH, F_DISTS_TO_GOAL, F_TIMES_REQUIRED, F_DIST_LEFT,
  F_NUM_OBST_COLL, F_NUM_AGENT_COLL, F_MIN_TIME, F_CUR_STEP, F_EPISODE, F_SLOT_POS, F_SLOT_OCC,
  F_SLOT_DELTA, F_FORMATION_DONE, F_GOAL_OCC, F_GOAL_HISTORY, F_GOAL_REACHED, F_STATUS, F_RESET_FLAG, F_STAGE_AGENT_POS, F_STAGE_LANDMARK_POS, F_STAGE_OBSTACLE_POS,
- F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, F_PLACE_FAILS, F_STAGE_PLACE_FAILS, F_MATCH_DUAL, NUM_FIELDS) = range(40)
+ F_STAGE_WALL_AXIS, F_STAGE_WALL_ORIENT, F_STAGE_GOAL_MATCH, F_STAGE_VALID, F_STAGE_NEED, F_PLACE_FAILS, F_STAGE_PLACE_FAILS, F_MATCH_DUAL, F_ROT_TABLE, NUM_FIELDS) = range(41)
 FLAG_ASYNC_RESET = 1
 FLAG_GLOBAL_FEATURES = 2
 FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos', 'wall_axis', 'wall_e0',
@@ -20,7 +22,7 @@ FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos
                'slot_pos', 'slot_occ', 'slot_delta', 'formation_done', 'goal_occ', 'goal_history', 'goal_reached', 'status',
                'reset_flag', 'stage_agent_pos',
                'stage_landmark_pos', 'stage_obstacle_pos', 'stage_wall_axis', 'stage_wall_orient', 'stage_goal_match',
-               'stage_valid', 'stage_need', 'place_fails', 'stage_place_fails', 'internal_match_dual')
+               'stage_valid', 'stage_need', 'place_fails', 'stage_place_fails', 'internal_match_dual', 'internal_rot_table')
 DTYPE_F64, DTYPE_I32 = 0, 1
 SCENARIOS = {'navigation_graph': 0, 'fair_graph_formation': 1, 'nav_fairassign_fairrew_formation_graph': 2}
 

@@ -72,8 +72,11 @@ struct Params {
     int stat_stride;   // statistics block of env el: LDS base + lds_stat + el * stat_stride (lds_env_bytes, or 5 N doubles when the blocks share the emission windows' region)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
     int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
+    int lds2_bytes, f_rows;   // second LDS region, lds_stage + el * lds2_bytes: tables dead once the emission starts (formation: lds_stat,
+                              // f_slot_old, f_theta, f_words; fairnav: lds_stat, n_D, n_minprox, n_occ, n_match, n_words) / formation: rows per window
     double2 *slot_pos;
     double *slot_occ, *slot_delta, *formation_done, *match_dual;
+    const double2 *rot_table;   // (cos, sin) of i * 2 pi / N, one table for all envs
     // fairnav scenario: extra per-env LDS tables (byte offsets), knob and state
     int n_D, n_minprox, n_occ, n_match, n_rows, n_words;
     double min_obs_dist;
@@ -149,6 +152,15 @@ __device__ __forceinline__ double log_1to2(double u) {
     q = fma(q, w, 1.0);
     const double r = 2.0 * s * q;
     return big ? r + 0.6931471805599453 : r;
+}
+
+// For values that only leave as float32 OUTPUTS (the fairness column of obs, reward, info planes): a quotient by a
+// reciprocal (an ulp or two off the correctly rounded division, 8 instructions instead of ~35) and tanh through one exp
+// (absolute error ~1e-16; the library's tanh is ~170 instructions).  Never used on state.
+__device__ __forceinline__ double ratio_out(double num, double den) { return num * rcp_nr(den); }
+__device__ __forceinline__ double tanh_out(double z) {
+    const double t = exp(-2.0 * fabs(z));   // (0, 1]
+    return copysign((1.0 - t) * rcp_nr(1.0 + t), z);
 }
 
 // np.logaddexp(0, z) * k -- reference core.py:391 / :439 (softplus penetration).

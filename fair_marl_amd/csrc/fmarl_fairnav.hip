@@ -25,25 +25,28 @@
 
 namespace fmarl {
 
-struct NavRow { int code; float occ, hist; int pad; };   // goal of an agent row: landmark index, -1 = own position
+struct NavRow { int code; float occ, hist; };   // goal of an agent row: landmark index, -1 = own position
 
 struct FairNavLds {
-    char *base;
+    char *base, *dead;   // the env's block / its part of the second region (tables nobody reads once the emission starts; the
+                         // emission windows alias that region)
     const Params &p;
-    __device__ FairNavLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
+    __device__ FairNavLds(const Params &p_, char *lds, uint32_t el)
+        : base(lds + (size_t)el * p_.lds_env_bytes), dead(lds + p_.lds_stage + (size_t)el * p_.lds2_bytes), p(p_) {}
+    __device__ double *stat() const { return (double *)(dead + p.lds_stat); }           // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
     __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
     __device__ float4 *agentf() const { return (float4 *)(base + p.lds_agentf); }   // (vx, vy, newly-stopped, -)
     __device__ float2 *posf() const { return (float2 *)(base + p.lds_posf); }       // (float)pos of every entity
     __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2)
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
-    __device__ double *D() const { return (double *)(base + p.n_D); }               // [N][L] |x_a - goal_g|
-    __device__ double *minprox() const { return (double *)(base + p.n_minprox); }   // [L] min_a |x_a - goal_g|
-    __device__ double *occ() const { return (double *)(base + p.n_occ); }           // [L] landmark_poses_occupied
-    __device__ double *hist() const { return (double *)(base + p.n_occ) + p.L; }    // [L] goal_history
-    __device__ int *match() const { return (int *)(base + p.n_match); }             // [N] goal_match_index (this step)
+    __device__ double *D() const { return (double *)(dead + p.n_D); }               // [N][L] |x_a - goal_g|
+    __device__ double *minprox() const { return (double *)(dead + p.n_minprox); }   // [L] min_a |x_a - goal_g|
+    __device__ double *occ() const { return (double *)(dead + p.n_occ); }           // [L] landmark_poses_occupied
+    __device__ double *hist() const { return (double *)(dead + p.n_occ) + p.L; }    // [L] goal_history
+    __device__ int *match() const { return (int *)(dead + p.n_match); }             // [N] goal_match_index (this step)
     __device__ NavRow *rows() const { return (NavRow *)(base + p.n_rows); }         // [N ego][N entity]
-    __device__ int *words() const { return (int *)(base + p.n_words); }             // a*, all-done, free-empty
+    __device__ int *words() const { return (int *)(dead + p.n_words); }             // a*, all-done, free-empty
     __device__ bool skip() const { return *flag() != 0; }
 
     // the 13 features of entity e in the row block of ego i (nf:1222-1334), ego part included:
@@ -278,7 +281,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     const int env = env0 + el;
     const size_t g = (size_t)env * N + i;
     const FairNavLds t(p, lds, el);
-    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
+    double *s_stat = t.stat();
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0, status = 0;
@@ -388,7 +391,6 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             else if (!free_empty) { r.code = best; r.occ = (float)t.occ()[best]; r.hist = (float)t.hist()[best]; }
             else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = (float)t.hist()[i]; }
             else { r.code = c; r.occ = 0.f; r.hist = (float)t.hist()[c]; }   // after the clear every goal is free
-            r.pad = 0;
             t.rows()[a * N + i] = r;
         }
         __syncthreads();
@@ -425,7 +427,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             double fairness, m, sd;   // nf:693-698, same stale / fresh rule as navigation_graph
             if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
             else mixed_stats(s_stat + 2 * N, s_stat + N, N, i, m, sd);
-            fairness = m / (sd + 0.0001);
+            fairness = ratio_out(m, sd + 0.0001);
             int ag_hits = 0;
             for (int j = 0; j < N; ++j)
                 if (j != i && closer_than(x, t.pos()[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
@@ -440,7 +442,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             else rew -= dgoal;
             rew -= p.collision_rew * ag_hits;
             if (ob_hit) rew -= p.collision_rew;
-            double fr = p.fair_rew * tanh(fairness - p.zeroshift);
+            double fr = p.fair_rew * tanh_out(fairness - p.zeroshift);
             if (fr < -p.fair_rew) fr = -p.fair_rew;
             rew = fmin(fmax(rew + fr, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
@@ -464,12 +466,12 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
                 inf[FMARL_INFO_NUM_OBST_COLLISIONS * plane] = (float)noc;
                 inf[FMARL_INFO_DISTANCE_MEAN * plane] = (float)dm;
                 inf[FMARL_INFO_DISTANCE_VARIANCE * plane] = (float)ds;
-                inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)(dm / (ds + 0.0001));
+                inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)ratio_out(dm, ds + 0.0001);
                 inf[FMARL_INFO_DISTS_TRAVELED * plane] = (float)Dg_new;
                 inf[FMARL_INFO_TIME_TAKEN * plane] = (float)Tr_new;   // nf:582: times_required again
                 inf[FMARL_INFO_TIME_MEAN * plane] = (float)tm;
                 inf[FMARL_INFO_TIME_STDDEV * plane] = (float)ts;
-                inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)(tm / (ts + 0.0001));
+                inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)ratio_out(tm, ts + 0.0001);
                 inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
                 inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
             }
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, Fma
         t.agentf()[i] = make_float4(__uint_as_float(r[2]), __uint_as_float(r[3]), __uint_as_float(r[4]), 0.f);
         for (int e = 0; e < N; ++e) {
             NavRow nr;
-            nr.code = (int)r[5 + 3 * e]; nr.occ = __uint_as_float(r[6 + 3 * e]); nr.hist = __uint_as_float(r[7 + 3 * e]); nr.pad = 0;
+            nr.code = (int)r[5 + 3 * e]; nr.occ = __uint_as_float(r[6 + 3 * e]); nr.hist = __uint_as_float(r[7 + 3 * e]);
             t.rows()[i * N + e] = nr;
         }
         if (i == 0) *t.flag() = 0;

@@ -98,16 +98,17 @@ __device__ __forceinline__ void hungarian_tasks(const Params &p, char *lds, int 
 
 // Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
 struct FormLds {
-    char *base;
+    char *base, *dead;   // the env's block / its part of the second region (tables nobody reads once the emission starts)
     const Params &p;
-    __device__ FormLds(const Params &p_, char *lds, uint32_t el) : base(lds + (size_t)el * p_.lds_env_bytes), p(p_) {}
+    __device__ FormLds(const Params &p_, char *lds, uint32_t el)
+        : base(lds + (size_t)el * p_.lds_env_bytes), dead(lds + p_.lds_stage + (size_t)el * p_.lds2_bytes), p(p_) {}
     __device__ double2 *pos() const { return (double2 *)(base + p.lds_pos); }
     __device__ float2 *velf() const { return (float2 *)(base + p.lds_agentf); }     // (vx, vy) in f32
     __device__ float2 *posf() const { return (float2 *)(base + p.lds_posf); }
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
-    __device__ double2 *slot_old() const { return (double2 *)(base + p.f_slot_old); }
+    __device__ double2 *slot_old() const { return (double2 *)(dead + p.f_slot_old); }
     // small per-agent indices as bytes (N <= 32): slot of the matching on the current / previous slots, nearest slot
     // within thr (-1: none), and at [3 N] the nearest previous slot of agent 0
     __device__ int8_t *g_new() const { return (int8_t *)(base + p.f_g); }
@@ -115,10 +116,11 @@ struct FormLds {
     __device__ int8_t *near_new() const { return (int8_t *)(base + p.f_g) + 2 * p.N; }
     __device__ int8_t *near_old0() const { return (int8_t *)(base + p.f_g) + 3 * p.N; }
     __device__ uint32_t *masks() const { return (uint32_t *)(base + p.f_masks); }   // [N][3]: b, flag, obs code
-    __device__ double *theta() const { return (double *)(base + p.f_theta); }
-    __device__ double *vdual() const { return (double *)(base + p.f_words); }   // column potentials the last matching left (state)
+    __device__ double *theta() const { return (double *)(dead + p.f_theta); }
+    __device__ double *vdual() const { return (double *)(dead + p.f_words); }   // column potentials the last matching left (state)
     __device__ uint32_t *words() const { return (uint32_t *)(base + p.lds_flag) + 1; }   // occ_old, occ_new, occ_final (behind the flag)
-    __device__ uint32_t *openmask() const { return (uint32_t *)(base + p.lds_stat + 2 * p.N * 8); }   // bit j: agent j has not arrived yet
+    __device__ double *stat() const { return (double *)(dead + p.lds_stat); }   // [pd_new | Dg_old] x N
+    __device__ uint32_t *openmask() const { return (uint32_t *)(dead + p.lds_stat + 2 * p.N * 8); }   // bit j: agent j has not arrived yet
     __device__ bool skip() const { return *flag() != 0; }
 
     // goal of agent entity e as seen in the graph row of ego i (ff:916-943)
@@ -126,7 +128,8 @@ struct FormLds {
         const int nr = near_new()[e];
         if (nr >= 0) return slot_new()[nr];
         if ((masks()[3 * i] >> e) & 1) return slot_new()[g_new()[i]];
-        return pos()[e];
+        const float2 pf = posf()[e];   // (its own position: the float32 rounding the row starts from)
+        return make_double2((double)pf.x, (double)pf.y);
     }
 };
 
@@ -167,42 +170,84 @@ __device__ __forceinline__ uint32_t branch_event(int near_e, int g_ego, uint32_t
 
 constexpr int kFormationRecordWords = 9;   // include/fmarl.h fmarl_step_record_words
 
+// One node_obs row (ff:896-971) of the wave's envs: row q = (env, ego a, entity e) -> F = 12 floats as three 16-byte chunks
+// [dv dx] [goal flag dx.x] [dx.y dx type]; the chunks share the position loads and the index math.
+__device__ __forceinline__ void formation_row(const Params &p, char *lds, int el0w, uint32_t q, float4 &c0, float4 &c1, float4 &c2) {
+    const uint32_t N = p.N, NE = N * p.E, first_wall = N + p.L + p.O;
+    const uint32_t e_l = p.dNE.div(q), r = q - e_l * NE;
+    const FormLds te(p, lds, el0w + e_l);
+    const uint32_t a = p.dE.div(r), e = r - a * p.E;
+    // differences of the f32 roundings (as navigation_graph's rows): within 1.2e-7 of the rounded f64 difference
+    const float2 vi = te.velf()[a], pi = te.posf()[a], pe = te.posf()[e];
+    const float dx = pe.x - pi.x, dy = pe.y - pi.y;
+    float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
+    if (e < N) {
+        const float2 ve = te.velf()[e];
+        vx = ve.x; vy = ve.y;
+        const double2 gl = te.graph_goal(a, e);
+        gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
+        fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
+    } else if (e >= first_wall) {
+        const double *wl = te.wall() + (e - first_wall) * 4;   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
+        const float4 wc = make_float4((float)wl[1], (float)(wl[0] + kWallWidth / 2), (float)wl[2], (float)(wl[0] - kWallWidth / 2));
+        t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
+    }
+    const float type = e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
+    c0 = make_float4(vx - vi.x, vy - vi.y, dx, dy);
+    c1 = make_float4(gx, gy, fl, t7);
+    c2 = make_float4(t8, t9, t10, type);
+}
+
+// `nrows` consecutive 48-byte rows (lane l holds row l as three chunks) to gdst through the wave's LDS window, so that global
+// memory sees contiguous 16-byte chunks -- 1 KiB per store instruction -- instead of 16 bytes per lane at a 48-byte stride
+// (three times the write requests for the same bytes).  The window is the wave's part of the second LDS region: its envs'
+// tables there are dead by now, and it is private to the wave (wave-local ordering).  The frame starts at the previous
+// 64-byte boundary of gdst (rows are 16-byte aligned, so the offset is whole chunks): lane quads then write whole blocks.
+__device__ __forceinline__ void formation_flush_rows(const Params &p, char *lds, float4 c0, float4 c1, float4 c2, uint32_t nrows,
+                                                     float4 *gdst) {
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *buf = (float4 *)(lds + p.lds_stage + wave * p.stage_wave_bytes);
+    const uint32_t shift = (uint32_t)(((uintptr_t)gdst >> 4) & 3), end = shift + 3 * nrows;
+    if (lane < nrows) { buf[shift + 3 * lane] = c0; buf[shift + 3 * lane + 1] = c1; buf[shift + 3 * lane + 2] = c2; }
+    wave_sync();
+    float4 *gal = gdst - shift;
+    // all LDS reads first, then the stores (at most 3 chunks per lane: 3 * 63 + 3 <= 192)
+    const bool in0 = lane >= shift && lane < end, in1 = lane + 64 < end, in2 = lane + 128 < end;
+    float4 v0 = make_float4(0, 0, 0, 0), v1 = v0, v2 = v0;
+    if (in0) v0 = buf[lane];
+    if (in1) v1 = buf[lane + 64];
+    if (in2) v2 = buf[lane + 128];
+    if (in0) gal[lane] = v0;
+    if (in1) gal[lane + 64] = v1;
+    if (in2) gal[lane + 128] = v2;
+    wave_sync();   // the next window's writes stay behind these reads
+}
+
 // node_obs rows of the envs [el0w, el0w + nenv_w) of the workgroup by one wave (ff:896-971): shared by the step / reset
 // kernels and the learner-side rebuild (formation_rebuild_kernel), which fills the same LDS tables from the records.
 __device__ __forceinline__ void formation_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int el0w,
                                                     int nenv_w, int lane) {
     const int N = p.N;
-    if (o.node_obs) {
-        // one lane per (ego, entity) row of F = 12 floats = three 16-byte stores: [dv dx] [goal flag dx.x] [dx.y dx type];
-        // the three chunks share the position loads and the index math; consecutive lanes write consecutive rows (ff:896-971)
-        // (each wave streams the rows of its own envs)
-        const uint32_t NE = N * p.E, total = nenv_w * NE, first_wall = N + p.L + p.O;
-        float4 *dst = (float4 *)(o.node_obs + ((size_t)env0 + el0w) * NE * 12);
+    if (!o.node_obs) return;
+    const uint32_t NE = N * p.E, total = nenv_w * NE;
+    float4 *dst = (float4 *)(o.node_obs + ((size_t)env0 + el0w) * NE * 12);
+    const bool some_skip = __ballot(lane < nenv_w && FormLds(p, lds, el0w + lane).skip()) != 0;
+    wave_sync();   // every lane is done with the tables of the second region: it becomes the wave's window
+    if (!some_skip && p.f_rows >= 8) {
+        const uint32_t R = p.f_rows;
+        for (uint32_t w0 = 0; w0 < total; w0 += R) {
+            const uint32_t nrows = min(R, total - w0);
+            float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0;
+            if ((uint32_t)lane < nrows) formation_row(p, lds, el0w, w0 + lane, c0, c1, c2);
+            formation_flush_rows(p, lds, c0, c1, c2, nrows, dst + (size_t)w0 * 3);
+        }
+    } else {   // some envs keep their previous rows (reset in flight): per-lane stores of the others
         for (uint32_t q = lane; q < total; q += 64) {
-            const uint32_t e_l = p.dNE.div(q), r = q - e_l * NE;
-            const FormLds te(p, lds, el0w + e_l);
-            if (te.skip()) continue;
-            const uint32_t a = p.dE.div(r), e = r - a * p.E;
-            // differences of the f32 roundings (as navigation_graph's rows): within 1.2e-7 of the rounded f64 difference
-            const float2 vi = te.velf()[a], pi = te.posf()[a], pe = te.posf()[e];
-            const float dx = pe.x - pi.x, dy = pe.y - pi.y;
-            float vx = 0.f, vy = 0.f, gx = dx, gy = dy, fl = 1.f, t7 = dx, t8 = dy, t9 = dx, t10 = dy;
-            if (e < (uint32_t)N) {
-                const float2 ve = te.velf()[e];
-                vx = ve.x; vy = ve.y;
-                const double2 gl = te.graph_goal(a, e);
-                gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
-                fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
-            } else if (e >= first_wall) {
-                const double *wl = te.wall() + (e - first_wall) * 4;   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
-                const float4 wc = make_float4((float)wl[1], (float)(wl[0] + kWallWidth / 2), (float)wl[2], (float)(wl[0] - kWallWidth / 2));
-                t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
-            }
-            const float type = e < (uint32_t)N ? 0.f : (e < (uint32_t)(N + p.L) ? 1.f : (e < first_wall ? 2.f : 3.f));
+            if (FormLds(p, lds, el0w + p.dNE.div(q)).skip()) continue;
+            float4 c0, c1, c2;
+            formation_row(p, lds, el0w, q, c0, c1, c2);
             float4 *d = dst + (size_t)q * 3;
-            d[0] = make_float4(vx - vi.x, vy - vi.y, dx, dy);
-            d[1] = make_float4(gx, gy, fl, t7);
-            d[2] = make_float4(t8, t9, t10, type);
+            d[0] = c0; d[1] = c1; d[2] = c2;
         }
     }
 }
@@ -220,7 +265,7 @@ __device__ __forceinline__ void travelled_stats(const double *pd, const double *
         const double d = ((j < split && ((open >> j) & 1u)) ? pd[j] : stale[j]) - mean;
         q += d * d;
     }
-    sd = sqrt(q / n);
+    sd = sqrt_pos(q / n);
 }
 
 // STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877)
@@ -244,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     const int env = env0 + el;
     const size_t g = (size_t)env * N + i;
     const FormLds t(p, lds, active ? el : 0);
-    double *s_stat = (double *)(t.base + p.lds_stat);   // [pd_new | Dg_old] x N, then the mask of agents still under way
+    double *s_stat = t.stat();   // [pd_new | Dg_old] x N, then the mask of agents still under way
     const uint32_t full = N >= 32 ? ~0u : ((1u << N) - 1);
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
@@ -255,11 +300,12 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     // memory round trip each (nine in a row at the head of every wave), and a load behind stores waits for those stores
     // (one vmcnt counter orders both on gfx9).
     double Dg_old = 0, Tr_old = 0, fdone = 0, socc = 0, mtime = 0, vd = 0;
-    double2 so = make_double2(0, 0);
+    double2 so = make_double2(0, 0), rot = make_double2(1, 0);
     int noc_old = 0, nac_old = 0, a_pre = -1, cs = 0, rf = 0;
     if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
         so = p.slot_pos[g];
+        if (STEP) rot = p.rot_table[i];
         vd = p.match_dual[g];
         socc = p.slot_occ[g];
         cs = p.cur_step[env];
@@ -273,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     }
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
     if (!STEP && !__syncthreads_or(active && rf != 0)) return;
-    load_statics(p, lds, env0, nenv);   // (its loads join the batch: nothing above has waited for a value yet)
+    load_statics_range(p, lds, env0, 0, nenv, tid, blockDim.x);   // (its loads join the batch: nothing above has waited for a value yet)
     if (active) {
         t.pos()[i] = x;
         t.slot_old()[i] = so;
@@ -295,12 +341,15 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
         t.pos()[i] = x;
         t.velf()[i] = make_float2((float)v.x, (float)v.y);
         t.posf()[i] = make_float2((float)x.x, (float)x.y);
-        double th = atan2(x.y - L0.y, x.x - L0.x);   // ff:35-40
-        if (th < 0) th += 2 * M_PI;
-        t.theta()[i] = th;
         if (STEP) {
+            // ff:35-40 find_angle = arctan2 wrapped to [0, 2 pi); only its ORDER over the agents is needed (the anchor of the ring
+            // is the agent with the smallest angle, ff:633-636): a monotone key without the arctangent -- quadrant + |dy| /
+            // (|dx| + |dy|).  Two agents whose angles agree to the last bits may swap: the ring then turns by that much.
+            const double dx = x.x - L0.x, dy = x.y - L0.y, ax = fabs(dx), ay = fabs(dy), sum = ax + ay;
+            const double frac = sum > 0.0 ? ay * rcp_nr(sum) : 0.0;
+            t.theta()[i] = dy >= 0.0 ? (dx > 0.0 || sum == 0.0 ? frac : 2.0 - frac) : (dx < 0.0 ? 2.0 + frac : 4.0 - frac);
             const bool open = Tr_old == -1.0;
-            const double fd = dist2(x, L0);   // ff:445-451 ring test
+            const double fd = sqrt_pos(dx * dx + dy * dy);   // ff:445-451 ring test
             const bool ring = fd < 1.05 * kTargetRadius && fd > 0.95 * kTargetRadius;
             if (ring) fdone = 1.0;
             Tr_new = (ring && open) ? step * kDt : Tr_old;
@@ -313,10 +362,17 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (active) {   // slots: ff:630-648 (step: inside reward(agent 0)); on reset they come from the state
         double2 P;
         if (STEP) {
-            double tmin = t.theta()[0];
-            for (int j = 1; j < N; ++j) tmin = fmin(tmin, t.theta()[j]);
-            const double ang = tmin + i * ((2 * M_PI) / N);
-            P = make_double2(L0.x + kTargetRadius * cos(ang), L0.y + kTargetRadius * sin(ang));
+            // slot i = landmark 0 + radius (cos, sin)(theta_min + i 2 pi / N): the anchor agent's own direction (dx, dy) / r
+            // is (cos, sin)(theta_min); turning it by the tabulated (cos, sin)(i 2 pi / N) needs no trigonometric call
+            double kmin = t.theta()[0];
+            int jmin = 0;
+            for (int j = 1; j < N; ++j) { const double kj = t.theta()[j]; if (kj < kmin) { kmin = kj; jmin = j; } }
+            const double2 xa = t.pos()[jmin];
+            const double dx = xa.x - L0.x, dy = xa.y - L0.y, r2 = dx * dx + dy * dy;
+            double inv_r = 0.0;
+            if (r2 > 0.0) (void)sqrt_inv_pos(r2, inv_r);
+            const double c0 = r2 > 0.0 ? dx * inv_r : 1.0, s0 = r2 > 0.0 ? dy * inv_r : 0.0;   // arctan2(0, 0) = 0
+            P = make_double2(L0.x + kTargetRadius * (c0 * rot.x - s0 * rot.y), L0.y + kTargetRadius * (s0 * rot.x + c0 * rot.y));
         } else {
             P = t.slot_old()[i];
         }
@@ -461,7 +517,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             double fairness, m, sd;   // ff:623-628, same stale/fresh rule as navigation_graph
             if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
             else travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i, m, sd);
-            fairness = m / (sd + 0.0001);
+            fairness = ratio_out(m, sd + 0.0001);
             int ag_hits = 0;
             for (int j = 0; j < N; ++j)
                 if (j != i && closer_than(x, t.pos()[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
@@ -474,7 +530,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
             double rew = delta < p.thr ? p.goal_rew : -delta;   // ff:668-699
             rew -= p.collision_rew * ag_hits;
             if (ob_hit) rew -= p.collision_rew;
-            rew += p.fair_rew * tanh(fairness - 5.0);
+            rew += p.fair_rew * tanh_out(fairness - 5.0);
             rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
             const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
@@ -496,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
                 inf[FMARL_INFO_NUM_OBST_COLLISIONS * plane] = (float)noc;
                 inf[FMARL_INFO_DISTANCE_MEAN * plane] = (float)dm;
                 inf[FMARL_INFO_DISTANCE_VARIANCE * plane] = (float)ds;
-                inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)(dm / (ds + 0.0001));
+                inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)ratio_out(dm, ds + 0.0001);
                 inf[FMARL_INFO_DISTS_TRAVELED * plane] = (float)Dg_new;
                 inf[FMARL_INFO_TIME_TAKEN * plane] = 0.f;                      // never updated by this scenario
                 inf[FMARL_INFO_FORMATION_DIST * plane] = (float)fdone;          // 'Formation_dist' (ff:495)
@@ -540,14 +596,14 @@ __global__ __launch_bounds__(kThreads) void formation_rebuild_kernel(Params p, F
         t.near_new()[i] = (int8_t)(r[8] & 0xff); t.g_new()[i] = (int8_t)((r[8] >> 8) & 0xff);
         if (i == 0) *t.flag() = 0;
     }
-    for (int k = tid; k < nenv * LO; k += kThreads) {
+    for (int k = tid; k < nenv * LO; k += blockDim.x) {
         const int e_l = k / LO, j = k - e_l * LO;
         const float *sp = (const float *)(ep_rec + (size_t)(env0 + e_l) * words) + 2 * (N + j);
         const FormLds t(p, lds, e_l);
         t.pos()[N + j] = make_double2((double)sp[0], (double)sp[1]);
         t.posf()[N + j] = make_float2(sp[0], sp[1]);
     }
-    for (int k = tid; k < nenv * p.W; k += kThreads) {
+    for (int k = tid; k < nenv * p.W; k += blockDim.x) {
         const int e_l = k / p.W, w = k - e_l * p.W;
         const FormLds t(p, lds, e_l);
         const uint32_t *q = ep_rec + (size_t)(env0 + e_l) * words + 2 * (N + LO) + 6 * w;

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOut
         if (p.scan_stats) { m = sm; sd = sqrt(sq / p.N); }
         else if (Dg == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + p.N, s_stat + p.N, p.N, p.N, m, sd);
-        const double fairness = m / (sd + 0.0001);
+        const double fairness = ratio_out(m, sd + 0.0001);
         if (o.obs) {
             float *ob = o.obs + g * p.D;
             ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;

@@ -511,16 +511,19 @@ __device__ __forceinline__ double2 agent_force(const Params &p, const char *base
         double ppar = horiz ? x.x : x.y, pperp = horiz ? x.y : x.x;
         const double s = kEntitySize;
         if (ppar < e0 - s || ppar > e1 + s) continue;
-        double theta = 0.0, dmin = s + 0.5 * kWallWidth;
+        // core.py:423-445: theta = arcsin(past / size) beyond an end point, 0 inside the span; the force only needs
+        // cos(theta) = sqrt(1 - (past / size)^2) and sin(theta) = past / size (the library's asin + cos + sin, some 400
+        // instructions, ran for every lane of a wave as soon as one of its agents was inside a wall's span)
+        double sin_t = 0.0, cos_t = 1.0;
         if (ppar < e0 || ppar > e1) {
-            double past = ppar < e0 ? ppar - e0 : ppar - e1;
-            theta = asin(past / s);
-            dmin = cos(theta) * s + 0.5 * kWallWidth;
+            sin_t = (ppar < e0 ? ppar - e0 : ppar - e1) * (1.0 / s);
+            cos_t = sqrt_pos(fmax(1.0 - sin_t * sin_t, 0.0));
         }
+        const double dmin = cos_t * s + 0.5 * kWallWidth;
         double dpos = pperp - axis, d = fabs(dpos);
         double pen = softplus_pen(-(d - dmin) / kWallContactMargin, kWallContactMargin);
         double fm = kWallContactForce * dpos / d * pen;
-        double fperp = cos(theta) * fm, fpar = sin(theta) * fabs(fm);
+        double fperp = cos_t * fm, fpar = sin_t * fabs(fm);
         Fx += horiz ? fpar : fperp;
         Fy += horiz ? fperp : fpar;
     }
@@ -532,12 +535,12 @@ __device__ __forceinline__ void integrate_agent(const Params &p, const double2 F
     v.x = v.x * (1 - kDamping) + F.x * kDt;
     v.y = v.y * (1 - kDamping) + F.y * kDt;
     if (p.has_max_speed) {
-        double speed = sqrt(v.x * v.x + v.y * v.y);
+        double speed = sqrt_pos(v.x * v.x + v.y * v.y);
         if (speed > p.max_speed) { v.x = v.x / speed * p.max_speed; v.y = v.y / speed * p.max_speed; }
     }
     x.x += v.x * kDt; x.y += v.y * kDt;
     double sx = v.x * kDt, sy = v.y * kDt;
-    pd += sqrt(sx * sx + sy * sy);
+    pd += sqrt_pos(sx * sx + sy * sy);
 }
 
 // World.step for agent i: both halves.
@@ -640,7 +643,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         else if (p.scan_stats) { m = f_m; sd = f_sd; }
         else if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd);
-        fairness = m / (sd + 0.0001);
+        fairness = ratio_out(m, sd + 0.0001);
 
         // collisions (:701-705, :650-684)
         int ag_hits = 0;
@@ -657,7 +660,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         double rew = dg < p.thr ? p.goal_rew : -dg;
         rew -= p.collision_rew * ag_hits;
         if (ob_hit) rew -= p.collision_rew;
-        double fr = p.fair_rew * tanh(fairness - p.zeroshift);
+        double fr = p.fair_rew * tanh_out(fairness - p.zeroshift);
         if (fr < -2.0) fr = -2.0;
         rew += fr;
         rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
@@ -690,12 +693,12 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
             inf[FMARL_INFO_NUM_OBST_COLLISIONS * plane] = (float)noc;
             inf[FMARL_INFO_DISTANCE_MEAN * plane] = (float)dm;
             inf[FMARL_INFO_DISTANCE_VARIANCE * plane] = (float)ds;
-            inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)(dm / (ds + 0.0001));
+            inf[FMARL_INFO_MEAN_BY_VARIANCE * plane] = (float)ratio_out(dm, ds + 0.0001);
             inf[FMARL_INFO_DISTS_TRAVELED * plane] = (float)Dg_new;
             inf[FMARL_INFO_TIME_TAKEN * plane] = (float)(step * kDt);
             inf[FMARL_INFO_TIME_MEAN * plane] = (float)tm;
             inf[FMARL_INFO_TIME_STDDEV * plane] = (float)ts;
-            inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)(tm / (ts + 0.0001));
+            inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)ratio_out(tm, ts + 0.0001);
             inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
             inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
         }

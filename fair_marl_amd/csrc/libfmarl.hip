@@ -1,6 +1,7 @@
 // libfmarl.so -- C-ABI (include/fmarl.h) over the gfx950 kernels.  Single translation unit.
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 
@@ -103,6 +104,7 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     set(FMARL_F_PLACE_FAILS, n, FMARL_DTYPE_I32);
     set(FMARL_F_STAGE_PLACE_FAILS, async ? n : 0, FMARL_DTYPE_I32);
     set(FMARL_F_MATCH_DUAL, form ? n * N : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_ROT_TABLE, form ? 2 * N : 0, FMARL_DTYPE_F64);
     size_t off = 0;
     for (int f = 0; f < FMARL_NUM_FIELDS; ++f) {
         l->off[f] = off;
@@ -118,6 +120,7 @@ struct Handle {
     Params base;        // everything but the state pointers
     size_t lds_bytes;
     int grid;
+    int threads;        // workgroup size of the step / reset-emission launches (waves * 64)
     bool captured;      // a step of this handle was captured into a hipGraph: replays advance the device's step counters
                         // behind the host's back, so the host-side lockstep shortcut is off for good
     bool lockstep;      // all envs share one step counter, known on the host
@@ -135,6 +138,7 @@ struct Handle {
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int ev_cap, ev_n;
     int64_t counts[4];  // fmarl_launch_counts
+    double rot[64];     // formation: (cos, sin) of i * 2 pi / N, copied into the state buffer by fmarl_init_state
 };
 
 // Entry points that take a handle run on the handle's device whatever the caller's current device is
@@ -173,6 +177,7 @@ Params bind(const Handle *h, void *state) {
     p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
     p.stage_valid = (int *)(s + o[FMARL_F_STAGE_VALID]);            p.stage_need = (int *)(s + o[FMARL_F_STAGE_NEED]);
     p.match_dual = (double *)(s + o[FMARL_F_MATCH_DUAL]);
+    p.rot_table = (const double2 *)(s + o[FMARL_F_ROT_TABLE]);
     p.place_fails = (int *)(s + o[FMARL_F_PLACE_FAILS]);             p.st_place_fails = (int *)(s + o[FMARL_F_STAGE_PLACE_FAILS]);
     return p;
 }
@@ -234,7 +239,7 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
     }
     if (outs && (outs->obs || outs->node_obs || outs->adj)) {
         if (form)
-            hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
+            hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs,
                                (const int32_t *)nullptr, (const float *)nullptr, 0);
         else if (p.scenario == FMARL_SCENARIO_FAIRNAV)
             hipLaunchKernelGGL(fairnav_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
@@ -315,30 +320,43 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // navigation_graph: the statistics blocks are dead once the emission starts (a workgroup barrier apart), so they share
     // the region of the emission windows instead of sitting in every env's table (one more workgroup per CU at N = 10)
     const bool stat_shared = staged && !form && !fnav && !p.scan_stats;
-    p.lds_stat = off;   off = align16(off + ((p.scan_stats || stat_shared) ? 0 : (form ? 2 * p.N * 8 + 12 : 5 * p.N * 8)));   // wave scans need no table; formation: [pd | Dg_old] + a mask word
+    p.lds_stat = off;   off = align16(off + ((p.scan_stats || stat_shared || form || fnav) ? 0 : 5 * p.N * 8));   // wave scans need no table; formation / fairnav: below
     p.lds_wall = off;   off = align16(off + p.W * 4 * 8);
     p.lds_flag = off;   off = align16(off + 16);   // flag, then the formation scenario's three occupancy words or the env's policy-edge counter
-    p.lds_cnt = form ? p.lds_stat + 2 * p.N * 8 + 8 : p.lds_flag + 4;   // formation: in the padding behind its statistics block
+    p.lds_cnt = p.lds_flag + 4;   // (formation: the occupancy word of the previous pass, dead once the emission starts)
     p.has_posf = 1;   // f32 copy of the entity positions: adj and the node rows start from it (all three scenarios)
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
     p.has_wallf = !form;   // the formation kernel converts the corners from the f64 wall table (LDS budget: five workgroups per CU)
     p.lds_wallf = off;  off = align16(off + (p.has_wallf ? p.W * 16 : 0));
     p.lds_constf = off; off = align16(off + (!form && !fnav ? 16 : 0));
+    int form_dead = 0;   // bytes per env in the second LDS region (formation, fairnav)
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
-        p.f_slot_old = off; off = align16(off + p.N * 16);
         p.f_g = off;        off = align16(off + 3 * p.N + 1);
         p.f_masks = off;    off = align16(off + (3 * p.N * 4 > p.N * 8 ? 3 * p.N * 4 : p.N * 8));
-        p.f_theta = off;    off = align16(off + p.N * 8);
-        p.f_words = off;    off = align16(off + (p.N * 8 > (p.N + 2) * 4 ? p.N * 8 : (p.N + 2) * 4));   // column potentials of the last matching, then the walk's entity sets
+        // Tables nobody reads once the emission starts live in a region of their own behind all envs' blocks (offsets relative
+        // to the env's part of it, f_dead_bytes each): the envs of one wave are consecutive there, and their part doubles as
+        // the wave's emission window (rows leave as contiguous 16-byte chunks instead of 16 bytes per lane at a 48-byte stride)
+        int d = 0;
+        p.lds_stat = d;   d = align16(d + 2 * p.N * 8 + 12);   // [pd | Dg_old] + the mask of agents still under way
+        p.f_slot_old = d; d = align16(d + p.N * 16);
+        p.f_theta = d;    d = align16(d + p.N * 8);
+        p.f_words = d;    d = align16(d + (p.N * 8 > (p.N + 2) * 4 ? p.N * 8 : (p.N + 2) * 4));   // column potentials of the last matching, then the walk's entity sets
+        form_dead = p.lds2_bytes = d;
     }
     if (fnav) {   // fmarl_fairnav.hip FairNavLds
-        p.n_D = off;       off = align16(off + p.N * p.L * 8);
-        p.n_minprox = off; off = align16(off + p.L * 8);
-        p.n_occ = off;     off = align16(off + 2 * p.L * 8);
-        p.n_match = off;   off = align16(off + p.N * 4);
-        p.n_rows = off;    off = align16(off + p.N * p.N * 16);
-        p.n_words = off;   off = align16(off + 16);
+        p.n_rows = off;    off = align16(off + p.N * p.N * 12);
+        // Tables nobody reads once the emission starts: a region of their own behind all envs' blocks, which the waves' emission
+        // windows alias (13.5 KB that used to sit beside the envs' tables: 36 -> 58 envs per workgroup in the shipped FA+FR
+        // configuration, and the launch time falls with the number of workgroups: tools/epb_sweep.py fnav)
+        int d = 0;
+        p.lds_stat = d;    d += 5 * p.N * 8;        // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
+        p.n_D = d;         d += p.N * p.L * 8;
+        p.n_minprox = d;   d += p.L * 8;
+        p.n_occ = d;       d += 2 * p.L * 8;
+        p.n_match = d;     d += p.N * 4;
+        p.n_words = d;     d += 12;
+        form_dead = p.lds2_bytes = (d + 7) / 8 * 8;
     }
     p.lds_env_bytes = off;
     p.stage_wave_bytes = staged ? align16(kStageRows * p.F * 4 + 64) : 0;   // + the window's offset inside its 64-byte aligned frame
@@ -348,15 +366,26 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // 40 KB per workgroup = four workgroups per CU (160 KB).  With 48 KB the shipped nav_fairassign configuration took 47 envs
     // per workgroup at three per CU: 0.082 ms per launch against 0.078 with 36 envs at four per CU (tools/epb_probe.sh fnav);
     // navigation_graph at 10 agents had gained 7 % from the same 3 -> 4 step.
-    const int budget = 40 * 1024 - shared_bytes;
-    if (epb * p.lds_env_bytes > budget) epb = budget / p.lds_env_bytes;
+    // fairnav: the windows alias the second region (the tables there are dead by then): the region holds whichever is larger
+    const int budget = 40 * 1024 - (fnav ? 0 : shared_bytes);
+    const int env_lds = p.lds_env_bytes + form_dead;   // LDS of one env incl. its share of the second region (formation, fairnav)
+    if (epb * env_lds > budget) epb = budget / env_lds;
+    if (fnav) while (epb > 1 && epb * p.lds_env_bytes + (epb * form_dead > shared_bytes ? epb * form_dead : shared_bytes) > 40 * 1024) --epb;
     if (epb < 1) epb = 1;
-    if (form) {   // every env inside one wave (fmarl_formation.hip): 64 / N envs per wave, four waves
+    // fair_graph_formation: every env lives inside one wave (fmarl_formation.hip), 64 / N envs per wave, and no wave ever waits
+    // for another one.  Workgroups of ONE wave (the scheduler placing 64-lane units) measured slower than four waves per
+    // workgroup: 0.295 vs 0.274 ms per launch at BASELINE config 4, two waves 0.276-0.286 (profiles/r3_cfg4_notes.md)
+    int form_waves = kThreads / 64;
+#ifdef FMARL_MEASURE
+    if (const char *e = getenv("FMARL_FORM_WAVES")) form_waves = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : form_waves;
+#endif
+    h->threads = form ? 64 * form_waves : kThreads;
+    if (form) {
         int epw = 64 / p.N;
         if (epw < 1) { delete h; return fail(FMARL_EINVAL, "fmarl_create: fair_graph_formation is built for num_agents <= 32"); }
-        while (epw > 1 && (kThreads / 64) * epw * p.lds_env_bytes > budget) --epw;
+        while (epw > 1 && form_waves * epw * env_lds > budget) --epw;
         p.epw = epw;
-        epb = (kThreads / 64) * epw;
+        epb = form_waves * epw;
     }
     if (cfg->envs_per_workgroup > 0) {   // the caller's geometry (parity tests at the full-batch shape on a few envs)
         if (cfg->envs_per_workgroup < epb) epb = cfg->envs_per_workgroup;
@@ -367,11 +396,17 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 #ifdef FMARL_MEASURE
     if (const char *e = getenv("FMARL_EPB")) { const int v = atoi(e); if (v >= 1 && v <= epb) epb = v; }   // envs per workgroup (experiments)
 #endif
-    if (form) { p.epw = (epb + kThreads / 64 - 1) / (kThreads / 64); epb = p.epw * (kThreads / 64); }
-    if ((size_t)p.lds_env_bytes > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
+    if (form) { p.epw = (epb + form_waves - 1) / form_waves; epb = p.epw * form_waves; }
+    if ((size_t)env_lds > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     p.lds_stage = align16(epb * p.lds_env_bytes);
-    size_t stage_bytes = (size_t)(kThreads / 64) * p.stage_wave_bytes;
+    if (form) {   // the second region: epw envs per wave, the wave's part = its emission window
+        p.stage_wave_bytes = p.epw * form_dead;
+        const int rows = (p.stage_wave_bytes / 16 - 3) / 3;   // 48-byte rows + up to 3 chunks of alignment (formation_flush_rows)
+        p.f_rows = rows > 63 ? 63 : rows;
+    }
+    size_t stage_bytes = (size_t)(h->threads / 64) * p.stage_wave_bytes;
+    if (fnav && (size_t)epb * form_dead > stage_bytes) stage_bytes = (size_t)epb * form_dead;
     p.stat_stride = p.lds_env_bytes;
     if (stat_shared) {
         p.lds_stat = p.lds_stage; p.stat_stride = 5 * p.N * 8;
@@ -506,6 +541,11 @@ int fmarl_init_state(void *handle, void *state, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     h->cap_id = 0;
     HIP_OK(hipMemsetAsync(state, 0, h->layout.total, st));
+    if (h->layout.count[FMARL_F_ROT_TABLE]) {
+        const int N = h->cfg.num_agents;
+        for (int i = 0; i < N; ++i) { const double a = i * ((2 * M_PI) / N); h->rot[2 * i] = cos(a); h->rot[2 * i + 1] = sin(a); }
+        HIP_OK(hipMemcpyAsync((char *)state + h->layout.off[FMARL_F_ROT_TABLE], h->rot, sizeof(double) * 2 * N, hipMemcpyHostToDevice, st));
+    }
     int rc = launch_reset(h, state, kResetInit, nullptr, nullptr, st);
     if (rc == FMARL_OK && h->async && h->cfg.scenario == FMARL_SCENARIO_NAVIGATION_GRAPH) {
         // The first launch of a kernel pays for loading its code (about a millisecond for the 50 KB of step_end_kernel), and the
@@ -589,7 +629,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
         hipLaunchKernelGGL(fairnav_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
                            action_vec, auto_reset ? 1 : 0);
     else if (p.scenario == FMARL_SCENARIO_FORMATION)
-        hipLaunchKernelGGL(formation_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
+        hipLaunchKernelGGL(formation_kernel<true>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs, action_idx,
                            action_vec, auto_reset ? 1 : 0);
     else if (fold)
         hipLaunchKernelGGL(step_end_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec, 1);
@@ -817,7 +857,7 @@ int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_
         hipLaunchKernelGGL(fairnav_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o,
                            (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
     else if (sc == FMARL_SCENARIO_FORMATION)
-        hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o,
+        hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, (hipStream_t)stream, h->base, o,
                            (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
     else
         hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o, obs,

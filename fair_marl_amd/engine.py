@@ -210,7 +210,7 @@ class RolloutEngine:
                     reset_flag=(n,), stage_agent_pos=(n, N, 2), stage_landmark_pos=(n, L, 2),
                     stage_obstacle_pos=(n, O, 2), stage_wall_axis=(n, W), stage_wall_orient=(n, W),
                     stage_goal_match=(n, N), stage_valid=(n,), stage_need=(n,), place_fails=(n,), stage_place_fails=(n,),
-                    internal_match_dual=(n, N))
+                    internal_match_dual=(n, N), internal_rot_table=(N, 2))
 
     @property
     def envs_per_workgroup(self):

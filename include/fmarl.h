@@ -166,6 +166,8 @@ enum {
     FMARL_F_STAGE_PLACE_FAILS, /* i32 (n)        the same for the staged next episode (FMARL_FLAG_ASYNC_RESET)             */
     FMARL_F_MATCH_DUAL,        /* f64 (n, N)     internal (formation): column potentials of the last slot matching, the
                                                  warm start of the next one (any values are valid: the optimum is unique) */
+    FMARL_F_ROT_TABLE,         /* f64 (N, 2)     internal (formation), ONE table for all envs: (cos, sin) of i * 2 pi / N -- the slots on
+                                                 the circle are the anchor direction rotated by these (fair_graph_formation.py:630-648) */
     FMARL_NUM_FIELDS
 };
 #define FMARL_DTYPE_F64 0
