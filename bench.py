@@ -458,6 +458,7 @@ def main():
         # that ends an episode also commits the next one and emits its first observation (step_end_kernel), so every launch
         # writes the full outputs.  Which of the two happened is read from the library's launch counters, not assumed.
         ep = cfg.episode_length
+        fnav_sc = cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph'
         resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
         ca, cb = counts_eager if args.graph else (counts0, counts1)
         if pipe is not None:
@@ -502,7 +503,9 @@ def main():
                        'exchange': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
                                      else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
                                     % StepRecord.bytes_per_agent_step(cfg.obs_dim, eng.step_record_words if eng.emit_graph_record else 0)
-                                    + (' + %d B per env once per episode (goals, landmarks, obstacles, walls)'
+                                    + ((' + %d B per env with EVERY step (goals, landmarks, obstacles, walls: this scenario\'s episodes end env by env, '
+                                        'so the record is re-packed and gathered whenever an env may have been reset)' if fnav_sc else
+                                        ' + %d B per env once per episode (goals, landmarks, obstacles, walls)')
                                        % (4 * eng.episode_record_words) if episodes else '')) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -537,7 +540,8 @@ def main():
                                            'stalls the compute stream, a gloo wait blocks the host'},
                 'bytes_gathered_per_step': rec_bytes * world, 'bytes_received_by_rank0_per_step': recv_bytes,
                 'rank0_receive_GBps': recv_bytes / (elapsed / K) / 1e9,
-                'episode_record_bytes_per_rank': 4 * eng.episode_record_words * n_envs if episodes else 0}
+                'episode_record_bytes_per_rank': 4 * eng.episode_record_words * n_envs if episodes else 0,
+                'episode_record_gathers_per_step': (1.0 if fnav_sc else 1.0 / ep) if episodes else 0.0}
             if rebuild_ranks:
                 torch.cuda.synchronize(device)
                 ms = [a.elapsed_time(b) for a, b in rebuild_events]

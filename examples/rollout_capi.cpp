@@ -86,7 +86,7 @@ int main(int argc, char **argv) {
     HIP_OK(hipMalloc((void **)&edge_index, (size_t)2 * cap * 8));
     HIP_OK(hipMalloc((void **)&edge_attr, (size_t)cap * 4));
     FMARL_OKAY(fmarl_edge_offsets(outs.edge_nnz, n, 1, offsets, st));
-    FMARL_OKAY(fmarl_edge_fill_state(h, state, offsets, edge_index, edge_attr, cap, 1, st));
+    FMARL_OKAY(fmarl_edge_fill_state(h, state, offsets, edge_index, edge_attr, cap, 1, nullptr, st));
     HIP_OK(hipStreamSynchronize(st));
     int64_t total = 0;
     HIP_OK(hipMemcpy(&total, offsets + n, 8, hipMemcpyDeviceToHost));

@@ -23,7 +23,8 @@ FIELD_NAMES = ('agent_pos', 'agent_vel', 'p_dist', 'landmark_pos', 'obstacle_pos
                'reset_flag', 'stage_agent_pos',
                'stage_landmark_pos', 'stage_obstacle_pos', 'stage_wall_axis', 'stage_wall_orient', 'stage_goal_match',
                'stage_valid', 'stage_need', 'place_fails', 'stage_place_fails', 'internal_match_dual', 'internal_rot_table')
-DTYPE_F64, DTYPE_I32 = 0, 1
+DTYPE_F64, DTYPE_I32, DTYPE_I8 = 0, 1, 2
+DTYPE_BYTES = {DTYPE_F64: 8, DTYPE_I32: 4, DTYPE_I8: 1}
 SCENARIOS = {'navigation_graph': 0, 'fair_graph_formation': 1, 'nav_fairassign_fairrew_formation_graph': 2}
 
 
@@ -73,7 +74,7 @@ _SIGS = {
     'fmarl_edge_fill': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                   C.c_double, C.c_int, C.c_void_p]),
     'fmarl_edge_offsets': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    'fmarl_edge_fill_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    'fmarl_edge_fill_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     'fmarl_episode_record_words': (C.c_size_t, [C.POINTER(FmarlConfig)]),
     'fmarl_step_record_words': (C.c_size_t, [C.POINTER(FmarlConfig)]),
     'fmarl_rebuild_graph_rec': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -80,7 +80,8 @@ struct Params {
     // fairnav scenario: extra per-env LDS tables (byte offsets), knob and state
     int n_D, n_minprox, n_occ, n_match, n_rows, n_words;
     double min_obs_dist;
-    double *goal_occ, *goal_history, *goal_reached, *status;
+    double *goal_occ;
+    int8_t *goal_history, *goal_reached, *status;   // integer-valued in the reference (-1 / index, -1 / index, bool)
     // state
     double2 *agent_pos, *agent_vel, *landmark_pos, *obstacle_pos;
     double *p_dist, *wall_axis, *wall_e0, *wall_e1, *wall_length;

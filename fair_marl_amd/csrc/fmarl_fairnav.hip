@@ -287,9 +287,9 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     double pd = 0, status = 0;
     int step = 0;
     if (active) {
-        x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g]; status = p.status[g];
+        x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g]; status = (double)p.status[g];
         t.pos()[i] = x;
-        t.occ()[i] = p.goal_occ[g]; t.hist()[i] = p.goal_history[g];   // L == N
+        t.occ()[i] = p.goal_occ[g]; t.hist()[i] = (double)p.goal_history[g];   // L == N
         step = p.cur_step[env] + (STEP ? 1 : 0);
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
@@ -336,7 +336,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             if (newly) status = 1.0;
             done = status != 0.0 || step >= p.episode_length;   // environment.py:237-247
             if (!done) atomicAnd(&t.words()[1], 0);
-            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left = p.dist_left[g]; gr = p.goal_reached[g];
+            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left = p.dist_left[g]; gr = (double)p.goal_reached[g];
             int near = 0;
             double dn = t.D()[i * L];
             for (int k = 1; k < L; ++k) { const double d = t.D()[i * L + k]; if (d < dn) { dn = d; near = k; } }
@@ -411,7 +411,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)og.g_occ; ob[7] = (float)og.g_hist;
             ob[8] = (float)(sec.x - x.x); ob[9] = (float)(sec.y - x.y); ob[10] = (float)og.second_occ;
         }
-        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
+        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = (int8_t)t.hist()[i]; }
         if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
             uint32_t *r = o.graph_record + g * (size_t)(5 + 3 * N);
             const float4 af = t.agentf()[i];
@@ -448,8 +448,8 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
 
             const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
             const double2 vout = newly ? make_double2(0.0, 0.0) : v;   // nf:736-737
-            p.agent_pos[g] = x; p.agent_vel[g] = vout; p.p_dist[g] = pd; p.status[g] = status;
-            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left; p.goal_reached[g] = gr;
+            p.agent_pos[g] = x; p.agent_vel[g] = vout; p.p_dist[g] = pd; p.status[g] = (int8_t)status;
+            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left; p.goal_reached[g] = (int8_t)gr;
             p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac; p.goal_match[g] = t.match()[i];
             if (i == 0) p.cur_step[env] = step;
             if (o.reward) o.reward[g] = (float)rew;

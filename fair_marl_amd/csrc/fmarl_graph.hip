@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const float *adj, const 
     const float *a = adj + (size_t)(b / graphs_per_env) * EE;
     int64_t *rows = edge_index, *cols = edge_index + total;
     int64_t base = offsets[b];
+    const int64_t end = offsets[b + 1], limit = end < total ? end : total;   // (a graph stays inside its own range)
     const int64_t node0 = (int64_t)b * E;
     for (int q0 = 0; q0 < EE; q0 += 64) {
         const int q = q0 + lane;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void edge_fill_kernel(const float *adj, const 
         const unsigned long long m = __ballot(on);
         if (on) {
             const int64_t k = base + __popcll(m & ((1ull << lane) - 1));
-            if (k < total) { rows[k] = node0 + q / E; cols[k] = node0 + q % E; edge_attr[k] = d; }   // total = capacity of the buffers
+            if (k < limit) { rows[k] = node0 + q / E; cols[k] = node0 + q % E; edge_attr[k] = d; }   // total = capacity of the buffers
         }
         base += __popcll(m);
     }
@@ -198,14 +199,18 @@ __global__ __launch_bounds__(256) void edge_scan_fill_kernel(const int32_t *nnz,
 // processAdj from the world state: one wave per graph recomputes the env's adj entries exactly as
 // the emission did -- differences of the float32 roundings of the entity positions -- and compacts the policy edges 0 < d < max_edge_dist in row-major
 // order behind offsets[b]: rows | cols with node ids b * E + r, edge_attr = the adj entry.  adj is not read.
+// A graph never writes outside its own range [offsets[b], offsets[b + 1]): if the counts the offsets were built from do not
+// describe this state (another output set's edge_nnz, a state written in between), the graph's list is cut short or keeps
+// a gap instead of running into its neighbour's, and `mismatch` (optional device counter) counts such graphs.
 __global__ __launch_bounds__(256) void edge_fill_state_kernel(Params p, const int64_t *offsets, int64_t *edge_index,
-                                                              float *edge_attr, int64_t capacity, int gpe) {
+                                                              float *edge_attr, int64_t capacity, int gpe, int32_t *mismatch) {
     const int lane = threadIdx.x & 63;
     const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= p.n_envs * gpe) return;   // wave-uniform
     const int env = b / gpe, E = p.E, EE = E * E;
     int64_t *rows = edge_index, *cols = edge_index + capacity;
     int64_t base = offsets[b];
+    const int64_t end = offsets[b + 1], limit = end < capacity ? end : capacity;
     const int64_t node0 = (int64_t)b * E;
     for (int q0 = 0; q0 < EE; q0 += 64) {
         const int q = q0 + lane;
@@ -220,10 +225,11 @@ __global__ __launch_bounds__(256) void edge_fill_state_kernel(Params p, const in
         const unsigned long long m = __ballot(on);
         if (on) {
             const int64_t k = base + __popcll(m & ((1ull << lane) - 1));
-            if (k < capacity) { rows[k] = node0 + r; cols[k] = node0 + c; edge_attr[k] = d; }
+            if (k < limit) { rows[k] = node0 + r; cols[k] = node0 + c; edge_attr[k] = d; }
         }
         base += __popcll(m);
     }
+    if (mismatch && lane == 0 && base != end) atomicAdd(mismatch, 1);
 }
 
 // Per-agent means over the envs of every info field, reference onpolicy/runner/shared/base_runner.py:197-276

@@ -166,7 +166,7 @@ __device__ __forceinline__ void place_env(const Params &p, PL &pl, int mode, int
         }
     } else if (fairnav) {   // nav_fairassign_...py:233-238, :446-459: goal_match reset to arange BEFORE min_time
         for (int i = 0; i < N; ++i) {
-            p.goal_occ[a0 + i] = 0.0; p.goal_history[a0 + i] = -1.0; p.goal_reached[a0 + i] = -1.0; p.status[a0 + i] = 0.0;
+            p.goal_occ[a0 + i] = 0.0; p.goal_history[a0 + i] = -1; p.goal_reached[a0 + i] = -1; p.status[a0 + i] = 0;
             if (p.has_max_speed) p.min_time[a0 + i] = dist2(pl.g_agent(i), pl.g_landmark(i)) / p.max_speed;
         }
     } else if (p.has_max_speed) {   // :545-547, :719-728 -- previous episode's goal_match_index
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
         doit = p.cur_step[env] >= p.episode_length;
         if (!doit && p.scenario == FMARL_SCENARIO_FAIRNAV) {
             doit = true;
-            for (int i = 0; i < p.N; ++i) doit &= p.status[(size_t)env * p.N + i] != 0.0;
+            for (int i = 0; i < p.N; ++i) doit &= p.status[(size_t)env * p.N + i] != 0;
         }
     } else if (stage) doit = p.stage_valid[env] == 0;
     if (stage) p.stage_need[env] = doit ? 1 : 0;

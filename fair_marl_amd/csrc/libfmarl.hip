@@ -53,9 +53,10 @@ bool config_ok(const FmarlConfig *c, const char **why) {
     const bool form = c->scenario == FMARL_SCENARIO_FORMATION;
     const bool fnav = c->scenario == FMARL_SCENARIO_FAIRNAV;
     if (c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH && !form && !fnav) { *why = "unsupported scenario"; return false; }
-    if (fnav && (c->num_agents < 2 || c->num_agents > 32)) { *why = "nav_fairassign_fairrew_formation_graph needs 2..32 agents"; return false; }
+    if (fnav && (c->num_agents < 2 || c->num_agents > 32)) { *why = "nav_fairassign_fairrew_formation_graph is built for num_agents in 2..32"; return false; }
     if (c->n_envs < 1) { *why = "n_envs < 1"; return false; }
-    if (c->num_agents < 1 || c->num_agents > (form ? 32 : 64)) { *why = "num_agents must be in 1..64 (formation: 1..32)"; return false; }
+    if (form && (c->num_agents < 1 || c->num_agents > 32)) { *why = "fair_graph_formation is built for num_agents in 1..32"; return false; }
+    if (c->num_agents < 1 || c->num_agents > 64) { *why = "navigation_graph is built for num_agents in 1..64"; return false; }
     if (!form && c->num_landmarks != c->num_agents) { *why = "navigation_graph needs num_landmarks == num_agents"; return false; }
     if (form && c->num_landmarks < 1) { *why = "fair_graph_formation needs num_landmarks >= 1"; return false; }
     if (c->num_obstacles < 0 || c->num_obstacles > 4096) { *why = "bad num_obstacles"; return false; }
@@ -69,6 +70,8 @@ bool config_ok(const FmarlConfig *c, const char **why) {
     }
     return true;
 }
+
+size_t dtype_bytes(int dt) { return dt == FMARL_DTYPE_F64 ? 8 : (dt == FMARL_DTYPE_I32 ? 4 : 1); }
 
 void make_layout(const FmarlConfig *c, Layout *l) {
     const size_t n = c->n_envs, N = c->num_agents, L = c->num_landmarks, O = c->num_obstacles, W = c->num_walls;
@@ -89,8 +92,8 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     set(FMARL_F_SLOT_DELTA, form ? n * N : 0, FMARL_DTYPE_F64);
     set(FMARL_F_FORMATION_DONE, form ? n * N : 0, FMARL_DTYPE_F64);
     const bool fnav = c->scenario == FMARL_SCENARIO_FAIRNAV;
-    set(FMARL_F_GOAL_OCC, fnav ? n * N : 0, FMARL_DTYPE_F64);     set(FMARL_F_GOAL_HISTORY, fnav ? n * N : 0, FMARL_DTYPE_F64);
-    set(FMARL_F_GOAL_REACHED, fnav ? n * N : 0, FMARL_DTYPE_F64); set(FMARL_F_STATUS, fnav ? n * N : 0, FMARL_DTYPE_F64);
+    set(FMARL_F_GOAL_OCC, fnav ? n * N : 0, FMARL_DTYPE_F64);     set(FMARL_F_GOAL_HISTORY, fnav ? n * N : 0, FMARL_DTYPE_I8);
+    set(FMARL_F_GOAL_REACHED, fnav ? n * N : 0, FMARL_DTYPE_I8); set(FMARL_F_STATUS, fnav ? n * N : 0, FMARL_DTYPE_I8);
     set(FMARL_F_RESET_FLAG, n, FMARL_DTYPE_I32);
     const bool async = (c->flags & FMARL_FLAG_ASYNC_RESET) && !form && !fnav;
     set(FMARL_F_STAGE_AGENT_POS, async ? n * N * 2 : 0, FMARL_DTYPE_F64);
@@ -108,7 +111,7 @@ void make_layout(const FmarlConfig *c, Layout *l) {
     size_t off = 0;
     for (int f = 0; f < FMARL_NUM_FIELDS; ++f) {
         l->off[f] = off;
-        size_t bytes = l->count[f] * (l->dtype[f] == FMARL_DTYPE_F64 ? 8 : 4);
+        size_t bytes = l->count[f] * dtype_bytes(l->dtype[f]);
         off += (bytes + 255) / 256 * 256;
     }
     l->total = off;
@@ -170,8 +173,8 @@ Params bind(const Handle *h, void *state) {
     p.episode = (int *)(s + o[FMARL_F_EPISODE]);               p.reset_flag = (int *)(s + o[FMARL_F_RESET_FLAG]);
     p.slot_pos = (double2 *)(s + o[FMARL_F_SLOT_POS]);         p.slot_occ = (double *)(s + o[FMARL_F_SLOT_OCC]);
     p.slot_delta = (double *)(s + o[FMARL_F_SLOT_DELTA]);      p.formation_done = (double *)(s + o[FMARL_F_FORMATION_DONE]);
-    p.goal_occ = (double *)(s + o[FMARL_F_GOAL_OCC]);          p.goal_history = (double *)(s + o[FMARL_F_GOAL_HISTORY]);
-    p.goal_reached = (double *)(s + o[FMARL_F_GOAL_REACHED]);  p.status = (double *)(s + o[FMARL_F_STATUS]);
+    p.goal_occ = (double *)(s + o[FMARL_F_GOAL_OCC]);          p.goal_history = (int8_t *)(s + o[FMARL_F_GOAL_HISTORY]);
+    p.goal_reached = (int8_t *)(s + o[FMARL_F_GOAL_REACHED]);  p.status = (int8_t *)(s + o[FMARL_F_STATUS]);
     p.st_agent_pos = (double2 *)(s + o[FMARL_F_STAGE_AGENT_POS]);   p.st_landmark_pos = (double2 *)(s + o[FMARL_F_STAGE_LANDMARK_POS]);
     p.st_obstacle_pos = (double2 *)(s + o[FMARL_F_STAGE_OBSTACLE_POS]); p.st_wall_axis = (double *)(s + o[FMARL_F_STAGE_WALL_AXIS]);
     p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
@@ -665,7 +668,7 @@ static int copy_field(Handle *h, void *state, int field, void *host_or_dev, bool
     if (!h || !state || !host_or_dev) return fail(FMARL_EINVAL, "%s: null argument", who);
     DeviceGuard on_device(h);
     if (field < 0 || field >= FMARL_NUM_FIELDS) return fail(FMARL_EINVAL, "%s: bad field id", who);
-    const size_t bytes = h->layout.count[field] * (h->layout.dtype[field] == FMARL_DTYPE_F64 ? 8 : 4);
+    const size_t bytes = h->layout.count[field] * dtype_bytes(h->layout.dtype[field]);
     if (bytes == 0) return FMARL_OK;
     char *f = (char *)state + h->layout.off[field];
     HIP_OK(hipMemcpyAsync(to_state ? (void *)f : host_or_dev, to_state ? host_or_dev : (void *)f, bytes, hipMemcpyDefault, st));
@@ -787,7 +790,7 @@ int fmarl_edge_offsets(const int32_t *nnz, int n_envs, int graphs_per_env, int64
 }
 
 int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offsets, int64_t *edge_index, float *edge_attr,
-                          int64_t capacity, int graphs_per_env, void *stream) {
+                          int64_t capacity, int graphs_per_env, int32_t *mismatch, void *stream) {
     Handle *h = (Handle *)handle;
     DeviceGuard on_device(h);
     if (!h || !state || !offsets || capacity < 0 || graphs_per_env < 1 || (capacity > 0 && (!edge_index || !edge_attr)))
@@ -797,7 +800,7 @@ int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offset
     const int64_t graphs = (int64_t)p.n_envs * graphs_per_env;
     if (graphs > 0x7fffffff / 64) return fail(FMARL_EINVAL, "fmarl_edge_fill_state: too many graphs");
     hipLaunchKernelGGL(edge_fill_state_kernel, dim3((unsigned)((graphs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, offsets,
-                       edge_index, edge_attr, capacity, graphs_per_env);
+                       edge_index, edge_attr, capacity, graphs_per_env, mismatch);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

@@ -15,12 +15,12 @@ import torch
 from . import _lib
 from .config import EnvConfig
 
-_TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32}
+_TORCH_DT = {_lib.DTYPE_F64: torch.float64, _lib.DTYPE_I32: torch.int32, _lib.DTYPE_I8: torch.int8}
 
 
 class OutputSet(object):
     """obs / reward / done / info tensors of one step + the FmarlOutputs struct pointing at them."""
-    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'edge_nnz', 'graph_record', 'c')
+    __slots__ = ('obs', 'reward', 'done', 'info', 'info_planes', 'node_obs', 'adj_env', 'edge_nnz', 'graph_record', 'c', 'c_noinfo')
 
 
 class RolloutEngine:
@@ -80,7 +80,7 @@ class RolloutEngine:
                 if 0 in shapes[name]:   # empty field of this config (e.g. no walls), not a foreign scenario's field
                     self._fields[name] = torch.zeros(shapes[name], dtype=_TORCH_DT[dt.value], device=self.device)
                 continue
-            esz = 8 if dt.value == _lib.DTYPE_F64 else 4
+            esz = _lib.DTYPE_BYTES[dt.value]
             view = self.state[off.value: off.value + cnt.value * esz].view(_TORCH_DT[dt.value])
             self._fields[name] = view.view(shapes[name])
         with torch.cuda.device(self.device):
@@ -186,6 +186,7 @@ class RolloutEngine:
                                 o.info_planes.data_ptr() if o.info_planes is not None else None,
                                 o.edge_nnz.data_ptr() if o.edge_nnz is not None else None,
                                 o.graph_record.data_ptr() if o.graph_record is not None else None)
+        o.c_noinfo = _lib.FmarlOutputs(o.c.obs, o.c.node_obs, o.c.adj, o.c.reward, o.c.done, None, o.c.edge_nnz, o.c.graph_record)
         if o.graph_record is not None and (tuple(o.graph_record.shape) != (n, N, self.step_record_words) or o.graph_record.dtype != torch.int32
                                            or not o.graph_record.is_contiguous()):
             raise ValueError('graph_record must be a contiguous int32 tensor of shape %s' % ((n, N, self.step_record_words),))
@@ -195,6 +196,7 @@ class RolloutEngine:
         """Select the output set the next reset / step calls write into."""
         self.outs = out_set
         self._outs_ref = C.byref(out_set.c)   # (built once per set: the step path of a launch-bound batch counts microseconds)
+        self._outs_noinfo_ref = C.byref(out_set.c_noinfo)
         self.obs, self.reward, self.done, self.info = out_set.obs, out_set.reward, out_set.done, out_set.info
         self.node_obs, self.adj_env, self.graph_record = out_set.node_obs, out_set.adj_env, out_set.graph_record
 
@@ -225,7 +227,7 @@ class RolloutEngine:
         """Device tensor view of one state field (see include/fmarl.h FMARL_F_*)."""
         return self._fields[name]
 
-    _NP_DT = {torch.float64: np.float64, torch.int32: np.int32}
+    _NP_DT = {torch.float64: np.float64, torch.int32: np.int32, torch.int8: np.int8}
 
     def get_state(self):
         """All scenario state fields as NumPy arrays in the reference's shapes (fmarl_get_state)."""
@@ -286,10 +288,15 @@ class RolloutEngine:
                                             self._stream()), 'fmarl_reset')
         return self.obs, self.agent_id, self.node_obs, self.adj
 
-    def step(self, actions, auto_reset=True):
+    def step(self, actions, auto_reset=True, emit_info=True):
         """One env step for every env.  ``actions``: int tensor (n, N) of indices 0..4 or float tensor
         (n, N, 5) in the reference's one-hot / continuous form.  Returns device tensors
-        (obs, agent_id, node_obs, adj, reward, done, info)."""
+        (obs, agent_id, node_obs, adj, reward, done, info).
+
+        ``emit_info=False`` skips the 14 info planes of THIS step (56 bytes per agent-step of pure output; the world state
+        the reference's info_callback updates -- arrival times, collision counters, ... -- is kept either way).  The
+        reference's runner only reads the infos of an episode's last step (onpolicy/runner/shared/base_runner.py:197-276,
+        graph_mpe_runner.py:146); the returned ``info`` tensor then still holds the planes of the last step that wrote them."""
         a = actions if isinstance(actions, torch.Tensor) else torch.as_tensor(np.asarray(actions))
         n, N = self.n_envs, self.cfg.N
         idx_ptr = vec_ptr = None
@@ -305,7 +312,7 @@ class RolloutEngine:
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
             vec_ptr = a.data_ptr()
         # (the library switches to the handle's device itself; torch only supplies the stream of THAT device)
-        rc = self.lib.fmarl_step(self.handle, self._state_ptr, idx_ptr, vec_ptr, self._outs_ref, int(auto_reset),
+        rc = self.lib.fmarl_step(self.handle, self._state_ptr, idx_ptr, vec_ptr, self._outs_ref if emit_info else self._outs_noinfo_ref, int(auto_reset),
                                  torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _lib.check(rc, 'fmarl_step')
@@ -391,8 +398,13 @@ class RolloutEngine:
             ei = torch.empty(2, cap, dtype=torch.int64, device=self.device)
             ea = torch.empty(cap, dtype=torch.float32, device=self.device)
             if cap and fused:
+                if getattr(self, 'edge_mismatch', None) is None:
+                    # device counter of graphs whose state-rebuilt edges did not fill their offsets range exactly (the counts
+                    # must be those of the step the state is in); stays 0 in correct use, never read by this call
+                    self.edge_mismatch = torch.zeros(1, dtype=torch.int32, device=self.device)
                 _lib.check(self.lib.fmarl_edge_fill_state(self.handle, self.state.data_ptr(), offsets.data_ptr(), ei.data_ptr(),
-                                                          ea.data_ptr(), cap, reps, self._stream()), 'fmarl_edge_fill_state')
+                                                          ea.data_ptr(), cap, reps, self.edge_mismatch.data_ptr(), self._stream()),
+                           'fmarl_edge_fill_state')
             elif cap:
                 _lib.check(self.lib.fmarl_edge_fill(adj.data_ptr(), offsets.data_ptr(), ei.data_ptr(), ea.data_ptr(), cap, n * reps, reps, E,
                                                     thr, 1 if strict else 0, self._stream()), 'fmarl_edge_fill')

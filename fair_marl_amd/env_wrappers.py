@@ -14,7 +14,6 @@ There are no worker processes: every env lives in one ``RolloutEngine`` on one G
 throughput work use the engine directly (``venv.engine``): these wrappers copy every output to
 the host each step, which only makes sense for small ``n_rollout_threads``.
 """
-import sys
 import warnings
 from abc import ABC, abstractmethod
 
@@ -74,6 +73,11 @@ class _EngineVecEnv(ShareVecEnv):
     # :404, graph_buffer.py:229) behave the same, but N times fewer bytes cross PCIe and the host (784 MB -> 24.5 MB per
     # step at 512 envs x 32 agents).  Set to True for N materialised, writable copies.
     materialize_adj = False
+    # Ownership of the returned arrays.  0 (default): every array is fresh and the caller's for good, exactly like the arrays
+    # the reference's workers pipe back.  k > 0 (opt-in): the float64 arrays of one call are handed out again k calls later
+    # -- "valid until k steps later", for rollout loops that copy what they keep into their own buffers right away (the
+    # reference runner's insert does: graph_buffer.py:84-165) and do not want 20 MB of first-touch page faults per step.
+    reuse_outputs = 0
 
     def __init__(self, env_fns, device='cuda:0', emit_graph=True):
         specs = [fn() for fn in env_fns]
@@ -135,25 +139,25 @@ class _EngineVecEnv(ShareVecEnv):
         host.copy_(flat, non_blocking=True)
         torch.cuda.current_stream(self.engine.device).synchronize()
         arr, out, o = host.numpy(), [], 0
-        for t in tensors:
-            dst = self._fresh(tuple(t.shape))
+        for slot, t in enumerate(tensors):
+            dst = self._fresh(tuple(t.shape), slot)
             np.copyto(dst.reshape(-1), arr[o:o + t.numel()])
             out.append(dst)
             o += t.numel()
         return out
 
-    def _fresh(self, shape):
-        """A float64 array nobody else refers to.  Arrays handed out earlier come back into play once the caller has
-        dropped them (reference count back to this pool's own): the caller still owns what it keeps, exactly as with the
-        reference's fresh arrays, but a steady rollout loop stops paying first-touch page faults for 20 MB per step."""
-        pool = self.__dict__.setdefault('_pool', {}).setdefault(shape, [])
-        for a in pool:
-            if sys.getrefcount(a) == 3:   # the pool's list, the loop variable, getrefcount's argument
-                return a
-        a = np.empty(shape, dtype=np.float64)
-        if len(pool) < 8:
-            pool.append(a)
-        return a
+    def _fresh(self, shape, slot=0):
+        """A float64 array for output number ``slot`` of this call: new (the caller's for good) unless ``reuse_outputs = k``
+        opted into a ring of k generations per output."""
+        k = int(self.reuse_outputs)
+        if k <= 0:
+            return np.empty(shape, dtype=np.float64)
+        ring = self.__dict__.setdefault('_rings', {}).setdefault((slot, shape), [[], 0])
+        if len(ring[0]) < k:
+            ring[0].append(np.empty(shape, dtype=np.float64))
+            return ring[0][-1]
+        ring[1] = (ring[1] + 1) % k
+        return ring[0][ring[1] - 1]
 
     # beyond this many (env, agent) dicts per step the infos stay a lazy view (65 536 x 32 dicts per step cannot be built)
     EAGER_INFOS = 256

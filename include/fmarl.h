@@ -57,7 +57,11 @@ extern "C" {
 typedef struct FmarlConfig {
     int32_t scenario;        /* FMARL_SCENARIO_* */
     int32_t n_envs;          /* environments in this handle (n_rollout_threads of this shard) */
-    int32_t num_agents;      /* N */
+    int32_t num_agents;      /* N.  Limits the reference does not have (its Python loops take any N): navigation_graph 1..64 (the fair
+                              * assignment runs on one 64-lane wave per env); fair_graph_formation 1..32 and
+                              * nav_fairassign_fairrew_formation_graph 2..32 (32-bit occupancy masks, one env inside one wave).
+                              * fmarl_create / fmarl_state_bytes refuse other values with FMARL_EINVAL and a text naming the range;
+                              * the reference's own experiments use 3..10 agents (onpolicy/scripts/train_mpe.py:71-106). */
     int32_t num_landmarks;   /* L (navigation_graph needs L == N for the assignment) */
     int32_t num_obstacles;   /* O */
     int32_t num_walls;       /* W (<= 2: navigation_graph.py:289 has two wall axes) */
@@ -122,7 +126,9 @@ enum {
 /* World state: ONE caller-owned device buffer of fmarl_state_bytes() bytes holding the fields
  * below back to back (each 256-byte aligned, row-major, env-major), i.e. the SoA restatement of
  * multiagent/core.py:12-19,60-128 EntityState/Entity/Agent/Wall objects and the per-world
- * vectors of navigation_graph.py:212-225.  float64 where the reference is float64. */
+ * vectors of navigation_graph.py:212-225.  float64 where the reference holds real values in float64; integer-valued
+ * reference fields (counters, indices, flags) as i32 / i8 -- fmarl_get_state / fmarl_set_state copy the field in the dtype
+ * fmarl_state_field reports. */
 enum {
     FMARL_F_AGENT_POS = 0,     /* f64 (n, N, 2)  agent.state.p_pos                         */
     FMARL_F_AGENT_VEL,         /* f64 (n, N, 2)  agent.state.p_vel                         */
@@ -147,10 +153,10 @@ enum {
     FMARL_F_SLOT_OCC,          /* f64 (n, N)     formation: scenario.expected_poses_occupied */
     FMARL_F_SLOT_DELTA,        /* f64 (n, N)     formation: scenario.delta_dists            */
     FMARL_F_FORMATION_DONE,    /* f64 (n, N)     formation: world.formation_complete        */
-    FMARL_F_GOAL_OCC,          /* f64 (n, N)     fairnav: scenario.landmark_poses_occupied  */
-    FMARL_F_GOAL_HISTORY,      /* f64 (n, N)     fairnav: scenario.goal_history             */
-    FMARL_F_GOAL_REACHED,      /* f64 (n, N)     fairnav: scenario.goal_reached             */
-    FMARL_F_STATUS,            /* f64 (n, N)     fairnav: agent.status (0 / 1)              */
+    FMARL_F_GOAL_OCC,          /* f64 (n, N)     fairnav: scenario.landmark_poses_occupied (real-valued: 0, 1, a distance, 1 - a distance) */
+    FMARL_F_GOAL_HISTORY,      /* i8  (n, N)     fairnav: scenario.goal_history (reference: float array holding -1 or an agent index) */
+    FMARL_F_GOAL_REACHED,      /* i8  (n, N)     fairnav: scenario.goal_reached (reference: float array holding -1 or a goal index)   */
+    FMARL_F_STATUS,            /* i8  (n, N)     fairnav: agent.status (reference: Python bool)                                       */
     FMARL_F_RESET_FLAG,        /* i32 (n)        internal: envs picked by the last reset launch */
     FMARL_F_STAGE_AGENT_POS,   /* f64 (n, N, 2)  staged next episode (FMARL_FLAG_ASYNC_RESET) ...          */
     FMARL_F_STAGE_LANDMARK_POS,/* f64 (n, L, 2)                                                            */
@@ -172,6 +178,7 @@ enum {
 };
 #define FMARL_DTYPE_F64 0
 #define FMARL_DTYPE_I32 1
+#define FMARL_DTYPE_I8 2    /* small integer-valued fields of the reference (indices, flags): one byte instead of a float64 */
 
 /* --- lifetime ---------------------------------------------------------------------------- */
 
@@ -301,10 +308,13 @@ int fmarl_edge_fill(const float *adj, const int64_t *offsets, int64_t *edge_inde
  *   fmarl_edge_fill_state: edge_index i64 (2, capacity) rows | cols with node ids b * E + r, edge_attr f32 (capacity), in
  *       the row-major order of processAdj; edges beyond `capacity` are dropped (size the buffers with offsets[last], or
  *       with an upper bound when the host must not wait).  Call it after the fmarl_step / fmarl_reset whose adj it
- *       describes and before the next step.  edge_attr equals the adj entries bit for bit. */
+ *       describes and before the next step.  edge_attr equals the adj entries bit for bit.  The offsets must come from the
+ *       edge_nnz of THAT step's output set: a graph only ever writes inside [offsets[b], offsets[b + 1]), and `mismatch`
+ *       (device int32 counter, may be NULL) is incremented for every graph whose edges recomputed from the state do not
+ *       fill that range exactly (counts of another output set, a state rewritten in between). */
 int fmarl_edge_offsets(const int32_t *nnz, int n_envs, int graphs_per_env, int64_t *offsets, void *stream);
 int fmarl_edge_fill_state(void *handle, const void *state, const int64_t *offsets, int64_t *edge_index, float *edge_attr,
-                          int64_t capacity, int graphs_per_env, void *stream);
+                          int64_t capacity, int graphs_per_env, int32_t *mismatch, void *stream);
 
 /* Cross-GPU hand-off of the graph observation (navigation_graph; fair_graph_formation: see fmarl_step_record_words).  The reference's workers pipe node_obs /
  * adj to the learner with every step (onpolicy/envs/env_wrappers.py:988-996).  Between GPUs only the compact

@@ -621,6 +621,43 @@ def test_process_adj_matches_reference_semantics():
     assert ei2.shape[1] >= ei1.shape[1]
 
 
+def test_fused_process_adj_with_counts_of_another_state_stays_inside_each_graph():
+    """The fused processAdj takes its counts from the output set's edge_nnz and its edges from the LIVE state.  When the two
+    do not belong together (here: the state is rewritten between the step and process_adj) every graph still writes only
+    inside its own [offsets[b], offsets[b + 1]) -- no neighbour's range is touched -- and the engine's device counter says
+    how many graphs disagreed; in correct use it stays 0."""
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=2)
+    n = 50
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=3, count_edges=True)
+    eng.reset()
+    gen = torch.Generator(device=DEV); gen.manual_seed(1)
+    eng.step(torch.randint(0, 5, (n, 4), device=DEV, generator=gen, dtype=torch.int32))
+    ei, ea, off = eng.process_adj()
+    assert int(eng.edge_mismatch) == 0
+    good_ei, good_ea = ei.clone(), ea.clone()
+    st = eng.get_state()
+    pos = st['agent_pos'].copy()
+    pos[::2] = pos[::2] * 0.25            # every second env: agents pulled together -> more policy edges than counted
+    pos[1::2] = pos[1::2] + np.array([5.0, 0.0]) * np.arange(4)[None, :, None]   # the others: spread out -> fewer
+    eng.set_state(dict(agent_pos=pos))
+    cap = int(off[-1])
+    import ctypes as C
+    from fair_marl_amd import _lib
+    ei2 = torch.full((2, cap), -1, dtype=torch.int64, device=DEV)
+    ea2 = torch.full((cap,), -1.0, dtype=torch.float32, device=DEV)
+    _lib.check(eng.lib.fmarl_edge_fill_state(eng.handle, eng.state.data_ptr(), off.data_ptr(), ei2.data_ptr(), ea2.data_ptr(), cap, 1,
+                                             eng.edge_mismatch.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'fmarl_edge_fill_state')
+    assert int(eng.edge_mismatch) >= n // 2
+    o, ei2 = off.cpu().numpy(), ei2.cpu().numpy()
+    gaps = 0
+    for b in range(n):                     # whatever a graph wrote lies inside its own range and names its own nodes
+        for part in ei2[:, o[b]:o[b + 1]]:
+            w = part[part >= 0]
+            assert ((w >= b * cfg.E) & (w < (b + 1) * cfg.E)).all(), b
+            gaps += int((part < 0).sum())
+    assert gaps > 0                        # the spread-out envs left part of their (stale, too large) range unwritten
+
+
 def test_device_rollout_buffer_matches_reference_insert():
     """DeviceRolloutBuffer (GraphReplayBuffer layout, filled in place) vs oracle.runner_oracle.ReplayBuffer (pinned by
     the reference's GraphReplayBuffer + GMPERunner.insert, tests/test_runner_golden.py) fed by a twin engine."""
@@ -930,6 +967,37 @@ def test_captured_inserts_fill_masks_like_eager_inserts():
     with pytest.raises(RuntimeError, match='start at buffer step'):
         buf_b.step = 2
         cap.replay()
+
+
+@pytest.mark.parametrize('kw', SHARD_CASES, ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
+def test_info_planes_can_be_skipped_per_step(kw):
+    """step(emit_info=False) (FmarlOutputs.info = NULL for that call): the 14 info planes are not written -- the tensor keeps
+    the last step that wrote them -- while everything the reference's info_callback does to the WORLD (arrival times,
+    frozen distances, collision counters) still happens: states and all other outputs stay bit-identical to an engine that
+    emits the infos every step, and a step that emits again reports the same values (the runner reads the infos of an
+    episode's last step only: base_runner.py:197-276)."""
+    cfg = fm.EnvConfig(**kw)
+    n = 70
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=8)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=8)
+    a.reset(); b.reset()
+    gen = torch.Generator(device=DEV); gen.manual_seed(3)
+    prev = None
+    for t in range(2 * cfg.episode_length + 3):
+        act = torch.randint(0, 5, (n, cfg.N), device=DEV, generator=gen, dtype=torch.int32)
+        emit = (t + 1) % cfg.episode_length == 0 or t % 7 == 0
+        ra, rb = a.step(act), b.step(act, emit_info=emit)
+        for k in (0, 2, 4, 5):
+            assert torch.equal(ra[k], rb[k]), (t, k)
+        assert torch.equal(a.adj_env, b.adj_env)
+        if emit:
+            assert torch.equal(ra[6], rb[6]), t
+            prev = rb[6].clone()
+        elif prev is not None:
+            assert torch.equal(rb[6], prev), t
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
 
 
 def test_exhausted_rejection_sampling_is_reported():

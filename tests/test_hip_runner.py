@@ -392,3 +392,38 @@ def test_edge_offsets_prefix_sum_at_scale():
         _lib.check(lib.fmarl_edge_offsets(d.data_ptr(), n, reps, off.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'offsets')
         want = np.concatenate([[0], np.cumsum(np.repeat(nnz.astype(np.int64), reps))])
         assert np.array_equal(off.cpu().numpy(), want), (n, reps)
+
+
+def test_returned_arrays_belong_to_the_caller_unless_reuse_is_opted_into():
+    """Default: every array a wrapper returns is fresh -- one the caller still holds (directly, in a list, through a raw pointer)
+    is never rewritten by later steps, like the arrays the reference's workers pipe back.  ``reuse_outputs = k`` is the
+    explicit opt-in: the arrays of one call come back k calls later (valid until then), values unchanged in between."""
+    import argparse
+    args = argparse.Namespace(**json.loads(str(load('runner_nav.npz')['args'])))
+    fns = _env_fns(vars(args), 6, 3, fm.GraphMPEEnv)
+    venv = fm.GraphSubprocVecEnv(fns)
+    venv.reset()
+    rs = np.random.RandomState(0)
+    act = lambda: np.eye(5)[rs.randint(0, 5, size=(6, args.num_agents))]  # noqa: E731
+    kept = []
+    for t in range(6):
+        res = venv.step(act())
+        kept.append((res, [np.array(x, copy=True) for x in (res[0], res[2], res[3], res[4])]))
+    ids = set()
+    for res, copies in kept:
+        for x, c in zip((res[0], res[2], res[3], res[4]), copies):
+            assert np.array_equal(x, c)            # nothing the caller kept was overwritten
+        for x in (res[0], res[2], res[4]):
+            assert id(x) not in ids and x.flags.owndata and x.flags.writeable
+            ids.add(id(x))
+    venv.close()
+    venv = fm.GraphSubprocVecEnv(fns)
+    venv.reuse_outputs = 2
+    venv.reset()
+    outs = [venv.step(act()) for _ in range(5)]
+    assert outs[0][0] is outs[2][0] is outs[4][0] and outs[1][0] is outs[3][0] and outs[0][0] is not outs[1][0]
+    assert outs[0][4] is outs[2][4] and outs[0][4] is not outs[0][5]     # rewards and dones (same shape) have their own rings
+    last = np.array(outs[4][2], copy=True)
+    venv.step(act())                                                      # writes generation 1: generation 0 stays valid
+    assert np.array_equal(outs[4][2], last)
+    venv.close()

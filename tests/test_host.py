@@ -46,7 +46,7 @@ def test_state_layout_and_config_validation(lib):
         off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int()
         assert lib.fmarl_state_field(C.byref(c), fid, C.byref(off), C.byref(cnt), C.byref(dt)) == 0
         assert off.value % 256 == 0 and off.value >= prev_end
-        prev_end = off.value + cnt.value * (8 if dt.value == _lib.DTYPE_F64 else 4)
+        prev_end = off.value + cnt.value * _lib.DTYPE_BYTES[dt.value]
     assert prev_end <= total
     off, cnt, dt = C.c_size_t(), C.c_size_t(), C.c_int()
     lib.fmarl_state_field(C.byref(c), _lib.F_AGENT_POS, C.byref(off), C.byref(cnt), C.byref(dt))
@@ -146,6 +146,30 @@ def test_lazy_infos_match_reference_structure():
     assert [a['Time_taken'] for a in infos[0]] == list(rec[0, :, 8])
     f = LazyInfos(rec, 'fair_graph_formation')[0][1]
     assert len(f) == 12 and f['Formation_dist'] == rec[0, 1, 9] and 'Time_mean' not in f
+
+
+def test_agent_count_limits_are_named_at_the_boundary(lib):
+    """The reference's Python loops take any number of agents; the device kernels do not.  The limits stand next to
+    FmarlConfig.num_agents in include/fmarl.h and in INTEGRATION.md, and a config beyond them is refused with a text that
+    names the supported range (never a crash or a silently wrong launch)."""
+    import fair_marl_amd as fm
+    hdr = open(os.path.join(ROOT, 'include', 'fmarl.h')).read()
+    integ = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    for text in ('navigation_graph 1..64', 'fair_graph_formation 1..32', 'nav_fairassign_fairrew_formation_graph 2..32'):
+        assert text in hdr and text in integ, text
+    h = C.c_void_p()
+    for kw, want in ((dict(num_agents=65, num_landmarks=65), b'navigation_graph is built for num_agents in 1..64'),
+                     (dict(scenario_name='fair_graph_formation', num_agents=33, num_landmarks=1), b'fair_graph_formation is built for num_agents in 1..32'),
+                     (dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=33, num_landmarks=33),
+                      b'nav_fairassign_fairrew_formation_graph is built for num_agents in 2..32'),
+                     (dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=1, num_landmarks=1),
+                      b'nav_fairassign_fairrew_formation_graph is built for num_agents in 2..32')):
+        c = fm.EnvConfig(**kw).to_c(4)
+        assert lib.fmarl_create(C.byref(c), C.byref(h)) != 0 and want in lib.fmarl_last_error(), lib.fmarl_last_error()
+        assert lib.fmarl_state_bytes(C.byref(c)) == 0 and want in lib.fmarl_last_error()
+    for kw in (dict(num_agents=64, num_landmarks=64), dict(scenario_name='fair_graph_formation', num_agents=32, num_landmarks=1),
+               dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=32, num_landmarks=32)):
+        assert lib.fmarl_state_bytes(C.byref(fm.EnvConfig(**kw).to_c(4))) > 0   # the limits themselves are supported
 
 
 def test_shard_range_partitions_exactly():
