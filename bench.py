@@ -56,7 +56,7 @@ CONFIGS = {   # workload: a format string, filled with the number of envs the ru
 KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
-SECONDARY = (('cfg2', 'eager'), ('cfg2', 'graph'), ('cfg4', 'eager'), ('fnav', 'eager'), ('n10', 'eager'))
+SECONDARY = (('cfg2', 'rollout'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('n10', 'eager'))
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
@@ -113,18 +113,22 @@ def launch_bytes(cfg, agents, counts0, counts1):
 
 def secondary_line(name, mode, device, steps=300, warmup=50):
     """One more BASELINE config on this GPU: fresh engine, `warmup` untimed steps (one episode end), `steps` timed steps
-    (whole episodes), synchronised on both sides.  mode 'graph' = RolloutEngine.rollout replaying one hipGraph per episode."""
+    (whole episodes), synchronised on both sides.  mode 'rollout' = RolloutEngine.rollout(tape), the default way to run a tape
+    of actions: it replays one hipGraph per episode for launch-bound batches (n_envs x N < RolloutEngine.GRAPH_BELOW_AGENTS) and
+    steps eagerly otherwise; 'eager' = one fmarl_step call per step whatever the size; 'pipeline<k>' = k sub-batches."""
     spec = CONFIGS[name]
     cfg = fm.EnvConfig(**spec['env'])
     n = spec['n_envs']
     ep = cfg.episode_length
     steps, warmup = max(ep, steps // ep * ep), (warmup + ep - 1) // ep * ep
-    eng = fm.RolloutEngine(cfg, n, device=device, seed=1, tune_placement=0)
+    if mode.startswith('pipeline'):
+        return secondary_pipeline(name, int(mode[len('pipeline'):]), device, steps, warmup)
+    eng = fm.RolloutEngine(cfg, n, device=device, seed=1)   # (output placement probe as for any engine of this size)
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
     eng.reset()
-    use_graph = mode == 'graph'
+    use_graph = mode == 'rollout' and n * cfg.N < eng.GRAPH_BELOW_AGENTS   # what rollout() itself decides
     c0 = eng.launch_counts()
     if use_graph:   # the per-kernel hipEvents cannot live inside a graph: kernel time from an eager pass over two episodes
         eng.profile_enable(2 * ep)
@@ -152,7 +156,8 @@ def secondary_line(name, mode, device, steps=300, warmup=50):
     per_launch = launch_bytes(cfg, n * cfg.N, c0, c1)
     ceil_ms = store_ceiling_ms(eng)
     folded = c1[1] - c0[1] > 0
-    out = dict(config=name, workload=spec['workload'] % n, launch=('one hipGraph replay per episode (kernel_avg_ms from an eager pass)'
+    out = dict(config=name, workload=spec['workload'] % n, launch=('RolloutEngine.rollout: one hipGraph replay per episode, the staged reset a forked '
+                                                                 'branch of the graph (kernel_avg_ms from an eager pass)'
                                                                  if use_graph else 'one fmarl_step call per step'),
                value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup, ms_per_step=elapsed / steps * 1e3,
                kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel'),
@@ -161,6 +166,47 @@ def secondary_line(name, mode, device, steps=300, warmup=50):
                frac_of_box_ceiling=(ceil_ms / k_avg if ceil_ms else None))
     eng.close()
     del eng, tape
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_pipeline(name, k, device, steps, warmup):
+    """The same envs as k sub-batches on k streams (fair_marl_amd.PipelinedRollout; bit-identical results): the tail of one
+    sub-batch's launch overlaps the head of another's next step.  What a random-action rollout -- actions known ahead -- or an
+    alternating sampler gets out of the chip for the compute-heavy scenarios; `frac` is the whole job's algorithmic bytes per
+    step over the time per step (a launch that shares the chip is longer than it would be alone)."""
+    spec = CONFIGS[name]
+    cfg = fm.EnvConfig(**spec['env'])
+    n, ep = spec['n_envs'], cfg.episode_length
+    pipe = fm.PipelinedRollout(cfg, n, k=k, device=device, seed=1, tune_placement=0)
+    g = torch.Generator(device=device)
+    g.manual_seed(2000)
+    tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
+    pipe.reset()
+    for t in range(warmup):
+        pipe.step(tape[t % ep])
+    pipe.synchronize()
+    torch.cuda.synchronize(device)
+    for e in pipe.engines:
+        e.profile_enable(steps)
+    c0 = [e.launch_counts() for e in pipe.engines]
+    t0 = time.perf_counter()
+    for t in range(steps):
+        pipe.step(tape[t % ep])
+    pipe.synchronize()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [v for e in pipe.engines for v in e.profile_read()]
+    per_launch = float(np.mean([launch_bytes(cfg, (n // k) * cfg.N, a, e.launch_counts()) for a, e in zip(c0, pipe.engines)]))
+    job = per_launch * k / (elapsed / steps) / 1e9
+    out = dict(config=name, workload=spec['workload'] % n, launch='%d sub-batches of %d envs on their own streams, one fmarl_step call per '
+               'sub-batch and step' % (k, n // k), value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup,
+               ms_per_step=elapsed / steps * 1e3, kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel'),
+               kernel_avg_ms=float(np.mean(kernel_ms)), frac=job / HBM_PEAK_GBS,
+               frac_basis='whole job: algorithmic bytes per step of all envs / time per step (kernel_avg_ms is ONE sub-batch launch while others run)',
+               algorithmic_bytes_per_launch=per_launch, store_ceiling_ms=None, frac_of_box_ceiling=None)
+    pipe.close()
+    del pipe, tape
     torch.cuda.empty_cache()
     return out
 
@@ -230,6 +276,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='N=1: capture one episode of steps in a hipGraph and replay it '
                     '(launch-bound small batches, e.g. --config cfg2; --steps is rounded to whole episodes; with the staged reset the side stream '
                     'is a forked branch of the graph)')
+    ap.add_argument('--eager', action='store_true', help='N=1: one fmarl_step call per step even for a launch-bound batch (default there: '
+                    'graph replay, as RolloutEngine.rollout picks it)')
     ap.add_argument('--pipeline', type=int, default=1, help='step the env batch as this many sub-batches on their own streams '
                     '(fair_marl_amd.PipelinedRollout: the tail of one sub-batch\'s step kernel overlaps the head of the next one\'s); '
                     'no trajectory gather in this mode')
@@ -296,6 +344,9 @@ def main():
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
     workload = spec['workload'] % n_envs
+    if (not args.graph and not args.eager and world == 1 and not args.record_path and not args.rccl_selftest and args.pipeline <= 1
+            and n_envs * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS):
+        args.graph = True   # launch-bound batch: what RolloutEngine.rollout does by default
     if args.graph:
         if world > 1:
             raise SystemExit('bench.py: --graph is a single-GPU mode')

@@ -27,24 +27,25 @@ def one(pattern):
 
 
 def counter_mean(path, kernel, counter):
+    names = kernel if isinstance(kernel, tuple) else (kernel,)
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
-            if kernel in r['Kernel_Name'] and r['Counter_Name'] == counter]
+            if any(k in r['Kernel_Name'] for k in names) and r['Counter_Name'] == counter]
     return float(np.mean(vals)), float(np.max(vals)), len(vals)
 
 
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, cfg)))
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
-kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, 'step_kernel')
+kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
 w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), kname, 'WRITE_SIZE')
 traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
 traffic_full = (2.0 * f_max + w_max) * 1024.0
 tpath = os.path.join(dst, 'pmc_traffic.json')
 allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
-allt[cfg] = dict(hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
+allt[cfg] = dict(n_envs=bench['config']['n_envs_per_gpu'], hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
                  write_kib_mean=w_mean, launches=nf, source='%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
-                 '(separate passes), %s rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % (tag, kname))
+                 '(separate passes), %s rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % (tag, ' + '.join(kname) if isinstance(kname, tuple) else kname))
 json.dump(allt, open(tpath, 'w'), indent=1, sort_keys=True)
 
 rows = list(csv.DictReader(open(stats)))
@@ -54,14 +55,19 @@ with open(out, 'w') as f:
     f.write('Commands (tools/profile.sh, on the MI355X box): `python bench.py --config %s` (bench line); '
             '`rocprofv3 --kernel-trace --stats -- python3 bench.py --config %s --steps 200 --warmup 50 --no-cpu-baseline` '
             '(kernel table); `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` in separate passes over '
-            '`python3 bench.py --config %s --steps 30 --warmup 25 --no-cpu-baseline` (traffic).\n\n' % (cfg, cfg, cfg))
+            '`python3 bench.py --config %s --steps 50 --warmup 25 --no-cpu-baseline` (traffic); all with `--no-secondary` '
+            '(the other configs of the default line run the same kernel names).\n\n' % (cfg, cfg, cfg))
     f.write('## bench.py JSON line\n\n```json\n%s\n```\n\n' % json.dumps(bench, indent=1))
     f.write('## rocprofv3 kernel stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n')
     for r in rows[:8]:
         f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'].split('(')[0][:60], r['Calls'], float(r['AverageNs']) / 1e3,
                                                        float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
     rl = bench['roofline']
-    krow = [r for r in rows if kname in r['Name']][0]
+    knames = kname if isinstance(kname, tuple) else (kname,)
+    krows = [r for r in rows if any(r['Name'].split('(')[0].split('::')[-1] == k for k in knames)]
+    calls = sum(int(r['Calls']) for r in krows)
+    krow = dict(AverageNs=sum(float(r['TotalDurationNs']) for r in krows) / calls, Calls=calls)
+    kname = ' + '.join(knames)
     traced = [l for l in open(os.path.join(src, 'trace.log')) if l.startswith('{')]
     traced_ms = json.loads(traced[-1])['roofline']['kernel_avg_ms'] if traced else float('nan')
     f.write('\n%s average: rocprofv3 %.1f us over %s launches vs %.1f us measured live by bench.py with hipEvents '
