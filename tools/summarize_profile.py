@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, cfg = (sys.argv + ['r1', 'cfg3'])[1:3]
 src = os.path.join(ROOT, 'gpurun_out', tag)
 dst = os.path.join(ROOT, 'profiles')
+stem = tag if tag.endswith('_' + cfg) else '%s_%s' % (tag, cfg)
 os.makedirs(dst, exist_ok=True)
 
 
@@ -34,7 +35,7 @@ def counter_mean(path, kernel, counter):
 
 
 stats = one('trace/*/*kernel_stats.csv')
-shutil.copy(stats, os.path.join(dst, '%s_%s_kernel_stats.csv' % (tag, cfg)))
+shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % stem))
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
 kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
@@ -49,7 +50,7 @@ allt[cfg] = dict(n_envs=bench['config']['n_envs_per_gpu'], hbm_bytes_per_launch=
 json.dump(allt, open(tpath, 'w'), indent=1, sort_keys=True)
 
 rows = list(csv.DictReader(open(stats)))
-out = os.path.join(dst, '%s_%s_summary.md' % (tag, cfg))
+out = os.path.join(dst, '%s_summary.md' % stem)
 with open(out, 'w') as f:
     f.write('# %s %s: bench line, kernel trace, HBM counters\n\n' % (tag, cfg))
     f.write('Commands (tools/profile.sh, on the MI355X box): `python bench.py --config %s` (bench line); '
