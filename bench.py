@@ -56,7 +56,8 @@ CONFIGS = {   # workload: a format string, filled with the number of envs the ru
 KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
-SECONDARY = (('cfg2', 'rollout'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('n10', 'eager'))
+SECONDARY = (('cfg3', 'span'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'),
+             ('fnav', 'eager'), ('n10', 'eager'), ('n10', 'span'))
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
@@ -111,11 +112,21 @@ def launch_bytes(cfg, agents, counts0, counts1):
     return agents * (algorithmic_bytes(cfg) * (launches - quiet) + algorithmic_bytes(cfg, emit=False) * quiet) / max(1, launches)
 
 
+# envs per workgroup for the span launches of the secondary lines (0 = the library's choice): a span kernel keeps a workgroup's
+# slot for a whole run of steps, so the number of workgroups should be a multiple of what the chip holds at once
+SPAN_EPB = {'cfg3': 4, 'n10': 16}
+
+
 def secondary_line(name, mode, device, steps=300, warmup=50):
-    """One more BASELINE config on this GPU: fresh engine, `warmup` untimed steps (one episode end), `steps` timed steps
-    (whole episodes), synchronised on both sides.  mode 'rollout' = RolloutEngine.rollout(tape), the default way to run a tape
-    of actions: it replays one hipGraph per episode for launch-bound batches (n_envs x N < RolloutEngine.GRAPH_BELOW_AGENTS) and
-    steps eagerly otherwise; 'eager' = one fmarl_step call per step whatever the size; 'pipeline<k>' = k sub-batches."""
+    """One more BASELINE config on this GPU: fresh engine, `warmup` untimed steps (whole episodes), `steps` timed steps (whole
+    episodes), synchronised on both sides, all through RolloutEngine.rollout(tape, mode):
+      'eager' = one fmarl_step call per step (what a policy in the loop gets);
+      'span'  = fmarl_step_span: the steps between episode ends as ONE launch in which every workgroup walks its own envs through
+                time, the step that ends the episode as a launch of its own (random-action / scripted rollouts: actions known
+                ahead, the metric of BASELINE.json);
+      'graph' = one hipGraph replay per episode (launch-bound batches);
+      'pipeline<k>' = k sub-batches on k streams.
+    kernel_avg_ms is per STEP in every mode (a span launch's duration divided by its steps)."""
     spec = CONFIGS[name]
     cfg = fm.EnvConfig(**spec['env'])
     n = spec['n_envs']
@@ -123,47 +134,48 @@ def secondary_line(name, mode, device, steps=300, warmup=50):
     steps, warmup = max(ep, steps // ep * ep), (warmup + ep - 1) // ep * ep
     if mode.startswith('pipeline'):
         return secondary_pipeline(name, int(mode[len('pipeline'):]), device, steps, warmup)
-    eng = fm.RolloutEngine(cfg, n, device=device, seed=1)   # (output placement probe as for any engine of this size)
+    eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=SPAN_EPB.get(name, 0) if mode == 'span' else 0)
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
     eng.reset()
-    use_graph = mode == 'rollout' and n * cfg.N < eng.GRAPH_BELOW_AGENTS   # what rollout() itself decides
-    c0 = eng.launch_counts()
-    if use_graph:   # the per-kernel hipEvents cannot live inside a graph: kernel time from an eager pass over two episodes
-        eng.profile_enable(2 * ep)
-        for _ in range(2):
-            eng.rollout(tape, use_graph=False)
-        torch.cuda.synchronize(device)
-        kernel_ms = eng.profile_read()
-        c1 = eng.launch_counts()
-        eng.profile_enable(0)
-    for _ in range(warmup // ep):
-        eng.rollout(tape, use_graph=use_graph)
+    timed = mode if mode != 'graph' else 'eager'   # hipEvents cannot live inside a graph: kernel time from an eager pass
+    for _ in range(max(1, warmup // ep)):
+        eng.rollout(tape, mode=timed)
     torch.cuda.synchronize(device)
-    if not use_graph:
-        eng.profile_enable(steps)
-        c0 = eng.launch_counts()
+    eng.profile_enable(steps)
+    c0 = eng.launch_counts()
+    if mode == 'graph':
+        for _ in range(2):
+            eng.rollout(tape, mode='eager')
+        torch.cuda.synchronize(device)
+        kernel_ms, c1 = eng.profile_read(), eng.launch_counts()
+        eng.profile_enable(0)
+        eng.rollout(tape, mode='graph')          # capture + first replay
+        torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps // ep):
-        eng.rollout(tape, use_graph=use_graph)
+        eng.rollout(tape, mode=mode)
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    if not use_graph:
-        kernel_ms = eng.profile_read()
-        c1 = eng.launch_counts()
-    k_avg = float(np.mean(kernel_ms))
-    per_launch = launch_bytes(cfg, n * cfg.N, c0, c1)
+    if mode != 'graph':
+        kernel_ms, c1 = eng.profile_read(), eng.launch_counts()
+    k_step = float(np.sum(kernel_ms)) / (c1[0] - c0[0])       # step-kernel time per step (a span launch covers many)
+    per_step = launch_bytes(cfg, n * cfg.N, c0, c1)
     ceil_ms = store_ceiling_ms(eng)
     folded = c1[1] - c0[1] > 0
-    out = dict(config=name, workload=spec['workload'] % n, launch=('RolloutEngine.rollout: one hipGraph replay per episode, the staged reset a forked '
-                                                                 'branch of the graph (kernel_avg_ms from an eager pass)'
-                                                                 if use_graph else 'one fmarl_step call per step'),
+    kern = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
+    if mode == 'span':
+        kern = {'fair_graph_formation': 'formation_span_kernel + formation_kernel<true>'}.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel')
+    out = dict(config=name, mode=mode, workload=spec['workload'] % n,
+               launch={'eager': 'one fmarl_step call per step',
+                       'span': 'fmarl_step_span: one launch per run of steps between episode ends (%d envs per workgroup), the episode-ending '
+                               'step a launch of its own' % eng.envs_per_workgroup,
+                       'graph': 'one hipGraph replay per episode, the staged reset a forked branch of the graph (kernel_avg_ms from an eager pass)'}[mode],
                value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup, ms_per_step=elapsed / steps * 1e3,
-               kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel'),
-               kernel_avg_ms=k_avg, frac=per_launch / (k_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               algorithmic_bytes_per_launch=per_launch, store_ceiling_ms=ceil_ms,
-               frac_of_box_ceiling=(ceil_ms / k_avg if ceil_ms else None))
+               kernel=kern, kernel_avg_ms=k_step, kernel_launches=len(kernel_ms), frac=per_step / (k_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               algorithmic_bytes_per_step=per_step, store_ceiling_ms=ceil_ms,
+               frac_of_box_ceiling=(ceil_ms / k_step if ceil_ms else None))
     eng.close()
     del eng, tape
     torch.cuda.empty_cache()
@@ -199,12 +211,12 @@ def secondary_pipeline(name, k, device, steps, warmup):
     kernel_ms = [v for e in pipe.engines for v in e.profile_read()]
     per_launch = float(np.mean([launch_bytes(cfg, (n // k) * cfg.N, a, e.launch_counts()) for a, e in zip(c0, pipe.engines)]))
     job = per_launch * k / (elapsed / steps) / 1e9
-    out = dict(config=name, workload=spec['workload'] % n, launch='%d sub-batches of %d envs on their own streams, one fmarl_step call per '
+    out = dict(config=name, mode='pipeline%d' % k, workload=spec['workload'] % n, launch='%d sub-batches of %d envs on their own streams, one fmarl_step call per '
                'sub-batch and step' % (k, n // k), value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup,
                ms_per_step=elapsed / steps * 1e3, kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel'),
                kernel_avg_ms=float(np.mean(kernel_ms)), frac=job / HBM_PEAK_GBS,
                frac_basis='whole job: algorithmic bytes per step of all envs / time per step (kernel_avg_ms is ONE sub-batch launch while others run)',
-               algorithmic_bytes_per_launch=per_launch, store_ceiling_ms=None, frac_of_box_ceiling=None)
+               algorithmic_bytes_per_step=per_launch * k, store_ceiling_ms=None, frac_of_box_ceiling=None)
     pipe.close()
     del pipe, tape
     torch.cuda.empty_cache()

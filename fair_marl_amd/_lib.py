@@ -38,6 +38,10 @@ class FmarlConfig(C.Structure):
                 ('seed', C.c_uint64), ('envs_per_workgroup', C.c_int32), ('reserved0', C.c_int32)]
 
 
+class FmarlSpan(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info', 'edge_nnz', 'graph_record', 'actions')]
+
+
 class FmarlOutputs(C.Structure):
     _fields_ = [('obs', C.c_void_p), ('node_obs', C.c_void_p), ('adj', C.c_void_p), ('reward', C.c_void_p),
                 ('done', C.c_void_p), ('info', C.c_void_p), ('edge_nnz', C.c_void_p), ('graph_record', C.c_void_p)]
@@ -55,6 +59,7 @@ _SIGS = {
     'fmarl_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs), C.c_void_p]),
     'fmarl_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs),
                              C.c_int, C.c_void_p]),
+    'fmarl_step_span': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FmarlOutputs), C.POINTER(FmarlSpan), C.c_void_p]),
     'fmarl_get_phase': (C.c_int, [C.c_void_p]),
     'fmarl_set_phase': (C.c_int, [C.c_void_p, C.c_int]),
     'fmarl_state_changed': (C.c_int, [C.c_void_p]),

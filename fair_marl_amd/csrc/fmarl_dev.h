@@ -94,6 +94,45 @@ struct Params {
     int *place_fails, *st_place_fails;   // placements accepted after kMaxTries colliding draws (live / staged episode)
 };
 
+// fmarl_step_span: per-step strides (elements) of the outputs and of the action tape.
+struct SpanStrides { long long obs, node_obs, adj, reward, done, info, edge_nnz, graph_record, actions; };
+__device__ __forceinline__ FmarlOutputs span_outputs(const FmarlOutputs &o, const SpanStrides &s, int t) {
+    FmarlOutputs ot = o;
+    if (ot.obs) ot.obs += (size_t)t * s.obs;
+    if (ot.node_obs) ot.node_obs += (size_t)t * s.node_obs;
+    if (ot.adj) ot.adj += (size_t)t * s.adj;
+    if (ot.reward) ot.reward += (size_t)t * s.reward;
+    if (ot.done) ot.done += (size_t)t * s.done;
+    if (ot.info) ot.info += (size_t)t * s.info;
+    if (ot.edge_nnz) ot.edge_nnz += (size_t)t * s.edge_nnz;
+    if (ot.graph_record) ot.graph_record += (size_t)t * s.graph_record;
+    return ot;
+}
+// The shapes and table offsets of `p`, made opaque: what a step derives from them once per launch (the emission's source-offset
+// tables, uses of the fast-division constants) must not be hoisted out of a span kernel's time loop and stay live across a whole
+// step -- the kernel would spill.
+__device__ __forceinline__ Params span_params(const Params &p) {
+    Params q = p;
+    const int z = pin_sgpr(0);   // an opaque zero: (invariant + z) is loop-variant to the compiler, yet can be re-formed at every use
+#define FMARL_PIN(f) q.f = p.f + z;
+    FMARL_PIN(N) FMARL_PIN(E) FMARL_PIN(F) FMARL_PIN(L) FMARL_PIN(O) FMARL_PIN(W) FMARL_PIN(D) FMARL_PIN(epb) FMARL_PIN(epw) FMARL_PIN(n_envs)
+    FMARL_PIN(lds_env_bytes) FMARL_PIN(lds_pos) FMARL_PIN(lds_agentf) FMARL_PIN(lds_ego) FMARL_PIN(lds_stat) FMARL_PIN(lds_wall)
+    FMARL_PIN(lds_flag) FMARL_PIN(lds_posf) FMARL_PIN(lds_wallf) FMARL_PIN(lds_constf) FMARL_PIN(lds_cnt) FMARL_PIN(lds_stage)
+    FMARL_PIN(stage_wave_bytes) FMARL_PIN(stat_stride) FMARL_PIN(vec_node) FMARL_PIN(vec_adj) FMARL_PIN(scan_stats)
+    FMARL_PIN(feat_global) FMARL_PIN(has_wallf) FMARL_PIN(has_posf) FMARL_PIN(lds2_bytes) FMARL_PIN(f_rows)
+    FMARL_PIN(f_slot_new) FMARL_PIN(f_slot_old) FMARL_PIN(f_g) FMARL_PIN(f_masks) FMARL_PIN(f_theta) FMARL_PIN(f_words)
+    FMARL_PIN(n_D) FMARL_PIN(n_minprox) FMARL_PIN(n_occ) FMARL_PIN(n_match) FMARL_PIN(n_rows) FMARL_PIN(n_words)
+    FMARL_PIN(dNEF.m) FMARL_PIN(dEF.m) FMARL_PIN(dF.m) FMARL_PIN(dEE.m) FMARL_PIN(dE.m) FMARL_PIN(dNE.m) FMARL_PIN(dC4.m) FMARL_PIN(dNC4.m)
+    FMARL_PIN(dEE4.m) FMARL_PIN(dE4.m)
+#undef FMARL_PIN
+    return q;
+}
+// between two steps of a span: a workgroup re-reads from global memory what it wrote itself
+__device__ __forceinline__ void span_step_done() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+}
+
 // Ordering point between phases of ONE wave that talk through LDS (kernels whose envs each live inside one wave): LDS
 // executes a wave's instructions in order, the fence keeps the compiler from moving accesses across.
 __device__ __forceinline__ void wave_sync() {

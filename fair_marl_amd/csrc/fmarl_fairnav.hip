@@ -491,8 +491,8 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
 //               step (three launches that nearly always find nothing to do: 31 % of the step time at 65 536 x 3).
 // STEP = false: the observation part of an explicit reset (fmarl_reset: placement and assignment by their own kernels).
 template <bool STEP>
-__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
-                                                           const float *action_vec, int auto_reset) {
+__device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
+                                             const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const bool ended = fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset, false, false);
     if (!STEP) return;
@@ -510,6 +510,12 @@ __global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutput
     __threadfence_block();   // the reset pass re-reads the state of the placed envs from global memory
     __syncthreads();
     fairnav_pass<false>(p, o, lds, nullptr, nullptr, 0, true, ended);
+}
+
+template <bool STEP>
+__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                           const float *action_vec, int auto_reset) {
+    fairnav_body<STEP>(p, o, action_idx, action_vec, auto_reset);
 }
 
 // Learner-side reconstruction of node_obs / adj of nav_fairassign_fairrew_formation_graph envs from the gathered records:

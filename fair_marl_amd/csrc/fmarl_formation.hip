@@ -271,8 +271,8 @@ __device__ __forceinline__ void travelled_stats(const double *pd, const double *
 // STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877)
 // STEP = false: observation of freshly reset envs (MultiAgentGraphEnv.reset, environment.py:892-897)
 template <bool STEP>
-__global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
-                                                             const float *action_vec, int auto_reset) {
+__device__ __forceinline__ void formation_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
+                                               const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, N = p.N;
     const int env0 = blockIdx.x * p.epb;
@@ -567,6 +567,22 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
     if (FMARL_SKIP(p, 32)) return;
     formation_emit_rows(p, o, lds, env0, el0w, nenv_w, lane);
     emit_adj(p, o, lds, env0, el0w, el0w + nenv_w, lane, 64);
+}
+
+template <bool STEP>
+__global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                             const float *action_vec, int auto_reset) {
+    formation_body<STEP>(p, o, action_idx, action_vec, auto_reset);
+}
+
+// fmarl_step_span for fair_graph_formation: T steps of the workgroup's own envs in one launch (no episode ends inside).
+__global__ __launch_bounds__(kThreads, 4) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, int T) {
+    for (int t = 0; t < T; ++t) {
+        const Params q = span_params(p);
+        const FmarlOutputs ot = span_outputs(o, s, t);
+        formation_body<true>(q, ot, action_idx + (size_t)t * s.actions, nullptr, 0);
+        span_step_done();
+    }
 }
 
 // Learner-side reconstruction of node_obs / adj of fair_graph_formation envs from the gathered records: the per-step

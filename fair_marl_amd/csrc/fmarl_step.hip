@@ -780,4 +780,19 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
     step_body<true>(p, o, action_idx, action_vec, auto_reset);
 }
 
+// A run of T consecutive steps of the SAME workgroup's envs in one launch (fmarl_step_span): envs never interact, so a
+// workgroup can walk its own envs through time without waiting for the rest of the batch.  Step t reads the actions at
+// action_idx + t * span.actions and writes the outputs shifted by the span's per-step strides (0 = the same buffer every
+// step).  No episode ends inside a span (the host splits there).  The state goes through global memory between the steps
+// (a workgroup re-reads what it wrote itself: workgroup-scope release / acquire around the barrier).
+__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_span_kernel(
+    Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, int T) {
+    for (int t = 0; t < T; ++t) {
+        const Params q = span_params(p);
+        const FmarlOutputs ot = span_outputs(o, s, t);
+        step_body<false>(q, ot, action_idx + (size_t)t * s.actions, nullptr, 0);
+        span_step_done();
+    }
+}
+
 }  // namespace fmarl

@@ -444,6 +444,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_end_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_span_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_span_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)rebuild_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
@@ -492,10 +494,15 @@ int fmarl_destroy(void *handle) {
     Handle *h = (Handle *)handle;
     DeviceGuard on_device(h);
     if (h) {
+        // (a handle may be destroyed -- e.g. by a garbage collector -- while some OTHER stream of the process is capturing:
+        // the synchronisation below must not invalidate that capture)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
         drop_events(h);
         if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
         if (h->ev_commit) (void)hipEventDestroy(h->ev_commit);
         if (h->ev_staged) (void)hipEventDestroy(h->ev_staged);
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
     }
     delete h;
     return FMARL_OK;
@@ -659,6 +666,57 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
             ++h->counts[2];
             if (h->lockstep) h->host_step = 0;
             h->episode_started = true;
+        }
+    }
+    return FMARL_OK;
+}
+
+int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_steps, const FmarlOutputs *outs,
+                    const FmarlSpan *span, void *stream) {
+    Handle *h = (Handle *)handle;
+    if (!h || !state || !outs || !span || !action_idx || n_steps < 0) return fail(FMARL_EINVAL, "fmarl_step_span: bad argument");
+    const int sc = h->cfg.scenario;
+    hipStream_t st = (hipStream_t)stream;
+    SpanStrides s = {span->obs, span->node_obs, span->adj, span->reward, span->done, span->info, span->edge_nnz, span->graph_record, span->actions};
+    int t = 0;
+    while (t < n_steps) {
+        // steps that certainly end no episode go out as one span launch; the first step after a reset (it enqueues the
+        // staging), the step that ends an episode and envs out of lockstep go through fmarl_step.  The third scenario's
+        // episodes end env by env and its step is one workgroup's dependent chain, not a store stream: a span kernel of it
+        // measured SLOWER than a launch per step (0.086 vs 0.075 ms per step, profiles/r3_notes.md), so it always steps.
+        int k = 0;
+        if (sc != FMARL_SCENARIO_FAIRNAV && h->lockstep && !h->stage_pending) k = h->cfg.episode_length - 1 - h->host_step;
+        if (k > n_steps - t) k = n_steps - t;
+        FmarlOutputs o = *outs;
+        if (o.obs) o.obs += (size_t)t * span->obs;
+        if (o.node_obs) o.node_obs += (size_t)t * span->node_obs;
+        if (o.adj) o.adj += (size_t)t * span->adj;
+        if (o.reward) o.reward += (size_t)t * span->reward;
+        if (o.done) o.done += (size_t)t * span->done;
+        if (o.info) o.info += (size_t)t * span->info;
+        if (o.edge_nnz) o.edge_nnz += (size_t)t * span->edge_nnz;
+        if (o.graph_record) o.graph_record += (size_t)t * span->graph_record;
+        const int32_t *a = action_idx + (size_t)t * span->actions;
+        if (k >= 2) {
+            DeviceGuard on_device(h);
+            Params p = bind(h, state);
+            if (!outputs_aligned(p, &o)) return fail(FMARL_EINVAL, "fmarl_step_span: node_obs / adj must be 16-byte aligned for this shape");
+            const bool prof = h->ev && h->ev_n < h->ev_cap;
+            if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
+            if (sc == FMARL_SCENARIO_FORMATION)
+                hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, k);
+            else
+                hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, k);
+            if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
+            HIP_OK(hipGetLastError());
+            if (h->lockstep) h->host_step += k;
+            h->episode_started = false;
+            h->counts[0] += k;
+            t += k;
+        } else {
+            int rc = fmarl_step(handle, state, a, nullptr, &o, FMARL_RESET_AUTO, stream);
+            if (rc) return rc;
+            ++t;
         }
     }
     return FMARL_OK;

@@ -81,6 +81,33 @@ class DeviceRolloutBuffer(object):
         self.step = t + 1
         return self._sets[t + 1]
 
+    def insert_span(self, action_tape):
+        """``insert_step(action_tape[t])`` for every t through ONE ``fmarl_step_span`` call: the time slots are contiguous
+        (T + 1, n, ...) arrays, so step t's obs / node_obs / adj land in slot ``step + t + 1`` and its reward / done at index
+        ``step + t`` by per-step strides; the masks of the runner's insert are formed for all steps at once afterwards.
+        Same buffer contents as T ``insert_step`` calls, bit for bit.  (The info planes are one array per slot: the planes
+        of the slot the span starts in receive every step's infos, the last step's are what ``process_infos`` sees.)"""
+        eng, t0 = self.engine, self.step
+        tape = action_tape.to(eng.device)
+        T = int(tape.shape[0])
+        if t0 + T > self.T:
+            raise RuntimeError('tape of %d steps does not fit behind step %d of %d' % (T, t0, self.T))
+        n, N = eng.n_envs, eng.cfg.N
+        first = self._sets[t0 + 1]
+        eng.use_outputs(first)
+        eng.step_span(tape, strides=dict(obs=self.obs[0].numel(), node_obs=self.node_obs[0].numel(), adj=self.adj_env[0].numel(),
+                                         reward=n * N, done=n * N))
+        done = self.dones[t0:t0 + T].to(torch.bool)                         # (T, n, N)
+        done_env = done.all(dim=2, keepdim=True)
+        self.masks[t0 + 1:t0 + T + 1] = (~done).to(torch.float32).unsqueeze(-1)
+        self.active_masks[t0 + 1:t0 + T + 1] = (~(done & ~done_env)).to(torch.float32).unsqueeze(-1)
+        self.step = t0 + T
+        last = self._sets[self.step]
+        if first.info_planes is not None and last is not first:
+            last.info_planes.copy_(first.info_planes)                       # the infos of the last step, where insert_step leaves them
+        eng.use_outputs(last)
+        return last
+
     def capture(self, action_tape):
         """Capture ``insert_step(action_tape[t])`` for every t -- the step kernels writing their slots AND the masks /
         active_masks of the runner's insert -- into one hipGraph.  ``replay()`` on the returned object runs the rollout
@@ -91,6 +118,8 @@ class DeviceRolloutBuffer(object):
         start = self.step
         if start + tape.shape[0] > self.T:
             raise RuntimeError('tape of %d steps does not fit behind step %d of %d' % (tape.shape[0], start, self.T))
+        import gc
+        gc.collect()   # nothing may be destroyed (streams, events, other graphs) while this stream captures
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.device(dev), torch.cuda.graph(graph):

@@ -231,6 +231,24 @@ int fmarl_reset(void *handle, void *state, const uint8_t *env_mask,
 int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float *action_vec,
                const FmarlOutputs *outs, int auto_reset, void *stream);
 
+/* A run of n_steps consecutive steps from an action tape in as few launches as possible (action indices; any scenario, any
+ * state of the handle): equivalent to n_steps fmarl_step(..., FMARL_RESET_AUTO ...) calls where step t reads action_idx + t *
+ * span->actions and writes the outputs of `outs` shifted by the span's per-step strides (in elements; 0 = every step writes the
+ * same buffer, e.g. a rollout that only needs the last observation; the slots of a rollout buffer laid out (T, n, ...) have
+ * stride n * ...).  Envs never interact, so inside a span every workgroup walks its own envs through the steps without waiting
+ * for the rest of the batch: no per-step launch, no per-step head and tail of the grid.  The step that ends an episode is a
+ * launch of its own (it commits / resets and, with the staged reset, waits for the staging that ran beside the span); so are
+ * the first step after a reset (it enqueues that staging), every step while the envs are not in lockstep, and every step of
+ * nav_fairassign_fairrew_formation_graph (whose step is a dependent chain, not a store stream: a span of it is slower).
+ * The scripted / random-action rollout of the reference's throughput runs; a policy in the loop needs fmarl_step.
+ * Measured (profiles/r3_notes.md): 10 agents x 65 536 envs 0.250 -> 0.199 ms per step, 3 agents x 4 096 envs 14.5 -> 11.5 us. */
+typedef struct FmarlSpan {
+    int64_t obs, node_obs, adj, reward, done, info, edge_nnz, graph_record;   /* per-step strides of the outputs, in elements */
+    int64_t actions;                                                             /* per-step stride of action_idx (n * N for a dense tape) */
+} FmarlSpan;
+int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_steps, const FmarlOutputs *outs,
+                    const FmarlSpan *span, void *stream);
+
 /* Host-side mirror of the envs' common step counter: steps since the last reset of all envs, or -1 when the envs are not
  * known to be in lockstep (masked resets, fmarl_set_state, graphs captured with FMARL_RESET_AUTO, fairnav).  No device access. */
 int fmarl_get_phase(void *handle);

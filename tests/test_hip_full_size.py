@@ -109,3 +109,27 @@ def test_full_batch_rollout_through_episode_ends_vs_oracle(case):
         assert torch.equal(torch.sort(gm, dim=1).values, torch.arange(N, device=DEV, dtype=torch.int32).expand(n, N))
     ep = eng.field('episode')
     assert int(ep.min()) >= 3   # the hidden make_world reset + reset() + two episode ends
+
+
+@pytest.mark.parametrize('case', ['cfg3', 'n10', 'cfg4'])
+def test_full_batch_step_span_equals_step_by_step(case):
+    """fmarl_step_span at the benchmarked size: 65 536 envs, two episodes + 3 steps from one tape, against an engine stepping
+    the same tape one launch per step (the path the test above pins against the oracle): final state and outputs bit for bit."""
+    c = CASES[case]
+    cfg = fm.EnvConfig(**c['kw'])
+    n, N, T = N_ENVS, cfg.N, 2 * cfg.episode_length + 3
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0)
+    gen = torch.Generator(device=DEV); gen.manual_seed(9)
+    tape = torch.randint(0, 5, (T, n, N), device=DEV, generator=gen, dtype=torch.int32)
+    a.reset(); b.reset()
+    for t in range(T):
+        a.step(tape[t])
+    b.rollout(tape)                      # mode 'span' by default for these scenarios
+    torch.cuda.synchronize()
+    assert b.launch_counts()[0] == T and a.phase == b.phase == 3
+    for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done', 'info'):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    for k in a._fields:
+        if not k.startswith(('stage_', 'internal_')) and k != 'reset_flag':
+            assert torch.equal(a.field(k), b.field(k)), k

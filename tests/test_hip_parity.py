@@ -729,6 +729,8 @@ def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
     gen = torch.Generator(device=DEV); gen.manual_seed(2)
     tape = torch.randint(0, 5, (T, n, 5), device=DEV, generator=gen, dtype=torch.int32)
     eager.reset(); graph.reset()
+    import gc
+    gc.collect()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -752,6 +754,8 @@ def test_whole_episode_captured_in_a_hip_graph_replays_bit_identically():
     staged.reset(); eager.reset()
     for t in range(3):   # some eager steps first: a staging is in flight / done when the capture begins
         staged.step(tape[t]); eager.step(tape[t])
+    import gc
+    gc.collect()
     torch.cuda.synchronize()
     g2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g2):
@@ -841,17 +845,19 @@ def test_staged_reset_is_captured_as_a_forked_branch(N, O, W, n, T):
                 eager.step(a); graph.step(a)
             same('eager episode')
     assert int(eager.get_state()['episode'].min()) >= 2 + 7
-    # RolloutEngine.rollout: launch-bound batches replay a cached graph, others step eagerly -- same results
+    # RolloutEngine.rollout(mode='graph'): one cached graph per (tape, length, output set) -- same results as eager stepping
     for rep in range(2):
         tape.copy_(torch.randint(0, 5, (2 * T, n, N), device=DEV, generator=gen, dtype=torch.int32))
-        graph.rollout(tape)
-        eager.rollout(tape, use_graph=False)
+        graph.rollout(tape, mode='graph')
+        eager.rollout(tape, mode='eager')
         same('rollout %d' % rep)
-    assert len(graph._rollout_graphs) == (1 if n * N < graph.GRAPH_BELOW_AGENTS else 0)
+    assert len(graph._rollout_graphs) == 1
     # refused: not from the first step after a reset / not whole episodes (their staging could not be joined inside the graph)
     graph.step(tape[0]); eager.step(tape[0])
     with pytest.raises(RuntimeError, match='whole episodes'):
         graph.capture_steps(tape, lockstep=True)
+    import gc
+    gc.collect()   # (torch no longer collects before a capture; a cyclic collection inside it may destroy streams / graphs)
     with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='first step after a reset'):
         g3 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g3):
@@ -998,6 +1004,85 @@ def test_info_planes_can_be_skipped_per_step(kw):
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize('geom', [0, 3, 'full'])
+@pytest.mark.parametrize('kw', SHARD_CASES + [dict(num_agents=32, num_landmarks=32, num_obstacles=8, episode_length=7),
+                                              dict(num_agents=10, num_landmarks=10, num_obstacles=3, episode_length=7)],
+                         ids=lambda kw: '%s-N%d' % (kw.get('scenario_name', 'navigation_graph'), kw['num_agents']))
+def test_step_span_equals_step_by_step(kw, geom):
+    """fmarl_step_span (RolloutEngine.step_span / rollout): the steps between episode ends as ONE launch in which every
+    workgroup walks its own envs through time.  Two and a half episodes from a tape, starting mid-episode: every step's
+    outputs -- written through per-step strides into (T, n, ...) arrays -- the final state and the launch bookkeeping equal
+    T step calls bit for bit, at one env per workgroup, three, and the full-batch geometry; then eager steps go on from
+    there (the host's step mirror and the staged reset stayed consistent)."""
+    cfg = fm.EnvConfig(**kw)
+    N, E, D, F, ep = cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat, cfg.episode_length
+    hint = geom_hint(geom, cfg)
+    n = 5 * max(hint, 1) // 2 + 3 if geom else 21
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=17, envs_per_workgroup=hint)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=17, envs_per_workgroup=hint)
+    gen = torch.Generator(device=DEV); gen.manual_seed(6)
+    a.reset(); b.reset()
+    for t in range(2):   # start the span in the middle of an episode
+        act = torch.randint(0, 5, (n, N), device=DEV, generator=gen, dtype=torch.int32)
+        a.step(act); b.step(act)
+    T = 2 * ep + ep // 2
+    tape = torch.randint(0, 5, (T, n, N), device=DEV, generator=gen, dtype=torch.int32)
+    z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=DEV)  # noqa: E731
+    big = dict(obs=z(T, n, N, D), node_obs=z(T, n, N, E, F), adj=z(T, n, E, E), reward=z(T, n, N), done=z(T, n, N, dt=torch.uint8))
+    b.use_outputs(b.new_output_set(obs=big['obs'][0], node_obs=big['node_obs'][0], adj_env=big['adj'][0], reward=big['reward'][0], done=big['done'][0]))
+    b.step_span(tape, strides={k: v[0].numel() for k, v in big.items()})
+    want = {k: [] for k in big}
+    for t in range(T):
+        r = a.step(tape[t])
+        for k, x in zip(('obs', 'node_obs', 'adj', 'reward', 'done'), (r[0], r[2], a.adj_env, r[4], r[5])):
+            want[k].append(x.clone())
+    torch.cuda.synchronize()
+    for k in big:
+        assert torch.equal(big[k], torch.stack(want[k])), k
+    assert torch.equal(a.info, b.info)   # (stride 0: the last step's infos)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert a.phase == b.phase and a.launch_counts()[0] == b.launch_counts()[0]
+    if cfg.scenario_name != 'nav_fairassign_fairrew_formation_graph':
+        assert b.launch_counts()[1:3] == a.launch_counts()[1:3]           # the episode ends went the same way (folded / reset launches)
+    b.use_outputs(b.new_output_set())
+    for t in range(ep + 1):   # and on with single steps
+        act = torch.randint(0, 5, (n, N), device=DEV, generator=gen, dtype=torch.int32)
+        ra, rb = a.step(act), b.step(act)
+        for k in (0, 2, 4, 5, 6):
+            assert torch.equal(ra[k], rb[k]), (t, k)
+
+
+def test_rollout_buffer_insert_span_equals_insert_step():
+    """DeviceRolloutBuffer.insert_span: a whole rollout through one fmarl_step_span call, the time slots addressed by per-step
+    strides -- same buffer (obs / node_obs / adj / rewards / dones / masks / active_masks) and the same episode metrics as
+    insert_step per step, over three rollouts incl. after_update."""
+    from fair_marl_amd.rollout_buffer import DeviceRolloutBuffer
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=3, num_walls=1, episode_length=9)
+    n, T = 150, 9
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=23)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=23)
+    buf_a, buf_b = DeviceRolloutBuffer(a), DeviceRolloutBuffer(b)
+    gen = torch.Generator(device=DEV); gen.manual_seed(2)
+    buf_a.reset(); buf_b.reset()
+    for ep in range(3):
+        tape = torch.randint(0, 5, (T, n, 4), device=DEV, generator=gen, dtype=torch.int32)
+        for t in range(T):
+            buf_a.insert_step(tape[t])
+        if ep == 1:   # a span may also start behind eager inserts
+            buf_b.insert_step(tape[0]); buf_b.insert_step(tape[1])
+            buf_b.insert_span(tape[2:])
+        else:
+            buf_b.insert_span(tape)
+        torch.cuda.synchronize()
+        assert buf_a.step == buf_b.step == T
+        for name in ('obs', 'node_obs', 'adj_env', 'rewards', 'dones', 'masks', 'active_masks'):
+            assert torch.equal(getattr(buf_a, name), getattr(buf_b, name)), 'rollout %d %s' % (ep, name)
+        assert a.process_infos() == b.process_infos()
+        buf_a.after_update(); buf_b.after_update()
 
 
 def test_exhausted_rejection_sampling_is_reported():
