@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import fair_marl_amd as fm  # noqa: E402
-from fair_marl_amd.sharding import StepRecord, TrajectoryGather  # noqa: E402
+from fair_marl_amd.sharding import SpanGather, StepRecord, TrajectoryGather  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
@@ -56,8 +56,8 @@ CONFIGS = {   # workload: a format string, filled with the number of envs the ru
 KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
-SECONDARY = (('cfg3', 'span'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'),
-             ('fnav', 'eager'), ('n10', 'eager'), ('n10', 'span'))
+SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'span'),
+             ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('n10', 'eager'), ('n10', 'span'))
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
@@ -114,7 +114,7 @@ def launch_bytes(cfg, agents, counts0, counts1):
 
 # envs per workgroup for the span launches of the secondary lines (0 = the library's choice): a span kernel keeps a workgroup's
 # slot for a whole run of steps, so the number of workgroups should be a multiple of what the chip holds at once
-SPAN_EPB = {'cfg3': 4, 'n10': 16}
+SPAN_EPB = {'cfg3': 4}
 
 
 def secondary_line(name, mode, device, steps=300, warmup=50):
@@ -278,6 +278,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
     ap.add_argument('--n-envs', type=int, default=0, help='envs per GPU (default: the config\'s)')
+    ap.add_argument('--launch', default='auto', choices=['auto', 'span', 'step', 'graph'],
+                    help='how the K steps are enqueued.  span: fmarl_step_span -- the steps between episode ends as ONE launch in which '
+                         'every workgroup walks its own envs through time, the episode-ending step a launch of its own (actions '
+                         'come from a tape: BASELINE\'s random-action rollout); step: one fmarl_step call per step (what a policy in '
+                         'the loop gets); graph: one hipGraph replay per episode (N=1).  auto = span, except for '
+                         'nav_fairassign_fairrew_formation_graph (its span is a loop of steps anyway)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: skip the RCCL trajectory gather')
     ap.add_argument('--record-path', action='store_true', help='N=1: write the step records / episode records as the '
@@ -285,19 +291,16 @@ def main():
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
     ap.add_argument('--no-tune-placement', action='store_true', help='keep the first allocation of node_obs / adj instead of '
                     'the fastest pair of a few (RolloutEngine tune_placement)')
-    ap.add_argument('--graph', action='store_true', help='N=1: capture one episode of steps in a hipGraph and replay it '
-                    '(launch-bound small batches, e.g. --config cfg2; --steps is rounded to whole episodes; with the staged reset the side stream '
-                    'is a forked branch of the graph)')
-    ap.add_argument('--eager', action='store_true', help='N=1: one fmarl_step call per step even for a launch-bound batch (default there: '
-                    'graph replay, as RolloutEngine.rollout picks it)')
+    ap.add_argument('--graph', action='store_true', help='same as --launch graph')
+    ap.add_argument('--eager', action='store_true', help='same as --launch step')
     ap.add_argument('--pipeline', type=int, default=1, help='step the env batch as this many sub-batches on their own streams '
                     '(fair_marl_amd.PipelinedRollout: the tail of one sub-batch\'s step kernel overlaps the head of the next one\'s); '
-                    'no trajectory gather in this mode')
+                    'one fmarl_step call per sub-batch and step, no trajectory gather in this mode')
     ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
                     'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
     ap.add_argument('--no-secondary', action='store_true', help='N=1: skip the other BASELINE configs after the headline region')
     ap.add_argument('--learner-rebuild', type=int, default=0, metavar='K', help='rank 0 rebuilds node_obs / adj of K ranks\' gathered '
-                    'step (fmarl_rebuild_graph) inside the timed loop -- what a learner has to do with what arrives, since node_obs / '
+                    'steps (fmarl_rebuild_graph) inside the timed loop -- what a learner has to do with what arrives, since node_obs / '
                     'adj never travel; reported separately in the line (needs the gather: N > 1, --record-path or --rccl-selftest)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
@@ -355,20 +358,24 @@ def main():
     cfg = fm.EnvConfig(**spec['env'])
     n_envs = args.n_envs or spec['n_envs']
     K, W = args.steps, args.warmup
+    ep = cfg.episode_length
     workload = spec['workload'] % n_envs
-    if (not args.graph and not args.eager and world == 1 and not args.record_path and not args.rccl_selftest and args.pipeline <= 1
-            and n_envs * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS):
-        args.graph = True   # launch-bound batch: what RolloutEngine.rollout does by default
-    if args.graph:
+    fnav_sc = cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph'
+    launch = 'graph' if args.graph else ('step' if args.eager else args.launch)
+    if args.pipeline > 1:
+        launch = 'step'
+    if launch == 'auto':
+        launch = 'step' if fnav_sc else 'span'
+    if launch == 'graph':
         if world > 1:
-            raise SystemExit('bench.py: --graph is a single-GPU mode')
-        ep_len = cfg.episode_length
-        K, W = max(ep_len, K // ep_len * ep_len), (W + ep_len - 1) // ep_len * ep_len   # whole episodes
+            raise SystemExit('bench.py: --launch graph is a single-GPU mode')
+        K, W = max(ep, K // ep * ep), (W + ep - 1) // ep * ep   # whole episodes
     gather = (world > 1 or args.record_path) and not args.no_gather
     pipe = None
+    epb_hint = SPAN_EPB.get(args.config, 0) if launch == 'span' and not args.n_envs else 0
     if args.pipeline > 1:
-        if args.graph or args.rccl_selftest:
-            raise SystemExit('bench.py: --pipeline does not combine with --graph / --rccl-selftest')
+        if args.rccl_selftest:
+            raise SystemExit('bench.py: --pipeline does not combine with --rccl-selftest')
         if world > 1 and not args.no_gather:   # never a multi-GPU number that silently dropped the exchange
             raise SystemExit('bench.py: --pipeline has no trajectory gather; for N > 1 say so with --no-gather')
         gather = False
@@ -377,15 +384,21 @@ def main():
         eng = pipe.engines[0]
     else:
         eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
-                               tune_placement=0 if args.no_tune_placement else None, emit_graph_record=gather)
+                               tune_placement=0 if args.no_tune_placement else None, emit_graph_record=gather,
+                               envs_per_workgroup=epb_hint)
     depth = 2
-    # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for
-    # fair_graph_formation, a 36-byte-per-agent record of the step's scenario state (RolloutEngine.step_record_words)
+    # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for the two
+    # formation scenarios, a per-step record of the step's scenario state (RolloutEngine.step_record_words)
     episodes = True
-    tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
-                          episode_words=eng.episode_record_words if episodes else 0,
-                          graph_words=eng.step_record_words if eng.emit_graph_record else 0, timing=True) if gather else None
-    # --learner-rebuild K: the learner rank turns K ranks' gathered step back into node_obs / adj inside the timed loop
+    graph_words = eng.step_record_words if eng.emit_graph_record else 0
+    tg = sg = None
+    if gather and launch == 'span':   # the records of a whole run of steps travel in one collective (SURVEY section 8 e)
+        sg = tg = SpanGather(ep, n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
+                             episode_words=eng.episode_record_words if episodes else 0, graph_words=graph_words, timing=True)
+    elif gather:
+        tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
+                              episode_words=eng.episode_record_words if episodes else 0, graph_words=graph_words, timing=True)
+    # --learner-rebuild K: the learner rank turns K ranks' gathered steps back into node_obs / adj inside the timed loop
     rebuild_ranks, rebuild_events, lr_node, lr_adj = [], [], None, None
     if args.learner_rebuild:
         if not gather:
@@ -395,20 +408,26 @@ def main():
             rebuild_ranks = peers[:max(1, min(args.learner_rebuild, world))]
             lr_node = torch.empty(n_envs, cfg.N, cfg.E, cfg.node_feat, dtype=torch.float32, device=device)
             lr_adj = torch.empty(n_envs, cfg.E, cfg.E, dtype=torch.float32, device=device)
-    if gather:
+    if gather and sg is None:
         sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done, graph_record=r.graph) for r in tg.records]
     else:
         sets = [eng.outs]
 
-    # synthetic action tape: int32 U{0..4} per (step, env, agent), resident in HBM before timing
+    # synthetic action tape: int32 U{0..4} per (step, env, agent), resident in HBM before timing; one episode long (step t
+    # reads entry t mod episode_length: a span's steps are consecutive entries)
     g = torch.Generator(device=device)
     g.manual_seed(1000 + rank)
-    tape_len = 32
+    tape_len = ep
     tape = torch.randint(0, 5, (tape_len, n_envs, cfg.N), device=device, generator=g, dtype=torch.int32)
 
     inject_error = bool(os.environ.get('FMARL_BENCH_INJECT_GATHER_ERROR'))   # test hook: tests/test_hip_parity.py
+    chunk = [0]          # runs of steps enqueued so far (span mode)
+    chunk_ended = {}     # run index -> its last step ended an episode
 
-    def run(first, count):   # reads `gather` / `sets` at call time
+    def rebuild(obs_r, epi_r, graph_r):
+        eng.rebuild_graph(obs_r, epi_r, node_obs=lr_node, adj_env=lr_adj, step_record=graph_r if eng.emit_graph_record else None)
+
+    def run_steps(first, count):   # one fmarl_step call per step
         if pipe is not None:
             for t in range(first, first + count):
                 pipe.step(tape[t % tape_len], auto_reset=True)
@@ -429,30 +448,72 @@ def main():
                     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ea.record()
                     for r in rebuild_ranks:
-                        eng.rebuild_graph(got[r][0], epi[r], node_obs=lr_node, adj_env=lr_adj,
-                                          step_record=graphs[r] if eng.emit_graph_record else None)
+                        rebuild(got[r][0], epi[r], graphs[r])
                     eb.record()
-                    rebuild_events.append((ea, eb))
+                    rebuild_events.append((ea, eb, 1))
                 if episodes and eng.episode_started:   # same steps on every rank (lockstep episodes)
                     eng.pack_episode(out=tg.episode_record())
                     tg.submit_episode()
         if gather:
             tg.finish()
 
+    def run_spans(first, count):   # fmarl_step_span: runs of steps that end at an episode end (or at the end of the region)
+        t, end = first, first + count
+        while t < end:
+            off = t % ep
+            k = min(ep - off, end - t)
+            c = chunk[0]
+            strides = None
+            if gather:
+                rec = sg.span_record(c)          # waits for the gather that last used this buffer (run c - depth)
+                eng.use_outputs(sg.output_set(eng, c))
+                strides = rec.strides
+            eng.step_span(tape[off:off + k], strides=strides)
+            if gather:
+                if inject_error and c == 1 and rank == world - 1:
+                    raise RuntimeError('injected gather error (FMARL_BENCH_INJECT_GATHER_ERROR)')
+                sg.submit_span(c, k)
+                chunk_ended[c] = bool(eng.episode_started)
+                if rebuild_ranks and c - 1 in chunk_ended:
+                    # run c - 1 has arrived (or is awaited here) while run c is in flight.  Its steps belong to the episode whose
+                    # record was current during that run -- except its last step when that ended an episode: the observation
+                    # behind an auto-reset belongs to the new episode, whose record went out right after run c - 1
+                    got = sg.gathered_span(c - 1)
+                    epi_new, epi_old = sg.gathered_episode(), sg.gathered_episode(back=1 if chunk_ended[c - 1] else 0)
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record()
+                    steps = got[0][0].shape[0]
+                    for j in range(steps):
+                        epi = epi_new if j == steps - 1 else epi_old
+                        for r in rebuild_ranks:
+                            rebuild(got[r][0][j], epi[r], got[r][3][j] if got[r][3] is not None else None)
+                    eb.record()
+                    rebuild_events.append((ea, eb, steps))
+                if episodes and eng.episode_started:   # the run ended an episode: the new one's record, once
+                    eng.pack_episode(out=sg.episode_record())
+                    sg.submit_episode()
+            chunk[0] = c + 1
+            t += k
+        if gather:
+            sg.finish()
+
+    run = run_spans if launch == 'span' else run_steps
     if pipe is not None:
         pipe.reset()
     else:
         eng.reset()
-    if args.graph:
+    if gather and episodes and pipe is None:   # the first episode's record
+        eng.pack_episode(out=tg.episode_record())
+        tg.submit_episode()
+    counts_eager = None
+    if launch == 'graph':
         # the per-kernel hipEvents cannot live inside a captured graph: the dominant kernel is timed in an eager pass
         # over whole episodes first, then the same steps run as graph replays inside the timed region
-        tape_len = cfg.episode_length
-        tape = tape[:tape_len].contiguous()
         eng.profile_enable(2 * tape_len)
         c_before_eager = eng.launch_counts()
-        run(0, 2 * tape_len)
+        run_steps(0, 2 * tape_len)
         torch.cuda.synchronize(device)
-        kernel_ms_eager = eng.profile_read()
+        kernel_ms_eager = eng.profile_read(with_steps=True)
         eng.profile_enable(0)
         counts_eager = (c_before_eager, eng.launch_counts())
         episode_graph = eng.capture_steps(tape, lockstep=True)   # whole episodes from phase 0: one reset per episode in the graph
@@ -467,7 +528,7 @@ def main():
         # A trajectory exchange that cannot run is a FAILED multi-GPU measurement, never a number without the exchange.
         print('bench.py: rank %d: rollout / trajectory gather failed: %s' % (rank, exc), file=sys.stderr, flush=True)
         sys.exit(1)
-    if not args.graph:
+    if launch != 'graph':
         for e in (pipe.engines if pipe is not None else [eng]):
             e.profile_enable(K)
     if tg is not None:   # the warm-up's waits do not count
@@ -475,11 +536,16 @@ def main():
         tg.stream_wait_ms()
     rebuild_events.clear()
     counts0 = eng.launch_counts()
+    chunk_start = chunk[0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    run(W, K)
+    try:
+        run(W, K)
+    except RuntimeError as exc:
+        print('bench.py: rank %d: rollout / trajectory gather failed: %s' % (rank, exc), file=sys.stderr, flush=True)
+        sys.exit(1)
     torch.cuda.synchronize(device)
     own_elapsed = time.perf_counter() - t0   # this rank's own K steps, before it waits for the others
     if world > 1:
@@ -507,12 +573,24 @@ def main():
         if ranks_seen != world:
             print('bench.py: all_reduce saw %d ranks, expected %d' % (ranks_seen, world), file=sys.stderr, flush=True)
             sys.exit(1)
-        if gather and rank == 0:   # the last gathered step really holds every rank's rows (rank r's envs start at r * n_envs)
-            got = tg.gathered(W + K - 1)
-            if len(got) != world or any(tuple(o.shape) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _ in got):
+        if gather and rank == 0:   # the last gathered record really holds every rank's rows (rank r's envs start at r * n_envs)
+            if sg is not None:
+                got = sg.gathered_span(chunk[0] - 1)
+                bad = len(got) != world or any(tuple(o.shape[1:]) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _, _ in got)
+            else:
+                got = tg.gathered(W + K - 1)
+                bad = len(got) != world or any(tuple(o.shape) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _ in got)
+            if bad:
                 print('bench.py: gathered record has the wrong shape', file=sys.stderr, flush=True)
                 sys.exit(1)
-    kernel_ms = kernel_ms_eager if args.graph else [v for e in (pipe.engines if pipe is not None else [eng]) for v in e.profile_read()]
+    if launch == 'graph':
+        kernel_ms, kernel_steps = kernel_ms_eager
+    else:
+        kernel_ms, kernel_steps = [], []
+        for e in (pipe.engines if pipe is not None else [eng]):
+            ms, st = e.profile_read(with_steps=True)
+            kernel_ms += ms
+            kernel_steps += st
 
     if rank == 0:
         agents = n_envs * cfg.N
@@ -520,28 +598,48 @@ def main():
         # reset launches emits nothing itself (state + reward bytes only); with the staged reset of navigation_graph the launch
         # that ends an episode also commits the next one and emits its first observation (step_end_kernel), so every launch
         # writes the full outputs.  Which of the two happened is read from the library's launch counters, not assumed.
-        ep = cfg.episode_length
-        fnav_sc = cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph'
         resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
-        ca, cb = counts_eager if args.graph else (counts0, counts1)
+        ca, cb = counts_eager if launch == 'graph' else (counts0, counts1)
+        sub = max(1, args.pipeline)
         if pipe is not None:
-            ca = (0, 0, 0, 0)   # sub-batch engines: their totals since creation
+            ca = (0, 0, 0, 0)   # sub-batch engines: their totals since creation (includes the warm-up's launches: same mix)
             cb = tuple(sum(e.launch_counts()[i] for e in pipe.engines) for i in range(4))
-            bytes_per_launch = launch_bytes(cfg, agents // args.pipeline, ca, cb)   # (includes the warm-up's launches: same mix)
-        else:
-            bytes_per_launch = launch_bytes(cfg, agents, ca, cb)
+        bytes_per_step = launch_bytes(cfg, agents // sub, ca, cb) * sub      # mean algorithmic bytes of one step of all envs
         folded = cb[1] - ca[1]
-        bytes_per_step = bytes_per_launch * max(1, args.pipeline)
-        k_avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float('nan')
+        kernel_ms, kernel_steps = np.asarray(kernel_ms, dtype=np.float64), np.asarray(kernel_steps, dtype=np.float64)
+        span_launches = kernel_steps > 1
+        if launch == 'span' and span_launches.any():
+            # the dominant kernel is the span kernel: a launch covers a run of steps, all of which emit
+            k_avg_ms = float(kernel_ms[span_launches].mean())
+            steps_per_launch = float(kernel_steps[span_launches].mean())
+            bytes_per_launch = agents * algorithmic_bytes(cfg) * steps_per_launch
+            kernel_name = 'formation_span_kernel' if cfg.scenario_name == 'fair_graph_formation' else 'step_span_kernel'
+        else:
+            k_avg_ms = float(kernel_ms.mean()) if kernel_ms.size else float('nan')
+            steps_per_launch = 1.0
+            bytes_per_launch = bytes_per_step / sub   # a launch steps one sub-batch
+            kernel_name = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath) and pipe is None:   # (the committed counters are per launch over ALL envs of the profiled run)
+        if os.path.exists(tpath) and pipe is None:   # (the committed counters are per STEP over all envs of the profiled run)
             with open(tpath) as f:
-                entry = json.load(f).get(args.config, {})
-            if entry.get('n_envs', spec['n_envs']) == n_envs:
-                traffic = entry.get('hbm_bytes_per_launch')
+                entry = json.load(f).get('%s/%s' % (args.config, launch), {})
+            if entry.get('n_envs') == n_envs and entry.get('hbm_bytes_per_step'):
+                traffic = entry['hbm_bytes_per_step'] * steps_per_launch
         ceiling_ms = store_ceiling_ms(eng) if pipe is None else None
+        launch_text = {
+            'span': 'fmarl_step_span: the steps between episode ends as ONE launch in which every workgroup walks its own envs through '
+                    'time (%d envs per workgroup; state in registers, static entities in LDS between the steps), the first step of an '
+                    'episode and the step that ends it as launches of their own: %d launches for the %d timed steps'
+                    % (eng.envs_per_workgroup, len(kernel_ms), K),
+            'step': ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
+                     % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step'),
+            'graph': 'one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed region)' % ep}[launch]
+        if gather and sg is not None:
+            exchange_text = 'one gather per run of steps (<= %d steps: %d B per agent-step, back to back)' % (ep, StepRecord.bytes_per_agent_step(cfg.obs_dim, graph_words))
+        else:
+            exchange_text = 'gather of obs/reward/done to rank 0 every step, %d B per agent-step' % StepRecord.bytes_per_agent_step(cfg.obs_dim, graph_words)
         out = {
             'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), %s random-action rollout' % cfg.scenario_name,
             'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'n_ranks_seen': ranks_seen,
@@ -551,10 +649,7 @@ def main():
             'config': {'workload': workload, 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
-                       'launch': ('one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed '
-                                  'region)' % cfg.episode_length if args.graph else
-                                  ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
-                                   % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step')),
+                       'launch_mode': launch, 'launch': launch_text,
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed and observed by the launch that ends the episode'
                                       ' (%d of %d episode ends folded)' % (folded, cb[1] - ca[1] + cb[2] - ca[2])),
@@ -564,8 +659,7 @@ def main():
                                                eng.placement_ms[0][0], max(map(max, eng.placement_ms)))
                                             if eng.placement_ms else 'first allocations'),
                        'exchange': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
-                                     else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' gather of obs/reward/done to rank 0 every step, %d B per agent-step'
-                                    % StepRecord.bytes_per_agent_step(cfg.obs_dim, eng.step_record_words if eng.emit_graph_record else 0)
+                                     else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' ' + exchange_text
                                     + ((' + %d B per env with EVERY step (goals, landmarks, obstacles, walls: this scenario\'s episodes end env by env, '
                                         'so the record is re-packed and gathered whenever an env may have been reset)' if fnav_sc else
                                         ' + %d B per env once per episode (goals, landmarks, obstacles, walls)')
@@ -574,12 +668,14 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_source': ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier '
                                             'run of this command, replayed here, not measured in this run') if traffic is not None else None,
-                         'kernel': KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel'),
-                         'kernel_avg_ms': k_avg_ms, 'kernel_launches': len(kernel_ms),
+                         'kernel': kernel_name,
+                         'kernel_avg_ms': k_avg_ms, 'kernel_launches': int(span_launches.sum()) if steps_per_launch > 1 else int(kernel_ms.size),
+                         'kernel_steps_per_launch': steps_per_launch,
+                         'step_kernels_ms_per_step': float(kernel_ms.sum() / max(1.0, kernel_steps.sum())),   # all step launches of the region / its steps
                          # the emission alone (node_obs + adj of every env, no env state) on the same buffers of the same box:
-                         # what this box's store stream allows; frac_of_box_ceiling = that time / the step kernel's
+                         # what one launch of this box's store stream takes; frac_of_box_ceiling = that time / the step kernels' per step
                          'store_ceiling_ms': ceiling_ms,
-                         'frac_of_box_ceiling': (ceiling_ms / k_avg_ms if ceiling_ms else None),
+                         'frac_of_box_ceiling': (ceiling_ms / float(kernel_ms.sum() / max(1.0, kernel_steps.sum())) if ceiling_ms else None),
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
         }
@@ -593,40 +689,43 @@ def main():
         if per_rank is not None:
             # one run must explain itself: every rank's own time per step, what it waited for the exchange, what the learner
             # rank receives and what it costs to turn that back into node_obs / adj
-            rec_bytes = tg.records[0].flat.numel() if tg is not None else 0
+            rec_bytes = (sg.spans[0].stride if sg is not None else tg.records[0].flat.numel()) if tg is not None else 0
             recv_bytes = rec_bytes * (world - 1)
             out['multi_gpu'] = {
                 'per_rank_ms_per_step': [float(v) for v in per_rank[:, 0]],
                 'gather_wait_ms': {'host_blocked_per_step': [float(v) for v in per_rank[:, 1]],
                                    'stream_stalled_per_step': [float(v) for v in per_rank[:, 2]],
-                                   'note': 'time inside TrajectoryGather waits (record / finish / episode_record): an RCCL wait '
-                                           'stalls the compute stream, a gloo wait blocks the host'},
+                                   'note': 'time inside the gather\'s waits (for the buffer of the run / step two back, at the end of the '
+                                           'region): an RCCL wait stalls the compute stream, a gloo wait blocks the host'},
                 'bytes_gathered_per_step': rec_bytes * world, 'bytes_received_by_rank0_per_step': recv_bytes,
                 'rank0_receive_GBps': recv_bytes / (elapsed / K) / 1e9,
+                'collectives': ('one per run of steps (%d in the timed region)' % (chunk[0] - chunk_start) if sg is not None else 'one per step'),
                 'episode_record_bytes_per_rank': 4 * eng.episode_record_words * n_envs if episodes else 0,
-                'episode_record_gathers_per_step': (1.0 if fnav_sc else 1.0 / ep) if episodes else 0.0}
+                'episode_record_gathers_per_step': (1.0 if fnav_sc and sg is None else 1.0 / ep) if episodes else 0.0}
             if rebuild_ranks:
                 torch.cuda.synchronize(device)
-                ms = [a.elapsed_time(b) for a, b in rebuild_events]
+                ms = [a.elapsed_time(b) for a, b, _ in rebuild_events]
+                nst = sum(k for _, _, k in rebuild_events)
                 out['multi_gpu']['learner_rebuild'] = {
-                    'ranks_rebuilt_per_step': rebuild_ranks, 'steps_rebuilt': len(ms),
-                    'ms_per_step': float(np.mean(ms)) if ms else None,
-                    'agent_steps_rebuilt_per_s': (len(rebuild_ranks) * agents / (np.mean(ms) * 1e-3)) if ms else None,
-                    'note': 'rank 0 rebuilds node_obs / adj of these ranks\' gathered step (fmarl_rebuild_graph) inside the timed loop, '
+                    'ranks_rebuilt_per_step': rebuild_ranks, 'steps_rebuilt': nst,
+                    'ms_per_step': float(np.sum(ms) / nst) if nst else None,
+                    'agent_steps_rebuilt_per_s': (len(rebuild_ranks) * agents * nst / (np.sum(ms) * 1e-3)) if nst else None,
+                    'note': 'rank 0 rebuilds node_obs / adj of these ranks\' gathered steps (fmarl_rebuild_graph) inside the timed loop, '
                             'on the same stream as its own step kernels; the reference ships node_obs / adj instead '
                             '(onpolicy/envs/env_wrappers.py:983-996)'}
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if args.config in REFERENCE_CPU:
             out['reference_cpu'] = REFERENCE_CPU[args.config]
-        if world == 1 and not args.no_secondary and pipe is None and not (args.graph or args.record_path or args.n_envs):
+        if world == 1 and not args.no_secondary and pipe is None and launch == ('step' if fnav_sc else 'span') and not (args.record_path or args.n_envs):
             eng.close()
             del eng, tape
             if sets:
                 sets.clear()
             torch.cuda.empty_cache()
             t_sec = time.perf_counter()
-            out['secondary'] = [secondary_line(name, mode, device) for name, mode in SECONDARY if not (name == args.config and mode == 'eager')]
+            # first the same config one launch per step (what a policy in the loop gets; the launch mode of rounds 1 and 2)
+            out['secondary'] = [secondary_line(name, mode, device) for name, mode in SECONDARY if not (name == args.config and mode == {'step': 'eager'}.get(launch, launch))]
             out['secondary_wall_s'] = time.perf_counter() - t_sec
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())

@@ -554,9 +554,14 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
 // FOLD = false: the step.  FOLD = true: the step that ends an episode whose successor is already staged (asynchronous reset,
 // envs in lockstep): after the terminal reward / done / info the same launch commits the staged episode (reset_commit_kernel)
 // and emits its first observation (reset_emit_kernel) -- one launch instead of a non-emitting step, a commit and an emission.
+// `carry` (span kernels): bit 0 = this agent's state arrives in `c` (left there by the previous step of the span) and the static
+// entities are still in the workgroup's LDS tables -- nothing is loaded but the action; bit 1 = the new state stays in `c`
+// for the next step of the span instead of going to global memory.  0 = a step of its own (loads and stores everything).
+struct StepCarry { double2 x, v; double pd, Dg, Tr, left, mtime; int noc, nac, match, step; };
+
 template <bool FOLD>
 __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx, const float *action_vec,
-                                          int auto_reset) {
+                                          int auto_reset, StepCarry &c, const int carry) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int env0 = blockIdx.x * p.epb;
@@ -570,23 +575,29 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     double *s_stat = (double *)(lds + p.lds_stat + (size_t)el * p.stat_stride);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
-    double pd = 0;
+    double pd = 0, mtime = 0;
     int step = 0, match = 0;
     double Dg_old = 0, Tr_old = 0, left_old = 0;
     int noc_old = 0, nac_old = 0;
-    if (active) {
-        // the whole state of the agent in one round of loads (one memory latency per launch, which is what a small
-        // batch waits for; the kernel has the registers since the emission stopped needing them)
-        x = p.agent_pos[g];
-        v = p.agent_vel[g]; pd = p.p_dist[g];
-        match = p.goal_match[g];
-        step = p.cur_step[env] + 1;   // environment.py:819, :823
-        Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left_old = p.dist_left[g];
-        noc_old = p.num_obst_coll[g]; nac_old = p.num_agent_coll[g];
-        s_pos[i] = x;
+    if (carry & 1) {   // (s_pos[i] already holds x: the previous step of the span wrote it, two barriers ago)
+        x = c.x; v = c.v; pd = c.pd; match = c.match; step = c.step + 1;
+        Dg_old = c.Dg; Tr_old = c.Tr; left_old = c.left; noc_old = c.noc; nac_old = c.nac; mtime = c.mtime;
+    } else {
+        if (active) {
+            // the whole state of the agent in one round of loads (one memory latency per launch, which is what a small
+            // batch waits for; the kernel has the registers since the emission stopped needing them)
+            x = p.agent_pos[g];
+            v = p.agent_vel[g]; pd = p.p_dist[g];
+            match = p.goal_match[g];
+            step = p.cur_step[env] + 1;   // environment.py:819, :823
+            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left_old = p.dist_left[g];
+            noc_old = p.num_obst_coll[g]; nac_old = p.num_agent_coll[g];
+            if (carry && o.info) mtime = p.min_time[g];
+            s_pos[i] = x;
+        }
+        load_statics(p, lds, env0, nenv);
+        __syncthreads();
     }
-    load_statics(p, lds, env0, nenv);
-    __syncthreads();
 
     // ---- World.step (core.py:250-274) ---------------------------------------------------------
     double2 goal = make_double2(0, 0);
@@ -667,10 +678,15 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
 
         // state + small outputs
         const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
-        p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
-        p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left_new;
-        p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
-        if (i == 0) p.cur_step[env] = step;
+        if (carry & 2) {
+            c.x = x; c.v = v; c.pd = pd; c.Dg = Dg_new; c.Tr = Tr_new; c.left = left_new; c.noc = noc; c.nac = nac;
+            c.match = match; c.step = step; c.mtime = mtime;
+        } else {
+            p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
+            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left_new;
+            p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
+            if (i == 0) p.cur_step[env] = step;
+        }
         if (o.reward && !FMARL_SKIP(p, 16)) o.reward[g] = (float)rew;
         if (o.done) o.done[g] = step >= p.episode_length;            // environment.py:237-247
         if (o.obs && !will_reset && !FMARL_SKIP(p, 16)) {               // :845-857
@@ -699,7 +715,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
             inf[FMARL_INFO_TIME_MEAN * plane] = (float)tm;
             inf[FMARL_INFO_TIME_STDDEV * plane] = (float)ts;
             inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)ratio_out(tm, ts + 0.0001);
-            inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
+            inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)(carry ? mtime : p.min_time[g]);
             inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
         }
     }
@@ -772,26 +788,30 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
 
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
-    step_body<false>(p, o, action_idx, action_vec, auto_reset);
+    StepCarry c;
+    step_body<false>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
     Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
-    step_body<true>(p, o, action_idx, action_vec, auto_reset);
+    StepCarry c;
+    step_body<true>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
 // A run of T consecutive steps of the SAME workgroup's envs in one launch (fmarl_step_span): envs never interact, so a
 // workgroup can walk its own envs through time without waiting for the rest of the batch.  Step t reads the actions at
 // action_idx + t * span.actions and writes the outputs shifted by the span's per-step strides (0 = the same buffer every
-// step).  No episode ends inside a span (the host splits there).  The state goes through global memory between the steps
-// (a workgroup re-reads what it wrote itself: workgroup-scope release / acquire around the barrier).
-__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_span_kernel(
+// step).  No episode ends inside a span (the host splits there).  Between the steps the agent's state stays in registers and
+// the static entities in the LDS tables (StepCarry): only the first step loads the state, only the last one stores it, and
+// the step body's own barriers are all the ordering the steps need (a step's first LDS writes come two barriers after its
+// start, by when every wave has left the previous step's emission).
+__global__ __launch_bounds__(kThreads, 3) void step_span_kernel(
     Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, int T) {
+    StepCarry c = {};
     for (int t = 0; t < T; ++t) {
         const Params q = span_params(p);
         const FmarlOutputs ot = span_outputs(o, s, t);
-        step_body<false>(q, ot, action_idx + (size_t)t * s.actions, nullptr, 0);
-        span_step_done();
+        step_body<false>(q, ot, action_idx + (size_t)t * s.actions, nullptr, 0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));
     }
 }
 

@@ -139,6 +139,7 @@ struct Handle {
     unsigned long long cap_stage_id;  // capture in which the staging of the next episode was last enqueued (0 = eagerly)
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
+    int *ev_steps;      // env steps each profiled launch covers (a span launch: many)
     int ev_cap, ev_n;
     int64_t counts[4];  // fmarl_launch_counts
     double rot[64];     // formation: (cos, sin) of i * 2 pi / N, copied into the state buffer by fmarl_init_state
@@ -478,7 +479,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         }
     }
     h->lockstep = false; h->host_step = 0; h->episode_started = false; h->captured = false;
-    h->ev = nullptr; h->ev_cap = h->ev_n = 0;
+    h->ev = nullptr; h->ev_steps = nullptr; h->ev_cap = h->ev_n = 0;
     memset(h->counts, 0, sizeof h->counts);
     *handle = h;
     return FMARL_OK;
@@ -487,7 +488,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 static void drop_events(Handle *h) {
     for (int i = 0; h->ev && i < 2 * h->ev_cap; ++i) (void)hipEventDestroy(h->ev[i]);
     delete[] h->ev;
-    h->ev = nullptr; h->ev_cap = h->ev_n = 0;
+    delete[] h->ev_steps;
+    h->ev = nullptr; h->ev_steps = nullptr; h->ev_cap = h->ev_n = 0;
 }
 
 int fmarl_destroy(void *handle) {
@@ -527,18 +529,22 @@ int fmarl_profile_enable(void *handle, int capacity) {
     drop_events(h);
     if (capacity == 0) return FMARL_OK;
     h->ev = new (std::nothrow) hipEvent_t[2 * (size_t)capacity];
-    if (!h->ev) return fail(FMARL_EINVAL, "fmarl_profile_enable: out of host memory");
+    h->ev_steps = new (std::nothrow) int[(size_t)capacity];
+    if (!h->ev || !h->ev_steps) return fail(FMARL_EINVAL, "fmarl_profile_enable: out of host memory");
     for (int i = 0; i < 2 * capacity; ++i) HIP_OK(hipEventCreate(&h->ev[i]));
     h->ev_cap = capacity;
     return FMARL_OK;
 }
 
-int fmarl_profile_read(void *handle, float *ms, int max_count, int *count) {
+int fmarl_profile_read(void *handle, float *ms, int *steps, int max_count, int *count) {
     Handle *h = (Handle *)handle;
     DeviceGuard on_device(h);
     if (!h || !ms || !count) return fail(FMARL_EINVAL, "fmarl_profile_read: bad argument");
     int n = h->ev_n < max_count ? h->ev_n : max_count;
-    for (int i = 0; i < n; ++i) HIP_OK(hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+    for (int i = 0; i < n; ++i) {
+        HIP_OK(hipEventElapsedTime(&ms[i], h->ev[2 * i], h->ev[2 * i + 1]));
+        if (steps) steps[i] = h->ev_steps[i];
+    }
     *count = n;
     h->ev_n = 0;
     return FMARL_OK;
@@ -646,7 +652,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     else
         hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
                            auto_reset ? 1 : 0);
-    if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
+    if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = 1; ++h->ev_n; }
     HIP_OK(hipGetLastError());
     ++h->counts[0];
     if (fold) ++h->counts[1];
@@ -707,7 +713,7 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
                 hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, k);
             else
                 hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, k);
-            if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); ++h->ev_n; }
+            if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = k; ++h->ev_n; }
             HIP_OK(hipGetLastError());
             if (h->lockstep) h->host_step += k;
             h->episode_started = false;

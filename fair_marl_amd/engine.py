@@ -651,13 +651,16 @@ class RolloutEngine:
             _lib.check(self.lib.fmarl_profile_enable(self.handle, int(capacity)), 'fmarl_profile_enable')
         self._prof_cap = int(capacity)
 
-    def profile_read(self):
-        """Per-launch step-kernel durations [ms] since profile_enable / the last read (stream must be idle)."""
+    def profile_read(self, with_steps=False):
+        """Per-launch step-kernel durations [ms] since profile_enable / the last read (stream must be idle);
+        ``with_steps=True``: (durations, env steps each launch covered -- 1 for a step, the run length for a span launch)."""
         buf = (C.c_float * max(self._prof_cap, 1))()
+        steps = (C.c_int * max(self._prof_cap, 1))()
         cnt = C.c_int()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fmarl_profile_read(self.handle, buf, self._prof_cap, C.byref(cnt)), 'fmarl_profile_read')
-        return [buf[i] for i in range(cnt.value)]
+            _lib.check(self.lib.fmarl_profile_read(self.handle, buf, steps, self._prof_cap, C.byref(cnt)), 'fmarl_profile_read')
+        ms = [buf[i] for i in range(cnt.value)]
+        return (ms, [steps[i] for i in range(cnt.value)]) if with_steps else ms
 
     def launch_counts(self):
         """(step launches, of which folded episode ends, steps followed by separate auto-reset launches, stagings) so far."""

@@ -63,6 +63,50 @@ class StepRecord(object):
         return obs_dim * 4 + 4 + 1 + 4 * graph_words
 
 
+class SpanRecord(object):
+    """T step records back to back in one flat byte buffer -- record t = the StepRecord layout at byte ``t * stride`` -- so that
+    a run of steps (``RolloutEngine.step_span``) writes them through per-step strides and ONE collective moves the whole run."""
+
+    def __init__(self, T, n_envs, num_agents, obs_dim, device, graph_words=0):
+        self.T, self.shape, self.graph_words = int(T), (int(n_envs), int(num_agents), int(obs_dim)), int(graph_words)
+        n, N, D = self.shape
+        G = self.graph_words
+        self.obs_bytes, self.rew_bytes, self.graph_bytes, self.done_bytes = n * N * D * 4, n * N * 4, n * N * G * 4, n * N
+        self.stride = (self.obs_bytes + self.rew_bytes + self.graph_bytes + self.done_bytes + 15) // 16 * 16
+        self.flat = torch.zeros(self.T * self.stride, dtype=torch.uint8, device=device)
+        self.obs, self.reward, self.done = self.views(self.flat, self.T)
+        self.graph = self.graph_view(self.flat, self.T)
+        # per-step element strides for fmarl_step_span (float / int32 arrays: stride / 4 elements, done: bytes)
+        self.strides = dict(obs=self.stride // 4, reward=self.stride // 4, done=self.stride, graph_record=self.stride // 4)
+
+    def views(self, flat, steps):
+        """(obs (steps, n, N, D), reward (steps, n, N), done (steps, n, N)) strided views of the first ``steps`` records."""
+        n, N, D = self.shape
+        f32, w = flat.view(torch.float32), self.stride // 4
+        obs = f32.as_strided((steps, n, N, D), (w, N * D, D, 1), 0)
+        rew = f32.as_strided((steps, n, N), (w, N, 1), self.obs_bytes // 4)
+        done = flat.as_strided((steps, n, N), (self.stride, N, 1), self.obs_bytes + self.rew_bytes + self.graph_bytes)
+        return obs, rew, done
+
+    def graph_view(self, flat, steps):
+        if not self.graph_words:
+            return None
+        n, N, _ = self.shape
+        G = self.graph_words
+        return flat.view(torch.int32).as_strided((steps, n, N, G), (self.stride // 4, N * G, G, 1), (self.obs_bytes + self.rew_bytes) // 4)
+
+    def first_step_buffers(self):
+        """Contiguous tensors of step 0 (what an OutputSet is built from; the span strides reach the other steps)."""
+        n, N, D = self.shape
+        a, b = self.obs_bytes, self.obs_bytes + self.rew_bytes
+        c = b + self.graph_bytes
+        obs = self.flat[:a].view(torch.float32).view(n, N, D)
+        rew = self.flat[a:b].view(torch.float32).view(n, N)
+        graph = self.flat[b:c].view(torch.int32).view(n, N, self.graph_words) if self.graph_words else None
+        done = self.flat[c:c + self.done_bytes].view(n, N)
+        return obs, rew, done, graph
+
+
 class TrajectoryGather(object):
     """Double-buffered asynchronous gather of StepRecords to the learner rank.
 
@@ -188,3 +232,69 @@ class TrajectoryGather(object):
         if not self.collective:
             return [self.records[k].graph]
         return [self.records[k].graph_view(f) for f in self.recv[k]]
+
+
+class SpanGather(TrajectoryGather):
+    """The exchange for rollouts that run as spans (``RolloutEngine.step_span``): the records of a whole run of steps -- up to
+    ``max_steps``, e.g. an episode -- are written back to back by the span launch and gathered to the learner rank with ONE
+    collective per run (SURVEY section 8 e: "batch T steps per collective"), double-buffered like the per-step gather: the
+    gather of run c moves over xGMI while run c + 1 is computed.  Episode records work as in ``TrajectoryGather``.
+
+    Usage per run c of k steps:  rec = sg.span_record(c)  ->  engine.use_outputs(sg.output_set(engine, c));
+    engine.step_span(tape, strides=rec.strides)  ->  sg.submit_span(c, k)."""
+
+    def __init__(self, max_steps, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0,
+                 force_collective=False, graph_words=0, timing=False):
+        TrajectoryGather.__init__(self, 1, num_agents, obs_dim, device, group=group, dst=dst, depth=depth, episode_words=0,
+                                  force_collective=force_collective, graph_words=0, timing=timing)   # (its per-step records stay unused: one env)
+        self.ep_send = [torch.zeros(int(n_envs), int(episode_words), dtype=torch.int32, device=device) for _ in range(2)]
+        if self.collective and self.rank == dst:
+            self.ep_recv = [[torch.zeros_like(b) for _ in range(self.world)] for b in self.ep_send]
+        self.spans = [SpanRecord(max_steps, n_envs, num_agents, obs_dim, device, graph_words) for _ in range(depth)]
+        self.span_pending, self.span_steps = [None] * depth, [0] * depth
+        self.span_recv = None
+        if self.collective and self.rank == dst:
+            self.span_recv = [[torch.zeros_like(r.flat) for _ in range(self.world)] for r in self.spans]
+        self._sets = {}
+
+    def span_record(self, c):
+        k = c % self.depth
+        if self.span_pending[k] is not None:
+            self._wait(self.span_pending[k])
+            self.span_pending[k] = None
+        return self.spans[k]
+
+    def output_set(self, engine, c):
+        """The engine's output set whose obs / reward / done / graph_record are step 0 of run c's record."""
+        k = c % self.depth
+        if (id(engine), k) not in self._sets:
+            obs, rew, done, graph = self.spans[k].first_step_buffers()
+            self._sets[(id(engine), k)] = engine.new_output_set(obs=obs, reward=rew, done=done, graph_record=graph if engine.emit_graph_record else None)
+        return self._sets[(id(engine), k)]
+
+    def submit_span(self, c, steps):
+        """Start the gather of run c (its first ``steps`` records).  Overwrites the learner's receive buffer of run c - depth."""
+        k = c % self.depth
+        self.span_steps[k] = int(steps)
+        if not self.collective:
+            return
+        nbytes = int(steps) * self.spans[k].stride
+        recv = [f[:nbytes] for f in self.span_recv[k]] if self.rank == self.dst else None
+        self.span_pending[k] = dist.gather(self.spans[k].flat[:nbytes], recv, dst=self.dst, group=self.group, async_op=True)
+
+    def gathered_span(self, c):
+        """On the learner rank: list over ranks of (obs (steps, n, N, D), reward, done, graph or None) of run c; waits for its
+        gather (the views are overwritten by ``submit_span(c + depth)``)."""
+        k = c % self.depth
+        if self.span_pending[k] is not None:
+            self.span_pending[k].wait()
+        rec, steps = self.spans[k], self.span_steps[k]
+        flats = [rec.flat] if not self.collective else self.span_recv[k]
+        return [rec.views(f, steps) + (rec.graph_view(f, steps),) for f in flats]
+
+    def finish(self):
+        TrajectoryGather.finish(self)
+        for k in range(self.depth):
+            if self.span_pending[k] is not None:
+                self._wait(self.span_pending[k])
+                self.span_pending[k] = None

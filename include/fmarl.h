@@ -267,15 +267,16 @@ int fmarl_state_changed(void *handle);
 
 /* Measurement hook (bench.py): record a hipEvent pair around every step-kernel launch of this
  * handle, on the launch stream.  enable(capacity) (re)starts recording into `capacity` pairs
- * (0 = off); read() returns the per-launch durations [ms] recorded since then -- the caller
+ * (0 = off); read() returns the per-launch durations [ms] recorded since then and (steps may be NULL) how many env
+ * steps each launch covered (1 for fmarl_step, the run length for a span launch) -- the caller
  * must have synchronised the stream -- and restarts. */
 int fmarl_profile_enable(void *handle, int capacity);
+int fmarl_profile_read(void *handle, float *ms, int *steps, int max_count, int *count);
 /* What fmarl_step has enqueued on this handle so far (host-side counters, no device access): counts[0] step-kernel launches,
  * counts[1] of those that also committed the staged episode and emitted its first observation (the folded episode end,
  * FMARL_FLAG_ASYNC_RESET above), counts[2] step calls followed by separate auto-reset launches, counts[3] stagings of a next
  * episode on the side stream.  bench.py derives the bytes a launch writes from these instead of from the configuration. */
 int fmarl_launch_counts(void *handle, int64_t *counts);
-int fmarl_profile_read(void *handle, float *ms, int max_count, int *count);
 
 /* Test hook (tests/test_hip_parity.py): fill the LDS of every CU with 0xFF bytes (one launch of workgroups that take
  * 64 KB each and write all of it).  LDS is not cleared between kernels, so a table a step kernel reads before writing

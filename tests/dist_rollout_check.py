@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import fair_marl_amd as fm  # noqa: E402
-from fair_marl_amd.sharding import TrajectoryGather, shard_range  # noqa: E402
+from fair_marl_amd.sharding import SpanGather, TrajectoryGather, shard_range  # noqa: E402
 
 
 def main():
@@ -52,6 +52,8 @@ def main():
     if rank == 0:                                  # the oracle of this test: the same envs in ONE engine
         full = fm.RolloutEngine(cfg, n_total, device=device, seed=seed, env_offset=0)
         full.reset()
+    if 'span' in sys.argv[1:]:
+        return span_main(cfg, eng, full, tape, per, T, n_total, lo, hi, rank, world, device)
     eng.reset()
     assert eng.episode_started
     eng.pack_episode(out=tg.episode_record())
@@ -84,6 +86,60 @@ def main():
                 assert torch.equal(adj, f_adj[l2:h2, 0]), 'rebuilt adj of rank %d at step %d' % (r, t)
                 checked += 1
     tg.finish()
+    dist.barrier()
+    if rank == 0:
+        assert checked == T * world
+        print('DIST_CHECK_OK steps=%d world=%d' % (T, world), flush=True)
+    dist.destroy_process_group()
+
+
+def span_main(cfg, eng, full, tape, per, T, n_total, lo, hi, rank, world, device):
+    """The same check for rollouts that run as spans (bench.py's default): runs of steps that end with an episode, their records
+    back to back in one buffer, ONE gather per run, the learner rebuilding every step of a run afterwards."""
+    ep = cfg.episode_length
+    sg = SpanGather(ep, per, cfg.N, cfg.obs_dim, device, dst=0, depth=2, episode_words=eng.episode_record_words,
+                    graph_words=eng.step_record_words)
+    eng.reset()
+    eng.pack_episode(out=sg.episode_record())
+    sg.submit_episode()
+    my_tape = tape[:, lo:hi].contiguous()
+    t, c, checked = 0, 0, 0
+    ref = []
+    while t < T:
+        k = min(ep - t % ep, T - t)
+        rec = sg.span_record(c)
+        eng.use_outputs(sg.output_set(eng, c))
+        eng.step_span(my_tape[t:t + k], strides=rec.strides)
+        sg.submit_span(c, k)
+        ended = eng.episode_started
+        if rank == 0:
+            ref = []
+            for j in range(k):
+                f_obs, _, f_node, f_adj, f_rew, f_done, _ = full.step(tape[t + j], auto_reset=True)
+                ref.append((f_obs.clone(), f_node.clone(), f_adj[:, 0].clone(), f_rew.clone(), f_done.clone()))
+            assert full.episode_started == ended
+        old_episode = sg.gathered_episode() if rank == 0 else None     # the record the run's steps (but the last, if it ended) belong to
+        if ended:
+            eng.pack_episode(out=sg.episode_record())
+            sg.submit_episode()
+        sg.span_pending[c % 2].wait() if sg.span_pending[c % 2] is not None else None
+        if rank == 0:
+            torch.cuda.synchronize(device)
+            new_episode = sg.gathered_episode()
+            for r, (obs, rew, done, graph) in enumerate(sg.gathered_span(c)):
+                l2, h2 = shard_range(n_total, world, r)
+                for j in range(k):
+                    f_obs, f_node, f_adj, f_rew, f_done = ref[j]
+                    assert torch.equal(obs[j], f_obs[l2:h2]), 'obs of rank %d at step %d' % (r, t + j)
+                    assert torch.equal(rew[j], f_rew[l2:h2]) and torch.equal(done[j].bool(), f_done[l2:h2].bool())
+                    epi = new_episode if (ended and j == k - 1) else old_episode
+                    node, adj = eng.rebuild_graph(obs[j].contiguous(), epi[r], step_record=graph[j].contiguous() if graph is not None else None)
+                    assert torch.equal(node, f_node[l2:h2]), 'rebuilt node_obs of rank %d at step %d' % (r, t + j)
+                    assert torch.equal(adj, f_adj[l2:h2]), 'rebuilt adj of rank %d at step %d' % (r, t + j)
+                    checked += 1
+        t += k
+        c += 1
+    sg.finish()
     dist.barrier()
     if rank == 0:
         assert checked == T * world

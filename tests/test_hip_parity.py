@@ -305,23 +305,36 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
     for scenario in ('formation', 'fairnav'):    # + the per-step graph record
         out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py'), scenario])
         assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
+    for args in (['span'], ['formation', 'span']):   # runs of steps as spans, ONE gather per run (the third scenario steps: its
+        # episodes end env by env, the episode record travels with every step)
+        out = _run_ranks([os.path.join(HERE, 'dist_rollout_check.py')] + args)
+        assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
 
 
-@pytest.mark.parametrize('world,extra', [(2, []), (4, ['--learner-rebuild', '2'])])
+@pytest.mark.parametrize('world,extra', [(2, ['--launch', 'step']), (4, ['--launch', 'step', '--learner-rebuild', '2']), (2, []),
+                                         (3, ['--learner-rebuild', '1'])])
 def test_bench_multi_rank_rehearsal(world, extra):
-    """bench.py's own multi-rank loop (record rotation, gathers inside the timed region, max over ranks, one JSON
-    line from rank 0) with two / four ranks sharing the GPU over gloo; the line of an N > 1 run explains itself: every
-    rank's own time per step, what each waited for the exchange, what rank 0 receives, and -- with --learner-rebuild --
-    what it costs rank 0 to turn two peers' gathered step back into node_obs / adj inside the timed loop."""
+    """bench.py's own multi-rank loops with ranks sharing the GPU over gloo -- one gather per step (--launch step) and the default:
+    runs of steps as spans, their records gathered with ONE collective per run -- record rotation, gathers inside the timed
+    region, max over ranks, one JSON line from rank 0.  The line of an N > 1 run explains itself: every rank's own time per
+    step, what each waited for the exchange, what rank 0 receives, and -- with --learner-rebuild -- what it costs rank 0 to turn
+    peers' gathered steps back into node_obs / adj inside the timed loop."""
     import json
     out = _run_ranks([os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', str(world), '--backend', 'gloo', '--n-envs', '512',
                       '--steps', '30', '--warmup', '5'] + extra, world=world)
     lines = [l for l in out.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out[-4000:]
     d = json.loads(lines[0])
+    span = '--launch' not in extra
     assert d['n_gpus'] == world and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
+    assert d['config']['launch_mode'] == ('span' if span else 'step')
     assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
-    assert 'cpu_baseline' not in d and d['roofline']['kernel_launches'] == 30 and d['n_ranks_seen'] == world
+    assert 'cpu_baseline' not in d and d['n_ranks_seen'] == world
+    if span:   # steps 5..34: [5, 25) = a run of 19 + the episode end, [25, 35) = the episode's first step + a run of 9
+        assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == 2
+        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(14.0) and 'one per run of steps (2 ' in d['multi_gpu']['collectives']
+    else:
+        assert d['roofline']['kernel_launches'] == 30 and d['roofline']['kernel_steps_per_launch'] == 1.0
     assert '512 envs per GPU' in d['config']['workload'] and d['roofline']['traffic'] is None   # --n-envs: no replayed 65 536-env counters
     assert 'secondary' not in d
     m = d['multi_gpu']
@@ -330,9 +343,11 @@ def test_bench_multi_rank_rehearsal(world, extra):
     rec = 512 * 32 * 33   # obs 28 + reward 4 + done 1 bytes per agent-step
     assert m['bytes_gathered_per_step'] == world * rec and m['bytes_received_by_rank0_per_step'] == (world - 1) * rec
     assert m['rank0_receive_GBps'] == pytest.approx((world - 1) * rec / (d['ms_per_step'] * 1e-3) / 1e9, rel=1e-6)
-    if extra:
+    if '--learner-rebuild' in extra:
         lr = m['learner_rebuild']
-        assert lr['ranks_rebuilt_per_step'] == [1, 2] and lr['steps_rebuilt'] == 29 and lr['ms_per_step'] > 0
+        k = int(extra[extra.index('--learner-rebuild') + 1])
+        assert lr['ranks_rebuilt_per_step'] == list(range(1, k + 1)) and lr['ms_per_step'] > 0
+        assert lr['steps_rebuilt'] == (25 if span else 29)   # span: the warm-up's run and [5, 25) are rebuilt while the next run is in flight
     else:
         assert 'learner_rebuild' not in m
 

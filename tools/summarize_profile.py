@@ -34,17 +34,22 @@ def counter_mean(path, kernel, counter):
     return float(np.mean(vals)), float(np.max(vals)), len(vals)
 
 
+bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % stem))
-bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
-kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
+mode = bench['config'].get('launch_mode', 'step')
+if mode == 'span':   # the dominant kernel is the span kernel (a launch = a run of steps)
+    kname = 'formation_span_kernel' if cfg == 'cfg4' else 'step_span_kernel'
+else:
+    kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
 w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), kname, 'WRITE_SIZE')
 traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
 traffic_full = (2.0 * f_max + w_max) * 1024.0
 tpath = os.path.join(dst, 'pmc_traffic.json')
 allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
-allt[cfg] = dict(n_envs=bench['config']['n_envs_per_gpu'], hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
+spl = bench['roofline'].get('kernel_steps_per_launch', 1.0)
+allt['%s/%s' % (cfg, mode)] = dict(n_envs=bench['config']['n_envs_per_gpu'], hbm_bytes_per_step=traffic_mean / spl, steps_per_launch=spl, hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
                  write_kib_mean=w_mean, launches=nf, source='%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
                  '(separate passes), %s rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % (tag, ' + '.join(kname) if isinstance(kname, tuple) else kname))
 json.dump(allt, open(tpath, 'w'), indent=1, sort_keys=True)
