@@ -80,6 +80,23 @@ with open(out, 'w') as f:
             '(%d launches, un-profiled run).  Inside the traced run itself bench.py measured %.1f us over its 200 timed '
             'launches (the trace also contains the 50 warm-up launches; profiled runs clock lower, MI355X_MICROARCH.md DVFS note 2).\n'
             % (kname, float(krow['AverageNs']) / 1e3, krow['Calls'], rl['kernel_avg_ms'] * 1e3, rl['kernel_launches'], traced_ms * 1e3))
+    if mode == 'span':
+        # per-launch durations of the span kernel from the kernel trace (a launch = a run of steps; --stats averages the
+        # warm-up's launches in as well)
+        def span_launches(pattern):
+            rows_ = [r for r in csv.DictReader(open(one(pattern))) if knames[0] in r['Kernel_Name']]
+            return [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows_]
+        d = span_launches('trace/*/*kernel_trace.csv')
+        f.write('\nSpan launches of the traced run (ms each, in order; the bench line above reports %.1f steps per launch and measured '
+                '%.3f ms per launch live): %s\n' % (rl.get('kernel_steps_per_launch', 0), rl['kernel_avg_ms'], ', '.join('%.3f' % v for v in d)))
+        if glob.glob(os.path.join(src, 'trace_driver/*/*kernel_trace.csv')):
+            dd = span_launches('trace_driver/*/*kernel_trace.csv')
+            line = [l for l in open(os.path.join(src, 'trace_driver.log')) if l.startswith('{')]
+            drl = json.loads(line[-1])['roofline'] if line else {}
+            f.write('\nThe driver\'s command, `python3 bench.py --gpus 1 --steps 20 --warmup 5`, under the same trace: span launches %s ms '
+                    '(the warm-up\'s run of 4 steps, then the timed run of 19); that run\'s own line: kernel_avg_ms %.3f over %.0f steps per '
+                    'launch, frac %.3f.\n' % (', '.join('%.3f' % v for v in dd), drl.get('kernel_avg_ms', float('nan')),
+                                             drl.get('kernel_steps_per_launch', float('nan')), drl.get('frac', float('nan'))))
     f.write('\n## HBM traffic of %s (PMC)\n\n' % kname)
     f.write('| counter | mean KiB / launch | max KiB / launch | launches |\n|---|---|---|---|\n')
     f.write('| FETCH_SIZE | %.0f | %.0f | %d |\n| WRITE_SIZE | %.0f | %.0f | %d |\n\n' % (f_mean, f_max, nf, w_mean, w_max, nw))
