@@ -13,7 +13,7 @@ from .env_wrappers import (DummyVecEnv, GraphDummyVecEnv, GraphSubprocVecEnv,  #
 from .MPE_env import GraphMPEEnv, MPEEnv  # noqa: F401
 from .pipeline import PipelinedRollout  # noqa: F401
 from .rollout_buffer import DeviceRolloutBuffer  # noqa: F401
-from .sharding import StepRecord, TrajectoryGather, shard_range  # noqa: F401
+from .sharding import SpanGather, SpanRecord, StepRecord, TrajectoryGather, shard_range  # noqa: F401
 from .spaces import Box, Discrete  # noqa: F401
 
 __version__ = '0.1.0'

@@ -235,6 +235,66 @@ def test_trajectory_gather_world_size_2_gloo():
     assert ok
 
 
+def _span_gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from fair_marl_amd.sharding import SpanGather, shard_range
+    n_total, N, D, G, Tmax = 14, 3, 7, 5, 6
+    lo, hi = shard_range(n_total, world, rank)
+    sg = SpanGather(Tmax, hi - lo, N, D, 'cpu', dst=0, depth=2, episode_words=4, graph_words=G)
+    ok = True
+    runs = [4, 6, 1, 5, 6]                       # run lengths (<= Tmax), as spans that end at episode ends give them
+    env = torch.arange(lo, hi, dtype=torch.float32).view(1, -1, 1)
+    for c, k in enumerate(runs):
+        rec = sg.span_record(c)                  # waits for the gather that used this buffer (run c - 2)
+        assert rec.strides['obs'] * 4 == rec.stride and rec.strides['done'] == rec.stride and rec.stride % 16 == 0
+        step = torch.arange(k, dtype=torch.float32).view(-1, 1, 1)
+        rec.obs[:k].copy_((env * 64 + step + 0.25 * c).unsqueeze(-1).expand(k, hi - lo, N, D))
+        rec.reward[:k].copy_((env + 100 * step).expand(k, hi - lo, N))
+        rec.done[:k].copy_(((step + c) % 2).to(torch.uint8).expand(k, hi - lo, N))
+        rec.graph[:k].copy_((env * 1000 + step + c).to(torch.int32).unsqueeze(-1).expand(k, hi - lo, N, G))
+        o0, r0, d0, g0 = rec.first_step_buffers()   # what the engine's output set points at: step 0 of the run
+        ok &= bool(torch.equal(o0, rec.obs[0])) and bool(torch.equal(g0, rec.graph[0])) and o0.is_contiguous() and d0.data_ptr() == rec.done[0].data_ptr()
+        sg.submit_span(c, k)
+        if c % 2 == 0:
+            sg.episode_record().copy_(torch.arange(lo, hi, dtype=torch.int32).view(-1, 1) * 10 + c)
+            sg.submit_episode()
+        if c >= 1 and rank == 0:                 # consume run c - 1 on the learner rank while run c is in flight
+            kk = runs[c - 1]
+            for r, (obs, rew, done, graph) in enumerate(sg.gathered_span(c - 1)):
+                l2, h2 = shard_range(n_total, world, r)
+                e = torch.arange(l2, h2, dtype=torch.float32).view(1, -1)
+                st = torch.arange(kk, dtype=torch.float32).view(-1, 1)
+                ok &= obs.shape == (kk, h2 - l2, N, D) and bool((obs[:, :, N - 1, D - 1] == e * 64 + st + 0.25 * (c - 1)).all())
+                ok &= bool((rew[:, :, 0] == e + 100 * st).all()) and bool((done[:, :, 1] == ((st + c - 1) % 2).to(torch.uint8)).all())
+                ok &= graph.shape == (kk, h2 - l2, N, G) and bool((graph[:, :, 2, G - 1] == (e * 1000 + st + c - 1).to(torch.int32)).all())
+            for r, ep in enumerate(sg.gathered_episode()):
+                l2, h2 = shard_range(n_total, world, r)
+                ok &= bool((ep[:, 3] == torch.arange(l2, h2, dtype=torch.int32) * 10 + (c // 2) * 2).all())
+    sg.finish()
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_span_gather_world_size_2_gloo():
+    """SpanGather (bench.py's default exchange for N > 1): the records of a whole run of steps back to back in one buffer --
+    the strides a span launch writes through -- ONE gather per run, runs of different lengths, double-buffered, episode
+    records beside them (two equal shards of 7 envs; gloo on the CPU)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_span_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+
+
 def test_trajectory_gather_world_size_8_with_the_layout_of_config_5():
     """BASELINE config 5's partition: 524 288 envs over 8 ranks = shard_range(524288, 8, r), 65 536 contiguous envs each,
     every step's record and every episode's record gathered to rank 0 and checked there against the GLOBAL env index
