@@ -311,11 +311,11 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
         assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
 
 
-@pytest.mark.parametrize('world,extra', [(2, ['--launch', 'step']), (4, ['--launch', 'step', '--learner-rebuild', '2']), (2, []),
-                                         (3, ['--learner-rebuild', '1'])])
+@pytest.mark.parametrize('world,extra', [(2, []), (4, ['--learner-rebuild', '2']), (2, ['--launch', 'span']),
+                                         (3, ['--launch', 'span', '--learner-rebuild', '1'])])
 def test_bench_multi_rank_rehearsal(world, extra):
-    """bench.py's own multi-rank loops with ranks sharing the GPU over gloo -- one gather per step (--launch step) and the default:
-    runs of steps as spans, their records gathered with ONE collective per run -- record rotation, gathers inside the timed
+    """bench.py's own multi-rank loops with ranks sharing the GPU over gloo -- one gather per step (the default for N > 1) and
+    --launch span: runs of steps as spans, their records gathered with ONE collective per run -- record rotation, gathers inside the timed
     region, max over ranks, one JSON line from rank 0.  The line of an N > 1 run explains itself: every rank's own time per
     step, what each waited for the exchange, what rank 0 receives, and -- with --learner-rebuild -- what it costs rank 0 to turn
     peers' gathered steps back into node_obs / adj inside the timed loop."""
@@ -325,7 +325,7 @@ def test_bench_multi_rank_rehearsal(world, extra):
     lines = [l for l in out.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out[-4000:]
     d = json.loads(lines[0])
-    span = '--launch' not in extra
+    span = '--launch' in extra
     assert d['n_gpus'] == world and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
     assert d['config']['launch_mode'] == ('span' if span else 'step')
     assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
