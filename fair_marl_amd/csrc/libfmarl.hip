@@ -683,6 +683,11 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
     if (!h || !state || !outs || !span || !action_idx || n_steps < 0) return fail(FMARL_EINVAL, "fmarl_step_span: bad argument");
     const int sc = h->cfg.scenario;
     hipStream_t st = (hipStream_t)stream;
+    {   // a span decides on the host where episodes end: not for stream capture (capture fmarl_step calls instead)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(FMARL_EINVAL, "fmarl_step_span: not capturable (capture fmarl_step calls with FMARL_RESET_LOCKSTEP instead)");
+    }
     SpanStrides s = {span->obs, span->node_obs, span->adj, span->reward, span->done, span->info, span->edge_nnz, span->graph_record, span->actions};
     int t = 0;
     while (t < n_steps) {

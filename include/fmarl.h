@@ -240,7 +240,8 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
  * launch of its own (it commits / resets and, with the staged reset, waits for the staging that ran beside the span); so are
  * the first step after a reset (it enqueues that staging), every step while the envs are not in lockstep, and every step of
  * nav_fairassign_fairrew_formation_graph (whose step is a dependent chain, not a store stream: a span of it is slower).
- * The scripted / random-action rollout of the reference's throughput runs; a policy in the loop needs fmarl_step.
+ * The scripted / random-action rollout of the reference's throughput runs; a policy in the loop needs fmarl_step.  Not
+ * capturable into a hipGraph (it decides on the host where episodes end; it needs no graph: an episode is three launches).
  * Measured (profiles/r3_notes.md): 10 agents x 65 536 envs 0.250 -> 0.199 ms per step, 3 agents x 4 096 envs 14.5 -> 11.5 us. */
 typedef struct FmarlSpan {
     int64_t obs, node_obs, adj, reward, done, info, edge_nnz, graph_record;   /* per-step strides of the outputs, in elements */
