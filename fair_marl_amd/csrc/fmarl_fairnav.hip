@@ -25,7 +25,8 @@
 
 namespace fmarl {
 
-struct NavRow { int code; float occ, hist; };   // goal of an agent row: landmark index, -1 = own position
+struct NavRow { float occ; int8_t code, hist; int16_t pad; };   // goal of an agent row: landmark index (-1 = own position), its
+                                                              // occupancy and history (an agent index or -1): 8 bytes
 
 struct FairNavLds {
     char *base, *dead;   // the env's block / its part of the second region (tables nobody reads once the emission starts; the
@@ -77,9 +78,9 @@ struct FairNavLds {
         o[2] = dx; o[3] = dy; o[4] = dx; o[5] = dy; o[8] = dx; o[9] = dy; o[10] = dx; o[11] = dy;
         if (e < N) {
             const NavRow r = ((const NavRow *)(base + off_rows))[i * N + e];
-            const float2 gl = r.code >= 0 ? posf_[N + r.code] : pe;
+            const float2 gl = r.code >= 0 ? posf_[N + (uint32_t)r.code] : pe;
             o[4] = gl.x - pi.x; o[5] = gl.y - pi.y;
-            o[6] = r.occ; o[7] = r.hist;
+            o[6] = r.occ; o[7] = (float)r.hist;
             o[12] = 0.f;
         } else {
             o[6] = 1.f;
@@ -387,10 +388,11 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             const int astar = t.words()[0];                        // N = nobody
             const bool cleared = free_empty && astar < i;         // an earlier entity already cleared the flags
             NavRow r;
-            if (!far) { r.code = c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = (float)t.hist()[c]; }
-            else if (!free_empty) { r.code = best; r.occ = (float)t.occ()[best]; r.hist = (float)t.hist()[best]; }
-            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = (float)t.hist()[i]; }
-            else { r.code = c; r.occ = 0.f; r.hist = (float)t.hist()[c]; }   // after the clear every goal is free
+            r.pad = 0;
+            if (!far) { r.code = (int8_t)c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = (int8_t)t.hist()[c]; }
+            else if (!free_empty) { r.code = (int8_t)best; r.occ = (float)t.occ()[best]; r.hist = (int8_t)t.hist()[best]; }
+            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = (int8_t)t.hist()[i]; }
+            else { r.code = (int8_t)c; r.occ = 0.f; r.hist = (int8_t)t.hist()[c]; }   // after the clear every goal is free
             t.rows()[a * N + i] = r;
         }
         __syncthreads();
@@ -420,7 +422,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             r[4] = __float_as_uint(af.z);
             for (int e = 0; e < N; ++e) {
                 const NavRow nr = t.rows()[i * N + e];
-                r[5 + 3 * e] = (uint32_t)nr.code; r[6 + 3 * e] = __float_as_uint(nr.occ); r[7 + 3 * e] = __float_as_uint(nr.hist);
+                r[5 + 3 * e] = (uint32_t)(int32_t)nr.code; r[6 + 3 * e] = __float_as_uint(nr.occ); r[7 + 3 * e] = __float_as_uint((float)nr.hist);
             }
         }
         if (STEP) {
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, Fma
         t.agentf()[i] = make_float4(__uint_as_float(r[2]), __uint_as_float(r[3]), __uint_as_float(r[4]), 0.f);
         for (int e = 0; e < N; ++e) {
             NavRow nr;
-            nr.code = (int)r[5 + 3 * e]; nr.occ = __uint_as_float(r[6 + 3 * e]); nr.hist = __uint_as_float(r[7 + 3 * e]);
+            nr.code = (int8_t)(int32_t)r[5 + 3 * e]; nr.occ = __uint_as_float(r[6 + 3 * e]); nr.hist = (int8_t)__uint_as_float(r[7 + 3 * e]); nr.pad = 0;
             t.rows()[i * N + e] = nr;
         }
         if (i == 0) *t.flag() = 0;

@@ -349,7 +349,20 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         form_dead = p.lds2_bytes = d;
     }
     if (fnav) {   // fmarl_fairnav.hip FairNavLds
-        p.n_rows = off;    off = align16(off + p.N * p.N * 12);
+        // the env's block packed to 8 bytes, 8-byte row records: 352 + 288 = 640 bytes per env at N = 3, i.e. 64 envs per
+        // workgroup in 40 KB = 1 024 workgroups for 65 536 envs (measured the same as 48 or 59 envs per workgroup: the launch
+        // time of this kernel stopped following the workgroup count beyond 36, profiles/r3_notes.md)
+        int o2 = 0;
+        p.lds_pos = o2;    o2 += p.E * 16;
+        p.lds_agentf = o2; o2 += p.N * 16;
+        p.lds_wall = o2;   o2 += p.W * 32;
+        p.lds_wallf = o2;  o2 += p.W * 16;
+        p.lds_posf = o2;   o2 += p.E * 8;      // (16-byte reads of it only when E % 4 == 0: the table then is a multiple of 32 bytes)
+        p.n_rows = o2;     o2 += p.N * p.N * 8;
+        p.lds_flag = o2;   o2 += 8;
+        p.lds_cnt = p.lds_flag + 4;
+        p.lds_constf = p.lds_ego = o2;
+        off = align16(o2);
         // Tables nobody reads once the emission starts: a region of their own behind all envs' blocks, which the waves' emission
         // windows alias (13.5 KB that used to sit beside the envs' tables: 36 -> 58 envs per workgroup in the shipped FA+FR
         // configuration, and the launch time falls with the number of workgroups: tools/epb_sweep.py fnav)
