@@ -634,8 +634,8 @@ def main():
         ceiling_ms = store_ceiling_ms(eng) if pipe is None else None
         launch_text = {
             'span': 'fmarl_step_span: the steps between episode ends as ONE launch in which every workgroup walks its own envs through '
-                    'time (%d envs per workgroup; state in registers, static entities in LDS between the steps), the first step of an '
-                    'episode and the step that ends it as launches of their own: %d launches for the %d timed steps'
+                    'time (%d envs per workgroup; state in registers, static entities in LDS between the steps), the step that ends an episode '
+                    'as a launch of its own: %d launches for the %d timed steps'
                     % (eng.envs_per_workgroup, len(kernel_ms), K),
             'step': ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
                      % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step'),

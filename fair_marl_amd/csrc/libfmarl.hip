@@ -704,12 +704,12 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
     SpanStrides s = {span->obs, span->node_obs, span->adj, span->reward, span->done, span->info, span->edge_nnz, span->graph_record, span->actions};
     int t = 0;
     while (t < n_steps) {
-        // steps that certainly end no episode go out as one span launch; the first step after a reset (it enqueues the
-        // staging), the step that ends an episode and envs out of lockstep go through fmarl_step.  The third scenario's
+        // steps that certainly end no episode go out as one span launch; the step that ends an episode and envs out of
+        // lockstep go through fmarl_step.  The third scenario's
         // episodes end env by env and its step is one workgroup's dependent chain, not a store stream: a span kernel of it
         // measured SLOWER than a launch per step (0.086 vs 0.075 ms per step, profiles/r3_notes.md), so it always steps.
         int k = 0;
-        if (sc != FMARL_SCENARIO_FAIRNAV && h->lockstep && !h->stage_pending) k = h->cfg.episode_length - 1 - h->host_step;
+        if (sc != FMARL_SCENARIO_FAIRNAV && h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;
         if (k > n_steps - t) k = n_steps - t;
         FmarlOutputs o = *outs;
         if (o.obs) o.obs += (size_t)t * span->obs;
@@ -723,6 +723,12 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
         const int32_t *a = action_idx + (size_t)t * span->actions;
         if (k >= 2) {
             DeviceGuard on_device(h);
+            if (h->stage_pending) {   // the span starts an episode: stage the one after it on the side stream first (as fmarl_step would)
+                h->stage_pending = false;
+                h->cap_id = 0;
+                int rc = launch_stage(h, state, st);
+                if (rc) return rc;
+            }
             Params p = bind(h, state);
             if (!outputs_aligned(p, &o)) return fail(FMARL_EINVAL, "fmarl_step_span: node_obs / adj must be 16-byte aligned for this shape");
             const bool prof = h->ev && h->ev_n < h->ev_cap;

@@ -238,7 +238,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
  * stride n * ...).  Envs never interact, so inside a span every workgroup walks its own envs through the steps without waiting
  * for the rest of the batch: no per-step launch, no per-step head and tail of the grid.  The step that ends an episode is a
  * launch of its own (it commits / resets and, with the staged reset, waits for the staging that ran beside the span); so are
- * the first step after a reset (it enqueues that staging), every step while the envs are not in lockstep, and every step of
+ * every step while the envs are not in lockstep and every step of
  * nav_fairassign_fairrew_formation_graph (whose step is a dependent chain, not a store stream: a span of it is slower).
  * The scripted / random-action rollout of the reference's throughput runs; a policy in the loop needs fmarl_step.  Not
  * capturable into a hipGraph (it decides on the host where episodes end; it needs no graph: an episode is three launches).

@@ -330,9 +330,9 @@ def test_bench_multi_rank_rehearsal(world, extra):
     assert d['config']['launch_mode'] == ('span' if span else 'step')
     assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
     assert 'cpu_baseline' not in d and d['n_ranks_seen'] == world
-    if span:   # steps 5..34: [5, 25) = a run of 19 + the episode end, [25, 35) = the episode's first step + a run of 9
+    if span:   # steps 5..34: [5, 25) = a run of 19 + the episode end, [25, 35) = a run of 10
         assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == 2
-        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(14.0) and 'one per run of steps (2 ' in d['multi_gpu']['collectives']
+        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(14.5) and 'one per run of steps (2 ' in d['multi_gpu']['collectives']
     else:
         assert d['roofline']['kernel_launches'] == 30 and d['roofline']['kernel_steps_per_launch'] == 1.0
     assert '512 envs per GPU' in d['config']['workload'] and d['roofline']['traffic'] is None   # --n-envs: no replayed 65 536-env counters
