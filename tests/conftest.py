@@ -34,7 +34,7 @@ def pytest_collection_modifyitems(config, items):
             return fn(self, *a, **kw)
         call.__name__, call.__doc__ = fn.__name__, fn.__doc__
         return call
-    for name in ('step', 'reset', 'rebuild_graph', 'update_graph', 'process_adj', 'process_infos', 'lexifair', 'cost_matrix'):
+    for name in ('step', 'step_span', 'reset', 'rebuild_graph', 'update_graph', 'process_adj', 'process_infos', 'lexifair', 'cost_matrix'):
         if hasattr(RolloutEngine, name):
             setattr(RolloutEngine, name, poisoned(getattr(RolloutEngine, name)))
     RolloutEngine._poisoned = True
