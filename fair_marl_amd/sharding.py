@@ -118,6 +118,15 @@ class TrajectoryGather(object):
 
     def __init__(self, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0,
                  force_collective=False, graph_words=0, timing=False):
+        self._setup_exchange(n_envs, device, group, dst, depth, episode_words, force_collective, timing)
+        self.records = [StepRecord(n_envs, num_agents, obs_dim, device, graph_words) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.recv = None
+        if self.collective and self.rank == dst:
+            self.recv = [[torch.zeros_like(r.flat) for _ in range(self.world)] for r in self.records]
+
+    def _setup_exchange(self, n_envs, device, group, dst, depth, episode_words, force_collective, timing):
+        """What the per-step and the per-run exchange share: the group, the wait clocks, the episode records."""
         self.group, self.dst, self.depth = group, dst, depth
         # timing: how long the rollout is held up by the exchange.  Two clocks, because an RCCL work's wait() only makes the
         # current STREAM wait (the host returns at once) while a gloo work's wait() blocks the HOST: ``host_wait_s``
@@ -129,11 +138,6 @@ class TrajectoryGather(object):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # force_collective: issue the gathers even in a group of ONE rank (the RCCL path on a one-GPU box)
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
-        self.records = [StepRecord(n_envs, num_agents, obs_dim, device, graph_words) for _ in range(depth)]
-        self.pending = [None] * depth
-        self.recv = None
-        if self.collective and self.rank == dst:
-            self.recv = [[torch.zeros_like(r.flat) for _ in range(self.world)] for r in self.records]
         # episode records (int32 words per env), two in rotation: the one of the running episode stays readable
         # on the learner while the next one is gathered
         self.ep_send = [torch.zeros(int(n_envs), int(episode_words), dtype=torch.int32, device=device) for _ in range(2)]
@@ -245,11 +249,8 @@ class SpanGather(TrajectoryGather):
 
     def __init__(self, max_steps, n_envs, num_agents, obs_dim, device, group=None, dst=0, depth=2, episode_words=0,
                  force_collective=False, graph_words=0, timing=False):
-        TrajectoryGather.__init__(self, 1, num_agents, obs_dim, device, group=group, dst=dst, depth=depth, episode_words=0,
-                                  force_collective=force_collective, graph_words=0, timing=timing)   # (its per-step records stay unused: one env)
-        self.ep_send = [torch.zeros(int(n_envs), int(episode_words), dtype=torch.int32, device=device) for _ in range(2)]
-        if self.collective and self.rank == dst:
-            self.ep_recv = [[torch.zeros_like(b) for _ in range(self.world)] for b in self.ep_send]
+        self._setup_exchange(n_envs, device, group, dst, depth, episode_words, force_collective, timing)
+        self.records, self.pending, self.recv = [], [None] * depth, None   # (no per-step records: ``record`` / ``submit`` are not for spans)
         self.spans = [SpanRecord(max_steps, n_envs, num_agents, obs_dim, device, graph_words) for _ in range(depth)]
         self.span_pending, self.span_steps = [None] * depth, [0] * depth
         self.span_recv = None
