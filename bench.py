@@ -57,7 +57,7 @@ KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassig
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
 SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'span'),
-             ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('n10', 'eager'), ('n10', 'span'))
+             ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
@@ -133,7 +133,8 @@ def secondary_line(name, mode, device, steps=300, warmup=50):
     ep = cfg.episode_length
     steps, warmup = max(ep, steps // ep * ep), (warmup + ep - 1) // ep * ep
     if mode.startswith('pipeline'):
-        return secondary_pipeline(name, int(mode[len('pipeline'):]), device, steps, warmup)
+        spans = mode.endswith('span')
+        return secondary_pipeline(name, int(mode[len('pipeline'):].replace('span', '')), device, steps, warmup, spans)
     eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=SPAN_EPB.get(name, 0) if mode == 'span' else 0)
     g = torch.Generator(device=device)
     g.manual_seed(2000)
@@ -182,11 +183,12 @@ def secondary_line(name, mode, device, steps=300, warmup=50):
     return out
 
 
-def secondary_pipeline(name, k, device, steps, warmup):
+def secondary_pipeline(name, k, device, steps, warmup, spans=False):
     """The same envs as k sub-batches on k streams (fair_marl_amd.PipelinedRollout; bit-identical results): the tail of one
-    sub-batch's launch overlaps the head of another's next step.  What a random-action rollout -- actions known ahead -- or an
-    alternating sampler gets out of the chip for the compute-heavy scenarios; `frac` is the whole job's algorithmic bytes per
-    step over the time per step (a launch that shares the chip is longer than it would be alone)."""
+    sub-batch's launch overlaps the head of another's.  What a random-action rollout -- actions known ahead -- or an
+    alternating sampler gets out of the chip for the compute-heavy scenarios; with ``spans`` every sub-batch runs its steps as
+    spans (PipelinedRollout.rollout).  `frac` is the whole job's algorithmic bytes per step over the time per step (a launch
+    that shares the chip is longer than it would be alone)."""
     spec = CONFIGS[name]
     cfg = fm.EnvConfig(**spec['env'])
     n, ep = spec['n_envs'], cfg.episode_length
@@ -194,31 +196,36 @@ def secondary_pipeline(name, k, device, steps, warmup):
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
+    tapes = pipe.split_tape(tape)
+    mode = 'span' if spans else 'eager'
     pipe.reset()
-    for t in range(warmup):
-        pipe.step(tape[t % ep])
+    for _ in range(max(1, warmup // ep)):
+        pipe.rollout(tapes, mode=mode)
     pipe.synchronize()
     torch.cuda.synchronize(device)
     for e in pipe.engines:
         e.profile_enable(steps)
     c0 = [e.launch_counts() for e in pipe.engines]
     t0 = time.perf_counter()
-    for t in range(steps):
-        pipe.step(tape[t % ep])
+    for _ in range(steps // ep):
+        pipe.rollout(tapes, mode=mode)
     pipe.synchronize()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     kernel_ms = [v for e in pipe.engines for v in e.profile_read()]
-    per_launch = float(np.mean([launch_bytes(cfg, (n // k) * cfg.N, a, e.launch_counts()) for a, e in zip(c0, pipe.engines)]))
-    job = per_launch * k / (elapsed / steps) / 1e9
-    out = dict(config=name, mode='pipeline%d' % k, workload=spec['workload'] % n, launch='%d sub-batches of %d envs on their own streams, one fmarl_step call per '
-               'sub-batch and step' % (k, n // k), value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup,
-               ms_per_step=elapsed / steps * 1e3, kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel'),
-               kernel_avg_ms=float(np.mean(kernel_ms)), frac=job / HBM_PEAK_GBS,
-               frac_basis='whole job: algorithmic bytes per step of all envs / time per step (kernel_avg_ms is ONE sub-batch launch while others run)',
-               algorithmic_bytes_per_step=per_launch * k, store_ceiling_ms=None, frac_of_box_ceiling=None)
+    c1 = [e.launch_counts() for e in pipe.engines]
+    per_step_sub = float(np.mean([launch_bytes(cfg, (n // k) * cfg.N, a, b) for a, b in zip(c0, c1)]))
+    job = per_step_sub * k / (elapsed / steps) / 1e9
+    out = dict(config=name, mode='pipeline%d%s' % (k, 'span' if spans else ''), workload=spec['workload'] % n,
+               launch='%d sub-batches of %d envs on their own streams, each %s' % (k, n // k, 'running its steps as spans (fmarl_step_span)'
+                                                                                   if spans else 'one fmarl_step call per step'),
+               value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup,
+               ms_per_step=elapsed / steps * 1e3, kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel' if spans else 'step_kernel / step_end_kernel'),
+               kernel_avg_ms=float(np.sum(kernel_ms)) / sum(b[0] - a[0] for a, b in zip(c0, c1)), kernel_launches=len(kernel_ms), frac=job / HBM_PEAK_GBS,
+               frac_basis='whole job: algorithmic bytes per step of all envs / time per step (kernel_avg_ms: a sub-batch\'s step kernels per step, while others run)',
+               algorithmic_bytes_per_step=per_step_sub * k, store_ceiling_ms=None, frac_of_box_ceiling=None)
     pipe.close()
-    del pipe, tape
+    del pipe, tape, tapes
     torch.cuda.empty_cache()
     return out
 

@@ -2,7 +2,7 @@
 
 A step kernel over 65 536 envs has a head (every workgroup loads, then computes, then stores at the same time) and a
 tail (the last workgroups of the grid run on a nearly empty chip); at BASELINE config 4 the two are about a sixth of the
-launch (``tools/two_stream.py``: the launch time is 0.05 ms + 0.255 ms per 65 536 envs).  Envs are independent
+launch (``tools/archive/two_stream.py``: the launch time is 0.05 ms + 0.255 ms per 65 536 envs).  Envs are independent
 (the reference steps them in separate OS processes, onpolicy/envs/env_wrappers.py:951-1026), so consecutive steps of
 DIFFERENT envs need no ordering: the batch is split into k contiguous sub-batches, each a ``RolloutEngine`` on its own
 stream with ``env_offset`` so that the union is the same set of envs with the same random streams, and the tail of one
@@ -69,6 +69,24 @@ class PipelinedRollout:
                 parts[j].record_stream(self.streams[j])   # allocated on the caller's stream, read on this one
             e.step(parts[j], auto_reset=auto_reset)
         self._each(one)
+
+    def rollout(self, action_tapes, mode=None):
+        """``RolloutEngine.rollout`` of every sub-batch on its own stream: ``action_tapes`` = one contiguous (T, n_envs / k, N)
+        int32 device tape per sub-batch (a slice of a (T, n_envs, N) tape along the env axis is not contiguous: split the
+        tape once, ``split_tape``).  With spans (the engines' default mode) a sub-batch's run of steps is one launch, and the
+        launch boundaries of one sub-batch -- the episode-ending step between two runs, where the chip drains and refills --
+        fall into the other's steady state: 10 agents x 65 536 envs 0.181 -> 0.163 ms per step (profiles/r3_notes.md)."""
+        if len(action_tapes) != self.k:
+            raise ValueError('expected %d per-sub-batch tapes, got %d' % (self.k, len(action_tapes)))
+
+        def one(j, e):
+            action_tapes[j].record_stream(self.streams[j])
+            e.rollout(action_tapes[j], mode=mode)
+        self._each(one)
+
+    def split_tape(self, action_tape):
+        """(T, n_envs, N) -> k contiguous (T, n_envs / k, N) tapes, sub-batch j holding the envs [j n_envs / k, (j + 1) n_envs / k)."""
+        return [action_tape[:, j * self.n_sub:(j + 1) * self.n_sub].contiguous() for j in range(self.k)]
 
     def join(self, j=None):
         """Order the caller's stream behind sub-batch j's last step (all sub-batches if None)."""

@@ -482,6 +482,30 @@ def test_shards_reproduce_the_unsharded_rollout(kw):
         same('step %d' % t)
 
 
+@pytest.mark.parametrize('kw', SHARD_CASES[:2], ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
+def test_pipelined_rollout_as_spans_reproduces_the_single_engine(kw):
+    """PipelinedRollout.rollout: every sub-batch runs its steps as spans on its own stream; the union equals one engine stepping
+    the same tape (two and a half episodes), bit for bit."""
+    cfg = fm.EnvConfig(**kw)
+    n, k, T = 96, 2, 2 * cfg.episode_length + cfg.episode_length // 2
+    one = fm.RolloutEngine(cfg, n, device=DEV, seed=4)
+    pipe = fm.PipelinedRollout(cfg, n, k=k, device=DEV, seed=4)
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    tape = torch.randint(0, 5, (T, n, cfg.N), device=DEV, generator=gen, dtype=torch.int32)
+    one.reset(); pipe.reset()
+    for t in range(T):
+        one.step(tape[t])
+    pipe.rollout(pipe.split_tape(tape))
+    pipe.join()
+    torch.cuda.synchronize()
+    for name in ('obs', 'node_obs', 'adj_env', 'reward', 'done'):
+        assert torch.equal(pipe.gather(name), getattr(one.outs, name) if name != 'adj_env' else one.adj_env), name
+    st = one.get_state()
+    parts = [e.get_state() for e in pipe.engines]
+    for key in st:
+        assert np.array_equal(np.concatenate([p[key] for p in parts], axis=0), st[key]), key
+
+
 @pytest.mark.parametrize('kw', SHARD_CASES, ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
 @pytest.mark.parametrize('k', [2, 3])
 def test_pipelined_sub_batches_reproduce_the_single_engine(kw, k):
