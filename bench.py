@@ -57,7 +57,7 @@ KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassig
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
 SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'span'),
-             ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
+             ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'pipeline2'), ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
