@@ -290,8 +290,9 @@ def main():
                          'every workgroup walks its own envs through time, the episode-ending step a launch of its own (actions '
                          'come from a tape: BASELINE\'s random-action rollout); step: one fmarl_step call per step (what a policy in '
                          'the loop gets); graph: one hipGraph replay per episode (N=1).  auto = span for N = 1 (except for '
-                         'nav_fairassign_fairrew_formation_graph: its span is a loop of steps anyway), step for N > 1 (a step\'s gather hides '
-                         'behind the next step; a run\'s gather can only start when its launch has ended)')
+                         'nav_fairassign_fairrew_formation_graph: its span is a loop of steps anyway) and for N > 1 from four episodes of timed '
+                         'steps on, step for shorter N > 1 runs (a step\'s gather hides behind the next step; a run\'s gather can only '
+                         'start when its launch has ended and the last one is exposed)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: skip the RCCL trajectory gather')
     ap.add_argument('--record-path', action='store_true', help='N=1: write the step records / episode records as the '
@@ -373,10 +374,7 @@ def main():
     if args.pipeline > 1:
         launch = 'step'
     if launch == 'auto':
-        # N = 1: spans.  N > 1: one launch and one gather per step -- a run's records can only leave when its launch has ended,
-        # so the gather of the LAST run of a timed region is exposed in full (19 steps x 69 MB x 7 peers into rank 0 behind a
-        # 27 ms region at cfg 3), where a step's gather hides behind the next step; for long regions --launch span wins again
-        launch = 'step' if (fnav_sc or world > 1) else 'span'
+XX
     if launch == 'graph':
         if world > 1:
             raise SystemExit('bench.py: --launch graph is a single-GPU mode')
