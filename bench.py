@@ -374,7 +374,11 @@ def main():
     if args.pipeline > 1:
         launch = 'step'
     if launch == 'auto':
-XX
+        # N = 1: spans.  N > 1, short timed regions: one launch and one gather per step -- a run's records can only leave when
+        # its launch has ended, so the gather of the LAST run of the region is exposed in full (19 steps x 69 MB x 7 peers into
+        # rank 0 behind a 27 ms region at cfg 3), where a step's gather hides behind the next step; from four episodes of timed
+        # steps on the spans win again
+        launch = 'step' if (fnav_sc or (world > 1 and K < 4 * ep)) else 'span'
     if launch == 'graph':
         if world > 1:
             raise SystemExit('bench.py: --launch graph is a single-GPU mode')
