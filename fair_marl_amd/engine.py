@@ -152,7 +152,7 @@ class RolloutEngine:
             torch.cuda.empty_cache()   # hand the losing allocations back to the driver
         self.placement_ms = times
 
-    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None, graph_record=None):
+    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None, graph_record=None, info_planes=None):
         """A set of per-step output buffers.  By default node_obs / adj are shared by all sets (large,
         consumed before the next step) while obs / reward / done / info are per set, so a set can still
         be read (e.g. by an in-flight RCCL gather, see sharding.py) while the next step writes another.
@@ -165,8 +165,12 @@ class RolloutEngine:
             o.reward = mk(reward, (n, N), torch.float32)
             o.done = mk(done, (n, N), torch.uint8)
             # field-major planes on the device (coalesced stores); exposed as an (n, N, K) view
-            o.info_planes = torch.zeros(_lib.INFO_WIDTH, n, N, dtype=torch.float32, device=self.device) if self.emit_info else None
-            o.info = o.info_planes.permute(1, 2, 0) if self.emit_info else None
+            o.info_planes = info_planes if info_planes is not None else (
+                torch.zeros(_lib.INFO_WIDTH, n, N, dtype=torch.float32, device=self.device) if self.emit_info else None)
+            if o.info_planes is not None and (tuple(o.info_planes.shape) != (_lib.INFO_WIDTH, n, N) or o.info_planes.dtype != torch.float32
+                                              or not o.info_planes.is_contiguous()):
+                raise ValueError('info_planes must be a contiguous float32 tensor of shape %s' % ((_lib.INFO_WIDTH, n, N),))
+            o.info = o.info_planes.permute(1, 2, 0) if o.info_planes is not None else None
             o.node_obs = node_obs if node_obs is not None else self._default_graph[0]
             o.adj_env = adj_env if adj_env is not None else self._default_graph[1]
             o.edge_nnz = torch.zeros(n, dtype=torch.int32, device=self.device) if self.count_edges else None

@@ -36,6 +36,7 @@ class DeviceRolloutBuffer(object):
         self.active_masks = torch.ones(T + 1, n, N, 1, dtype=torch.float32, device=dev)
         self.agent_id = torch.arange(N, dtype=torch.int32, device=dev).view(1, 1, N, 1).expand(T + 1, n, N, 1)
         self.share_agent_id = torch.arange(N, dtype=torch.int32, device=dev).view(1, 1, 1, N).expand(T + 1, n, N, N)
+        self.info_planes = z(T + 1, 14, n, N) if eng.emit_info else None   # one set of info planes per slot (the last step's: process_infos)
         self._scratch_reward = z(n, N)
         self._scratch_done = z(n, N, dtype=torch.uint8)
         # slot t receives the observation that FOLLOWS step t - 1; reward / done of step t go to index t
@@ -43,8 +44,8 @@ class DeviceRolloutBuffer(object):
         for t in range(T + 1):
             rew = self.rewards[t - 1].view(n, N) if t >= 1 else self._scratch_reward
             done = self.dones[t - 1] if t >= 1 else self._scratch_done
-            self._sets.append(eng.new_output_set(obs=self.obs[t], reward=rew, done=done,
-                                                 node_obs=self.node_obs[t], adj_env=self.adj_env[t]))
+            self._sets.append(eng.new_output_set(obs=self.obs[t], reward=rew, done=done, node_obs=self.node_obs[t], adj_env=self.adj_env[t],
+                                                 info_planes=self.info_planes[t] if self.info_planes is not None else None))
         self.step = 0
 
     # views in the reference's shapes ---------------------------------------------------------------
@@ -85,8 +86,7 @@ class DeviceRolloutBuffer(object):
         """``insert_step(action_tape[t])`` for every t through ONE ``fmarl_step_span`` call: the time slots are contiguous
         (T + 1, n, ...) arrays, so step t's obs / node_obs / adj land in slot ``step + t + 1`` and its reward / done at index
         ``step + t`` by per-step strides; the masks of the runner's insert are formed for all steps at once afterwards.
-        Same buffer contents as T ``insert_step`` calls, bit for bit.  (The info planes are one array per slot: the planes
-        of the slot the span starts in receive every step's infos, the last step's are what ``process_infos`` sees.)"""
+        Same buffer contents as T ``insert_step`` calls, bit for bit, the per-slot info planes included."""
         eng, t0 = self.engine, self.step
         tape = action_tape.to(eng.device)
         T = int(tape.shape[0])
@@ -96,15 +96,13 @@ class DeviceRolloutBuffer(object):
         first = self._sets[t0 + 1]
         eng.use_outputs(first)
         eng.step_span(tape, strides=dict(obs=self.obs[0].numel(), node_obs=self.node_obs[0].numel(), adj=self.adj_env[0].numel(),
-                                         reward=n * N, done=n * N))
+                                         reward=n * N, done=n * N, info=self.info_planes[0].numel() if self.info_planes is not None else 0))
         done = self.dones[t0:t0 + T].to(torch.bool)                         # (T, n, N)
         done_env = done.all(dim=2, keepdim=True)
         self.masks[t0 + 1:t0 + T + 1] = (~done).to(torch.float32).unsqueeze(-1)
         self.active_masks[t0 + 1:t0 + T + 1] = (~(done & ~done_env)).to(torch.float32).unsqueeze(-1)
         self.step = t0 + T
         last = self._sets[self.step]
-        if first.info_planes is not None and last is not first:
-            last.info_planes.copy_(first.info_planes)                       # the infos of the last step, where insert_step leaves them
         eng.use_outputs(last)
         return last
 

@@ -82,6 +82,33 @@ def test_engine_equals_the_reference_on_the_philox_stream(name, geom):
 
 
 @pytest.mark.parametrize('name', RUNNER)
+def test_span_equals_the_reference_on_the_philox_stream(name):
+    """The same reference rollouts through fmarl_step_span: the whole action tape of the fixture in ONE call (runs of steps as
+    single launches, the episode ends as launches of their own; the third scenario steps), every step's outputs written
+    through per-step strides and compared with the reference's own outputs of that step."""
+    fx = load(name)
+    eng, cfg, args, n = engine_of(fx)
+    T = fx['actions'].shape[0]
+    N, E, D, F = cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat
+    z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=DEV)  # noqa: E731
+    big = dict(obs=z(T, n, N, D), node_obs=z(T, n, N, E, F), adj=z(T, n, E, E), reward=z(T, n, N), done=z(T, n, N, dt=torch.uint8),
+               info=z(T, 14, n, N))
+    eng.reset()
+    eng.use_outputs(eng.new_output_set(obs=big['obs'][0], node_obs=big['node_obs'][0], adj_env=big['adj'][0], reward=big['reward'][0],
+                                       done=big['done'][0], info_planes=big['info'][0]))
+    eng.step_span(torch.as_tensor(fx['actions'], dtype=torch.int32, device=DEV).contiguous(), strides={k: v[0].numel() for k, v in big.items()})
+    torch.cuda.synchronize()
+    keys = [str(k) for k in fx['info_keys']]
+    slot = dict(fm.infos.key_map(cfg.scenario_name))
+    for k in ('obs', 'node_obs', 'adj', 'reward'):
+        np.testing.assert_allclose(big[k].cpu().numpy(), fx[k], err_msg='%s %s' % (name, k), **F32)
+    assert np.array_equal(big['done'].cpu().numpy().astype(bool), fx['done'])
+    info = big['info'].permute(0, 2, 3, 1).cpu().numpy()                     # (T, n, N, 14)
+    np.testing.assert_allclose(np.stack([info[..., slot[k]] for k in keys], axis=-1), fx['info'], err_msg=name + ' info', **F32)
+    assert fx['reset_count'].sum() >= 2
+
+
+@pytest.mark.parametrize('name', RUNNER)
 def test_device_rollout_buffer_equals_the_reference_replay_buffer(name):
     """DeviceRolloutBuffer (filled in place by the kernels) vs GraphReplayBuffer after the reference runner's
     warmup / insert / after_update; processAdj on stored slots; process_infos and the metric readers at episode end."""
