@@ -357,6 +357,11 @@ __device__ __forceinline__ void emit_node_rows_generic(const Params &p, const Fm
 __device__ __forceinline__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x;
     const uint32_t NEF = p.N * p.E * p.F, EF = p.E * p.F, EE = p.E * p.E;
+    // odd workgroups write adj first: the two output streams are then mixed over the chip at any time, instead of every
+    // workgroup of a generation being in the node stream and then every one in the adj stream (cfg 3, one launch per step:
+    // 1.602 -> 1.592 ms and 1.490 -> 1.479 on two boxes, profiles/r3_notes.md)
+    const bool adj_first = (blockIdx.x & 1) != 0;
+    if (adj_first) emit_adj(p, o, lds, env0, 0, nenv, tid, kThreads);
     if (o.node_obs && p.vec_node) {
         const uint32_t groups = ((EF >> 2) + 63) >> 6;
         if (groups <= 1) emit_node_rows<1>(p, o, lds, env0, nenv);
@@ -369,7 +374,7 @@ __device__ __forceinline__ void emit_graph(const Params &p, const FmarlOutputs &
         if (p.feat_global) emit_node_rows_generic<true>(p, o, lds, env0, nenv);
         else emit_node_rows_generic<false>(p, o, lds, env0, nenv);
     }
-    emit_adj(p, o, lds, env0, 0, nenv, tid, kThreads);
+    if (!adj_first) emit_adj(p, o, lds, env0, 0, nenv, tid, kThreads);
 }
 
 // f32 rows of agent i used by the emission: agentf = (vx, vy, gx, gy), ego = [vx vy x y 0].
