@@ -1095,6 +1095,29 @@ def test_step_span_equals_step_by_step(kw, geom):
             assert torch.equal(ra[k], rb[k]), (t, k)
 
 
+def test_step_span_refuses_what_it_cannot_do():
+    """A span decides on the host where episodes end: it is refused inside a stream capture (with a message that says what to
+    capture instead), and a tape of the wrong shape / dtype / device never reaches the library."""
+    import gc
+    cfg = fm.EnvConfig(num_agents=3, num_landmarks=3, num_obstacles=2, episode_length=6)
+    n = 40
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=1)
+    eng.reset()
+    tape = torch.zeros(4, n, 3, dtype=torch.int32, device=DEV)
+    for bad in (tape[:, :, :2], tape.to(torch.int64), tape.cpu(), tape[:, ::2]):
+        with pytest.raises(ValueError, match='action tape'):
+            eng.step_span(bad)
+    gc.collect()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with pytest.warns(UserWarning, match='empty'), pytest.raises(RuntimeError, match='not capturable'):
+        with torch.cuda.graph(g):
+            eng.step_span(tape)
+    eng.step_span(tape)      # and the handle is as it was
+    torch.cuda.synchronize()
+    assert eng.phase == 4
+
+
 def test_rollout_buffer_insert_span_equals_insert_step():
     """DeviceRolloutBuffer.insert_span: a whole rollout through one fmarl_step_span call, the time slots addressed by per-step
     strides -- same buffer (obs / node_obs / adj / rewards / dones / masks / active_masks) and the same episode metrics as
