@@ -59,7 +59,7 @@ _SIGS = {
     'fmarl_reset': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs), C.c_void_p]),
     'fmarl_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FmarlOutputs),
                              C.c_int, C.c_void_p]),
-    'fmarl_step_span': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FmarlOutputs), C.POINTER(FmarlSpan), C.c_void_p]),
+    'fmarl_step_span': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FmarlOutputs), C.POINTER(FmarlSpan), C.c_void_p]),
     'fmarl_get_phase': (C.c_int, [C.c_void_p]),
     'fmarl_set_phase': (C.c_int, [C.c_void_p, C.c_int]),
     'fmarl_state_changed': (C.c_int, [C.c_void_p]),

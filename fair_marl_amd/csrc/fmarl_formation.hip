@@ -576,11 +576,13 @@ __global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutp
 }
 
 // fmarl_step_span for fair_graph_formation: T steps of the workgroup's own envs in one launch (no episode ends inside).
-__global__ __launch_bounds__(kThreads, 4) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, int T) {
+__global__ __launch_bounds__(kThreads, 4) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx,
+                                                                     const float *action_vec, int T) {
     for (int t = 0; t < T; ++t) {
         const Params q = span_params(p);
         const FmarlOutputs ot = span_outputs(o, s, t);
-        formation_body<true>(q, ot, action_idx + (size_t)t * s.actions, nullptr, 0);
+        formation_body<true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr,
+                             action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0);
         span_step_done();
     }
 }

@@ -805,18 +805,19 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
 
 // A run of T consecutive steps of the SAME workgroup's envs in one launch (fmarl_step_span): envs never interact, so a
 // workgroup can walk its own envs through time without waiting for the rest of the batch.  Step t reads the actions at
-// action_idx + t * span.actions and writes the outputs shifted by the span's per-step strides (0 = the same buffer every
+// action_idx (or action_vec) + t * span.actions and writes the outputs shifted by the span's per-step strides (0 = the same buffer every
 // step).  No episode ends inside a span (the host splits there).  Between the steps the agent's state stays in registers and
 // the static entities in the LDS tables (StepCarry): only the first step loads the state, only the last one stores it, and
 // the step body's own barriers are all the ordering the steps need (a step's first LDS writes come two barriers after its
 // start, by when every wave has left the previous step's emission).
 __global__ __launch_bounds__(kThreads, 3) void step_span_kernel(
-    Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, int T) {
+    Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, const float *action_vec, int T) {
     StepCarry c = {};
     for (int t = 0; t < T; ++t) {
         const Params q = span_params(p);
         const FmarlOutputs ot = span_outputs(o, s, t);
-        step_body<false>(q, ot, action_idx + (size_t)t * s.actions, nullptr, 0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));
+        step_body<false>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr, action_vec ? action_vec + (size_t)t * s.actions : nullptr,
+                         0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));
     }
 }
 

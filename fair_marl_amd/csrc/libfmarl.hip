@@ -690,10 +690,12 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     return FMARL_OK;
 }
 
-int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_steps, const FmarlOutputs *outs,
-                    const FmarlSpan *span, void *stream) {
+int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const float *action_vec, int n_steps,
+                    const FmarlOutputs *outs, const FmarlSpan *span, void *stream) {
     Handle *h = (Handle *)handle;
-    if (!h || !state || !outs || !span || !action_idx || n_steps < 0) return fail(FMARL_EINVAL, "fmarl_step_span: bad argument");
+    if (!h || !state || !outs || !span || n_steps < 0) return fail(FMARL_EINVAL, "fmarl_step_span: bad argument");
+    if ((action_idx == nullptr) == (action_vec == nullptr))
+        return fail(FMARL_EINVAL, "fmarl_step_span: pass exactly one of action_idx / action_vec");
     const int sc = h->cfg.scenario;
     hipStream_t st = (hipStream_t)stream;
     {   // a span decides on the host where episodes end: not for stream capture (capture fmarl_step calls instead)
@@ -720,7 +722,8 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
         if (o.info) o.info += (size_t)t * span->info;
         if (o.edge_nnz) o.edge_nnz += (size_t)t * span->edge_nnz;
         if (o.graph_record) o.graph_record += (size_t)t * span->graph_record;
-        const int32_t *a = action_idx + (size_t)t * span->actions;
+        const int32_t *a = action_idx ? action_idx + (size_t)t * span->actions : nullptr;
+        const float *av = action_vec ? action_vec + (size_t)t * span->actions : nullptr;
         if (k >= 2) {
             DeviceGuard on_device(h);
             if (h->stage_pending) {   // the span starts an episode: stage the one after it on the side stream first (as fmarl_step would)
@@ -734,9 +737,9 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
             const bool prof = h->ev && h->ev_n < h->ev_cap;
             if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
             if (sc == FMARL_SCENARIO_FORMATION)
-                hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, k);
+                hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             else
-                hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, k);
+                hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = k; ++h->ev_n; }
             HIP_OK(hipGetLastError());
             if (h->lockstep) h->host_step += k;
@@ -744,7 +747,7 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_
             h->counts[0] += k;
             t += k;
         } else {
-            int rc = fmarl_step(handle, state, a, nullptr, &o, FMARL_RESET_AUTO, stream);
+            int rc = fmarl_step(handle, state, a, av, &o, FMARL_RESET_AUTO, stream);
             if (rc) return rc;
             ++t;
         }

@@ -588,7 +588,8 @@ class RolloutEngine:
     GRAPH_BELOW_AGENTS = 1 << 16
 
     def step_span(self, action_tape, strides=None):
-        """``len(action_tape)`` auto-resetting steps from a device tape (T, n, N) int32 through ``fmarl_step_span``: the steps
+        """``len(action_tape)`` auto-resetting steps from a device tape -- (T, n, N) int32 action indices or (T, n, N, 5) float32
+        action vectors (the reference's one-hot / continuous form, as for ``step``) -- through ``fmarl_step_span``: the steps
         between episode ends go out as ONE launch in which every workgroup walks its own envs through time (envs never
         interact; no per-step launch, no per-step head and tail of the grid), the step that ends an episode as a launch of
         its own.  Same results as T ``step`` calls, bit for bit.  By default every step writes the engine's current output
@@ -596,13 +597,17 @@ class RolloutEngine:
         'node_obs', 'adj', 'reward', 'done', 'info', 'edge_nnz', 'graph_record' makes step t write the set's buffers shifted
         by t strides -- the time slots of a rollout buffer laid out (T, n, ...) (``DeviceRolloutBuffer.insert_span``)."""
         tape = action_tape
-        if tape.dtype != torch.int32 or tape.device != self.device or not tape.is_contiguous() or tape.dim() != 3 or \
-                tuple(tape.shape[1:]) != (self.n_envs, self.cfg.N):
-            raise ValueError('action tape must be a contiguous int32 device tensor of shape (T, %d, %d)' % (self.n_envs, self.cfg.N))
+        shape = (self.n_envs, self.cfg.N)
+        as_idx = tape.dtype == torch.int32 and tape.dim() == 3 and tuple(tape.shape[1:]) == shape
+        as_vec = tape.dtype == torch.float32 and tape.dim() == 4 and tuple(tape.shape[1:]) == shape + (5,)
+        if not (as_idx or as_vec) or tape.device != self.device or not tape.is_contiguous():
+            raise ValueError('action tape must be a contiguous device tensor, int32 of shape (T, %d, %d) or float32 of shape (T, %d, %d, 5)'
+                             % (shape + shape))
         st = strides or {}
         span = _lib.FmarlSpan(*[int(st.get(k, 0)) for k in ('obs', 'node_obs', 'adj', 'reward', 'done', 'info', 'edge_nnz', 'graph_record')],
-                              self.n_envs * self.cfg.N)
-        rc = self.lib.fmarl_step_span(self.handle, self._state_ptr, tape.data_ptr(), int(tape.shape[0]), self._outs_ref, C.byref(span),
+                              self.n_envs * self.cfg.N * (1 if as_idx else 5))
+        rc = self.lib.fmarl_step_span(self.handle, self._state_ptr, tape.data_ptr() if as_idx else None, tape.data_ptr() if as_vec else None,
+                                      int(tape.shape[0]), self._outs_ref, C.byref(span),
                                       torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _lib.check(rc, 'fmarl_step_span')

@@ -245,10 +245,11 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
  * Measured (profiles/r3_notes.md): 10 agents x 65 536 envs 0.250 -> 0.199 ms per step, 3 agents x 4 096 envs 14.5 -> 11.5 us. */
 typedef struct FmarlSpan {
     int64_t obs, node_obs, adj, reward, done, info, edge_nnz, graph_record;   /* per-step strides of the outputs, in elements */
-    int64_t actions;                                                             /* per-step stride of action_idx (n * N for a dense tape) */
+    int64_t actions;   /* per-step stride of the action tape in elements: n * N for dense action_idx, n * N * 5 for action_vec */
 } FmarlSpan;
-int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, int n_steps, const FmarlOutputs *outs,
-                    const FmarlSpan *span, void *stream);
+/* Exactly one of action_idx (T, n, N) int32 / action_vec (T, n, N, 5) float32, as for fmarl_step. */
+int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const float *action_vec, int n_steps,
+                    const FmarlOutputs *outs, const FmarlSpan *span, void *stream);
 
 /* Host-side mirror of the envs' common step counter: steps since the last reset of all envs, or -1 when the envs are not
  * known to be in lockstep (masked resets, fmarl_set_state, graphs captured with FMARL_RESET_AUTO, fairnav).  No device access. */

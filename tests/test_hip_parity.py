@@ -1095,6 +1095,39 @@ def test_step_span_equals_step_by_step(kw, geom):
             assert torch.equal(ra[k], rb[k]), (t, k)
 
 
+@pytest.mark.parametrize('kw', SHARD_CASES, ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
+def test_step_span_takes_action_vectors(kw):
+    """fmarl_step_span with a float tape (T, n, N, 5) -- the reference's action form, one-hot rows (onpolicy/runner/shared/
+    graph_mpe_runner.py:294, 430 build np.eye(5)[action]) or any continuous vector (multiagent/environment.py:302-303 read
+    u[0] += a[1] - a[2], u[1] += a[3] - a[4]): a one-hot tape gives what the index tape gives, a continuous one what T step
+    calls with the same vectors give, bit for bit, through an episode end."""
+    cfg = fm.EnvConfig(**kw)
+    n, N, ep = 37, cfg.N, cfg.episode_length
+    T = ep + 4
+    gen = torch.Generator(device=DEV); gen.manual_seed(8)
+    idx = torch.randint(0, 5, (T, n, N), device=DEV, generator=gen, dtype=torch.int32)
+    onehot = torch.nn.functional.one_hot(idx.long(), 5).to(torch.float32).contiguous()
+    cont = torch.rand((T, n, N, 5), device=DEV, generator=gen, dtype=torch.float32)
+    for tape_a, tape_b in ((idx, onehot), (cont, cont)):
+        a = fm.RolloutEngine(cfg, n, device=DEV, seed=23)
+        b = fm.RolloutEngine(cfg, n, device=DEV, seed=23)
+        a.reset(); b.reset()
+        if tape_a is idx:
+            a.step_span(tape_a)
+        else:
+            for t in range(T):
+                a.step(tape_a[t])
+        b.step_span(tape_b)
+        torch.cuda.synchronize()
+        for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done', 'info'):
+            assert torch.equal(getattr(a, k), getattr(b, k)), k
+        sa, sb = a.get_state(), b.get_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), k
+        assert a.phase == b.phase == (4 if cfg.scenario_name != 'nav_fairassign_fairrew_formation_graph' else a.phase)
+    assert not torch.equal(a.obs, fm.RolloutEngine(cfg, n, device=DEV, seed=23).reset()[0])
+
+
 def test_step_span_refuses_what_it_cannot_do():
     """A span decides on the host where episodes end: it is refused inside a stream capture (with a message that says what to
     capture instead), and a tape of the wrong shape / dtype / device never reaches the library."""
@@ -1104,7 +1137,7 @@ def test_step_span_refuses_what_it_cannot_do():
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=1)
     eng.reset()
     tape = torch.zeros(4, n, 3, dtype=torch.int32, device=DEV)
-    for bad in (tape[:, :, :2], tape.to(torch.int64), tape.cpu(), tape[:, ::2]):
+    for bad in (tape[:, :, :2], tape.to(torch.int64), tape.cpu(), tape[:, ::2], tape.to(torch.float32), torch.zeros(4, n, 3, 4, device=DEV)):
         with pytest.raises(ValueError, match='action tape'):
             eng.step_span(bad)
     gc.collect()
