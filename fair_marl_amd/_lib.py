@@ -47,6 +47,31 @@ class FmarlOutputs(C.Structure):
                 ('done', C.c_void_p), ('info', C.c_void_p), ('edge_nnz', C.c_void_p), ('graph_record', C.c_void_p)]
 
 
+class FmarlReturns(C.Structure):
+    _fields_ = [('gamma', C.c_double), ('gae_lambda', C.c_double), ('mean', C.c_float), ('stddev', C.c_float),
+                ('denormalize', C.c_int32), ('use_gae', C.c_int32), ('use_proper_time_limits', C.c_int32), ('T', C.c_int32),
+                ('columns', C.c_int64)]
+
+
+BATCH_SRC_ARRAYS = ('obs', 'node_obs', 'adj_env', 'rnn_states', 'rnn_states_critic', 'actions', 'action_log_probs', 'value_preds',
+                    'returns', 'masks', 'active_masks', 'advantages', 'available_actions')
+# the 16 arrays of a generator's tuple, in the reference's order (graph_buffer.py:448-453), + env_slot
+BATCH_DST_ARRAYS = ('share_obs', 'obs', 'node_obs', 'adj', 'agent_id', 'share_agent_id', 'rnn_states', 'rnn_states_critic', 'actions',
+                    'value_preds', 'returns', 'masks', 'active_masks', 'old_action_log_probs', 'adv_targ', 'available_actions',
+                    'env_slot')
+
+
+class FmarlBatchSrc(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in BATCH_SRC_ARRAYS] + \
+               [(k, C.c_int32) for k in ('T', 'n', 'N', 'D', 'E', 'F', 'rnn_elems', 'act_dim', 'avail_dim', 'reserved0')]
+
+
+class FmarlBatchDst(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('share_obs', 'obs', 'node_obs', 'adj', 'agent_id', 'share_agent_id', 'rnn_states',
+                                          'rnn_states_critic', 'actions', 'value_preds', 'returns', 'masks', 'active_masks',
+                                          'old_action_log_probs', 'adv_targ', 'available_actions', 'env_slot')]
+
+
 _SIGS = {
     'fmarl_create': (C.c_int, [C.POINTER(FmarlConfig), C.POINTER(C.c_void_p)]),
     'fmarl_destroy': (C.c_int, [C.c_void_p]),
@@ -86,6 +111,10 @@ _SIGS = {
     'fmarl_episode_started': (C.c_int, [C.c_void_p]),
     'fmarl_pack_episode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fmarl_rebuild_graph': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fmarl_compute_returns': (C.c_int, [C.POINTER(FmarlReturns), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'fmarl_advantages_workspace': (C.c_size_t, []),
+    'fmarl_advantages': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'fmarl_minibatch_gather': (C.c_int, [C.POINTER(FmarlBatchSrc), C.POINTER(FmarlBatchDst), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 _lib = None

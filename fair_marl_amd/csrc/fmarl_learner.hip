@@ -1,0 +1,177 @@
+// The learner's side of the rollout buffer on gfx950: what the reference's trainer computes on the
+// filled GraphReplayBuffer with NumPy on the host before the first gradient step --
+//   * GraphReplayBuffer.compute_returns         (onpolicy/utils/graph_buffer.py:285-366)   -> returns_kernel
+//   * the standardised advantages of GR_MAPPO.train (onpolicy/algorithms/graph_mappo.py:294-304) -> advantage_*_kernel
+//   * feed_forward_generator / recurrent_generator (graph_buffer.py:368-453, 597-758)     -> minibatch_gather_kernel
+// All of it is float32 streaming over (T, n, N) arrays: HBM-bound, no reuse, nothing for LDS beyond a block reduction.
+#pragma once
+#include "fmarl_dev.h"
+#include "fmarl_kernels.h"
+
+namespace fmarl {
+
+// One thread per (env, agent) column walks the time axis backwards; consecutive threads read consecutive columns, so
+// every load / store of a step is one contiguous segment per wave.  Float32 in the reference's order of operations
+// (-ffp-contract=off: no fused multiply-add): the result equals NumPy's bit for bit in all twelve branches
+// (tests/golden/learner_*.npz).  `denorm`: value_normalizer.denormalize = x * stddev + mean, product rounded first
+// (onpolicy/utils/valuenorm.py:92-104, onpolicy/algorithms/utils/popart.py:101-111).
+__global__ __launch_bounds__(256) void returns_kernel(FmarlReturns a, const float *rewards, float *value_preds, const float *masks,
+                                                      const float *bad_masks, const float *next_value, float *returns) {
+    const size_t C = (size_t)a.columns;
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int T = a.T;
+    const float g = (float)a.gamma, gl = (float)(a.gamma * a.gae_lambda);   // gamma * gae_lambda is formed in double first
+    const float mean = a.mean, sd = a.stddev;
+    const bool dn = a.denormalize != 0, proper = a.use_proper_time_limits != 0;
+    const float nv = next_value[c];
+    if (a.use_gae) {
+        value_preds[(size_t)T * C + c] = nv;                 // :299 / :340
+        float v1 = dn ? nv * sd + mean : nv;                 // denormalised value of step t + 1
+        float gae = 0.f;
+        float r = rewards[(size_t)(T - 1) * C + c], v = T > 0 ? value_preds[(size_t)(T - 1) * C + c] : 0.f;
+        float m1 = masks[(size_t)T * C + c], b1 = proper ? bad_masks[(size_t)T * C + c] : 1.f;
+        for (int t = T - 1; t >= 0; --t) {
+            // the next iteration's operands are requested before this one's arithmetic
+            float rn = 0.f, vn = 0.f, mn = 0.f, bn = 1.f;
+            if (t > 0) {
+                rn = rewards[(size_t)(t - 1) * C + c];
+                vn = value_preds[(size_t)(t - 1) * C + c];
+                mn = masks[(size_t)t * C + c];
+                if (proper) bn = bad_masks[(size_t)t * C + c];
+            }
+            const float v0 = dn ? v * sd + mean : v;
+            const float delta = (r + (g * v1) * m1) - v0;                   // :305-309 / :316-318 / :344-347 / :353-355
+            gae = (proper && dn) ? delta + (gl * gae) * m1                  // :310-311
+                                 : delta + (gl * m1) * gae;                 // :319-320 / :348-349 / :356-357
+            if (proper) gae = gae * b1;                                     // :312 / :321
+            returns[(size_t)t * C + c] = gae + v0;                          // :313-314 / :322 / :350-351 / :358
+            v1 = v0; r = rn; v = vn; m1 = mn; b1 = bn;
+        }
+    } else {
+        float acc = nv;
+        returns[(size_t)T * C + c] = nv;                     // :324 / :360
+        for (int t = T - 1; t >= 0; --t) {
+            acc = (acc * g) * masks[(size_t)(t + 1) * C + c] + rewards[(size_t)t * C + c];   // :327-328 / :333-334 / :362-364
+            if (proper) {
+                const float b = bad_masks[(size_t)(t + 1) * C + c], v = value_preds[(size_t)t * C + c];
+                acc = acc * b + (1.f - b) * (dn ? v * sd + mean : v);       // :329-331 / :335-337
+            }
+            returns[(size_t)t * C + c] = acc;
+        }
+    }
+}
+
+// advantages = returns[:-1] - denormalised value_preds[:-1]; mean / std over the entries whose active mask is not 0
+// (np.nanmean / np.nanstd after the masked entries were set to NaN, graph_mappo.py:300-303).  Pass 1 writes the raw
+// advantages and per-block (count, sum, sum of squares) in float64; the block that finishes last adds the partials in index
+// order (the same sum on every run) and leaves (mean, std) as float32 in stats[0..1].
+__global__ __launch_bounds__(256) void advantage_raw_kernel(const float *returns, const float *value_preds, const float *active_masks,
+                                                            float *adv, size_t total, float mean, float sd, int dn, double *partials,
+                                                            unsigned int *ticket, float *stats) {
+    __shared__ double red[3][4];
+    __shared__ bool last;
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = value_preds[i];
+        const float x = returns[i] - (dn ? v * sd + mean : v);
+        adv[i] = x;
+        if (active_masks[i] != 0.f) { cnt += 1.0; s1 += (double)x; s2 += (double)x * (double)x; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off; off >>= 1) { cnt += __shfl_down(cnt, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if (lane == 0) { red[0][wave] = cnt; red[1][wave] = s1; red[2][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *mine = partials + 3 * (size_t)blockIdx.x;
+        mine[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        mine[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        mine[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    cnt = s1 = s2 = 0.0;
+    if (threadIdx.x < 64) {   // one wave, lane l takes the partials l, l + 64, ... in order: the same sum on every run
+        for (unsigned int b = threadIdx.x; b < gridDim.x; b += 64) {
+            const volatile double *q = partials + 3 * (size_t)b;
+            cnt += q[0]; s1 += q[1]; s2 += q[2];
+        }
+        for (int off = 32; off; off >>= 1) { cnt += __shfl_down(cnt, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+        if (threadIdx.x == 0) {
+            const double m = cnt > 0.0 ? s1 / cnt : 0.0;
+            const double var = cnt > 0.0 ? s2 / cnt - m * m : 0.0;
+            stats[0] = (float)m;
+            stats[1] = (float)sqrt(var > 0.0 ? var : 0.0);
+            *ticket = 0;   // ready for the next call
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void advantage_scale_kernel(float *adv, size_t total, const float *stats) {
+    const float m = stats[0], d = stats[1] + 1e-5f;   // graph_mappo.py:304
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        adv[i] = (adv[i] - m) / d;
+}
+
+// Rows of a minibatch: one wave per output row, lanes stride over the row's segments.  mode 0 (feed_forward_generator):
+// index[r] is the flat position of row r over (T, n, N) in C order.  mode 1 (recurrent_generator): index[j] is a chunk
+// of `chunk` consecutive entries of the (n, N, T)-ordered series; output row l * chunks + j is entry index[j] * chunk + l
+// (a chunk runs over the end of one (env, agent) series into the next, exactly as the reference's reshape does), and the
+// two rnn-state outputs have one row per chunk: the state at the chunk's first entry.
+__device__ __forceinline__ void copy_row(float *dst, const float *src, int count, int lane) {
+    for (int k = lane; k < count; k += 64) dst[k] = src[k];
+}
+
+__global__ __launch_bounds__(256) void minibatch_gather_kernel(FmarlBatchSrc s, FmarlBatchDst d, const int64_t *index, int64_t rows,
+                                                               int mode, int chunk, int64_t chunks) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t T = s.T, n = s.n, N = s.N;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        int64_t t, e, a;
+        if (mode == 0) {
+            const int64_t f = index[r];
+            a = f % N; e = (f / N) % n; t = f / (N * n);
+        } else {
+            const int64_t l = r / chunks, j = r - l * chunks;
+            const int64_t f = index[j] * chunk + l;
+            t = f % T; a = (f / T) % N; e = f / (T * N);
+        }
+        const size_t slot = (size_t)(t * n + e), cell = slot * N + a;
+        if (d.share_obs) copy_row(d.share_obs + (size_t)r * N * s.D, s.obs + slot * N * s.D, (int)(N * s.D), lane);   // all agents' obs of the env
+        if (d.obs) copy_row(d.obs + (size_t)r * s.D, s.obs + cell * s.D, s.D, lane);
+        if (d.node_obs) copy_row(d.node_obs + (size_t)r * s.E * s.F, s.node_obs + cell * s.E * s.F, s.E * s.F, lane);
+        if (d.adj) copy_row(d.adj + (size_t)r * s.E * s.E, s.adj_env + slot * s.E * s.E, s.E * s.E, lane);           // one matrix per env
+        if (d.actions) copy_row(d.actions + (size_t)r * s.act_dim, s.actions + cell * s.act_dim, s.act_dim, lane);
+        if (d.old_action_log_probs) copy_row(d.old_action_log_probs + (size_t)r * s.act_dim, s.action_log_probs + cell * s.act_dim, s.act_dim, lane);
+        if (d.available_actions) copy_row(d.available_actions + (size_t)r * s.avail_dim, s.available_actions + cell * s.avail_dim, s.avail_dim, lane);
+        if (d.share_agent_id) for (int k = lane; k < N; k += 64) d.share_agent_id[(size_t)r * N + k] = k;          // graph_mpe_runner.py:479-484
+        if (mode == 0) {
+            if (d.rnn_states) copy_row(d.rnn_states + (size_t)r * s.rnn_elems, s.rnn_states + cell * s.rnn_elems, s.rnn_elems, lane);
+            if (d.rnn_states_critic) copy_row(d.rnn_states_critic + (size_t)r * s.rnn_elems, s.rnn_states_critic + cell * s.rnn_elems, s.rnn_elems, lane);
+        }
+        if (lane == 0) {
+            if (d.agent_id) d.agent_id[r] = (int32_t)a;
+            if (d.value_preds) d.value_preds[r] = s.value_preds[cell];
+            if (d.returns) d.returns[r] = s.returns[cell];
+            if (d.masks) d.masks[r] = s.masks[cell];
+            if (d.active_masks) d.active_masks[r] = s.active_masks[cell];
+            if (d.adv_targ) d.adv_targ[r] = s.advantages[cell];
+            if (d.env_slot) d.env_slot[r] = (int64_t)slot;
+        }
+    }
+    if (mode == 1) {   // the chunks' initial recurrent states
+        for (int64_t j = wave0; j < chunks; j += nwaves) {
+            const int64_t f = index[j] * chunk;
+            const int64_t t = f % T, a = (f / T) % N, e = f / (T * N);
+            const size_t cell = (size_t)((t * n + e) * N + a);
+            if (d.rnn_states) copy_row(d.rnn_states + (size_t)j * s.rnn_elems, s.rnn_states + cell * s.rnn_elems, s.rnn_elems, lane);
+            if (d.rnn_states_critic) copy_row(d.rnn_states_critic + (size_t)j * s.rnn_elems, s.rnn_states_critic + cell * s.rnn_elems, s.rnn_elems, lane);
+        }
+    }
+}
+
+}  // namespace fmarl

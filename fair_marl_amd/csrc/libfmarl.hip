@@ -14,6 +14,7 @@
 #include "fmarl_fairnav.hip"
 #include "fmarl_graph.hip"
 #include "fmarl_rebuild.hip"
+#include "fmarl_learner.hip"
 
 using namespace fmarl;
 
@@ -900,6 +901,65 @@ int fmarl_info_means(const float *info, double *means, int n_envs, int num_agent
     if (!info || !means || n_envs < 1 || num_agents < 1) return fail(FMARL_EINVAL, "fmarl_info_means: bad argument");
     hipLaunchKernelGGL(info_mean_kernel, dim3(FMARL_INFO_WIDTH * num_agents), dim3(256), 0, (hipStream_t)stream, info, means,
                        n_envs, num_agents, unreached_time);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+// ---- the learner's side of the rollout buffer (fmarl_learner.hip) ------------------------------------------------------
+int fmarl_compute_returns(const FmarlReturns *a, const float *rewards, float *value_preds, const float *masks,
+                          const float *bad_masks, const float *next_value, float *returns, void *stream) {
+    if (!a || !rewards || !value_preds || !masks || !next_value || !returns) return fail(FMARL_EINVAL, "fmarl_compute_returns: null argument");
+    if (a->T < 1 || a->columns < 1) return fail(FMARL_EINVAL, "fmarl_compute_returns: T and columns must be positive");
+    if (a->use_proper_time_limits && !bad_masks) return fail(FMARL_EINVAL, "fmarl_compute_returns: use_proper_time_limits needs bad_masks");
+    const int64_t blocks = (a->columns + 255) / 256;
+    if (blocks > 0x7fffffff) return fail(FMARL_EINVAL, "fmarl_compute_returns: too many columns");
+    hipLaunchKernelGGL(returns_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a, rewards, value_preds, masks, bad_masks,
+                       next_value, returns);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+static_assert(sizeof(FmarlReturns) == 48 && sizeof(FmarlBatchSrc) == 144 && sizeof(FmarlBatchDst) == 136, "C-ABI layout (fair_marl_amd/_lib.py mirrors it)");
+static const int kAdvBlocks = 2048;   // 8 per CU: enough loads in flight for the read stream, few enough partials for one wave
+
+size_t fmarl_advantages_workspace(void) { return 16 + (size_t)kAdvBlocks * 3 * sizeof(double); }
+
+int fmarl_advantages(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
+                     int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream) {
+    if (!returns || !value_preds || !active_masks || !advantages || !workspace || count < 1)
+        return fail(FMARL_EINVAL, "fmarl_advantages: bad argument");
+    float *stats = (float *)workspace;
+    unsigned int *ticket = (unsigned int *)((char *)workspace + 8);
+    double *partials = (double *)((char *)workspace + 16);
+    const int64_t want = (count + 255) / 256;
+    const int blocks = (int)(want < kAdvBlocks ? want : kAdvBlocks);
+    hipLaunchKernelGGL(advantage_raw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, returns, value_preds, active_masks,
+                       advantages, (size_t)count, mean, stddev, denormalize ? 1 : 0, partials, ticket, stats);
+    hipLaunchKernelGGL(advantage_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, advantages, (size_t)count, stats);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_minibatch_gather(const FmarlBatchSrc *s, const FmarlBatchDst *d, const int64_t *index, int64_t rows, int mode,
+                           int chunk, void *stream) {
+    if (!s || !d || !index || rows < 0) return fail(FMARL_EINVAL, "fmarl_minibatch_gather: bad argument");
+    if (rows == 0) return FMARL_OK;
+    if (s->T < 1 || s->n < 1 || s->N < 1) return fail(FMARL_EINVAL, "fmarl_minibatch_gather: T, n, N must be positive");
+    if (mode != 0 && mode != 1) return fail(FMARL_EINVAL, "fmarl_minibatch_gather: mode must be 0 (feed-forward) or 1 (recurrent chunks)");
+    if (mode == 1 && (chunk < 1 || rows % chunk)) return fail(FMARL_EINVAL, "fmarl_minibatch_gather: rows must be a multiple of the chunk length");
+    const struct { const void *dst, *src; const char *name; } need[] = {
+        {d->share_obs, s->obs, "share_obs"}, {d->obs, s->obs, "obs"}, {d->node_obs, s->node_obs, "node_obs"}, {d->adj, s->adj_env, "adj"},
+        {d->rnn_states, s->rnn_states, "rnn_states"}, {d->rnn_states_critic, s->rnn_states_critic, "rnn_states_critic"},
+        {d->actions, s->actions, "actions"}, {d->value_preds, s->value_preds, "value_preds"}, {d->returns, s->returns, "returns"},
+        {d->masks, s->masks, "masks"}, {d->active_masks, s->active_masks, "active_masks"},
+        {d->old_action_log_probs, s->action_log_probs, "action_log_probs"}, {d->adv_targ, s->advantages, "advantages"},
+        {d->available_actions, s->available_actions, "available_actions"}};
+    for (const auto &q : need)
+        if (q.dst && !q.src) return fail(FMARL_EINVAL, "fmarl_minibatch_gather: output %s needs its source array", q.name);
+    const int64_t chunks = mode == 1 ? rows / chunk : 0;
+    const int64_t want = (rows + 3) / 4;   // one wave per row, four per workgroup
+    const int blocks = (int)(want < 16384 ? want : 16384);
+    hipLaunchKernelGGL(minibatch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *s, *d, index, rows, mode, chunk, chunks);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

@@ -15,8 +15,19 @@ rewards into slot t.  What ``insert`` computes on the host is done with a few de
 
 At BASELINE config 3 (65 536 envs x 32 agents, E = 72) one slot is 8.3 GB, a 25-step episode 216 GB:
 it fits the 288 GB of one MI355X, which is the point of keeping it resident.
+
+The learner's side: ``attach_policy`` adds the slots the policy fills (value_preds, actions,
+action_log_probs, rnn states, bad_masks, available_actions: graph_buffer.py:116-164), ``compute_returns`` is
+``GraphReplayBuffer.compute_returns`` (:285-366, every branch, bit for bit), ``advantages`` what ``GR_MAPPO.train`` forms
+before its epochs (onpolicy/algorithms/graph_mappo.py:294-304), ``feed_forward_generator`` / ``recurrent_generator`` the
+reference's minibatch generators (:368-453, :597-758) yielding the same 16-tuples as device tensors -- one gather kernel per
+minibatch (``fmarl_minibatch_gather``) instead of NumPy fancy indexing on the host.
 """
+import ctypes as C
+
 import torch
+
+from . import _lib
 
 
 class DeviceRolloutBuffer(object):
@@ -37,6 +48,8 @@ class DeviceRolloutBuffer(object):
         self.agent_id = torch.arange(N, dtype=torch.int32, device=dev).view(1, 1, N, 1).expand(T + 1, n, N, 1)
         self.share_agent_id = torch.arange(N, dtype=torch.int32, device=dev).view(1, 1, 1, N).expand(T + 1, n, N, N)
         self.info_planes = z(T + 1, 14, n, N) if eng.emit_info else None   # one set of info planes per slot (the last step's: process_infos)
+        self.value_preds = self.returns = self.bad_masks = self.actions = self.action_log_probs = None   # attach_policy()
+        self.rnn_states = self.rnn_states_critic = self.available_actions = None
         self._scratch_reward = z(n, N)
         self._scratch_done = z(n, N, dtype=torch.uint8)
         # slot t receives the observation that FOLLOWS step t - 1; reward / done of step t go to index t
@@ -128,10 +141,166 @@ class DeviceRolloutBuffer(object):
 
     def after_update(self):
         """graph_buffer.py after_update: the last slot becomes the first of the next rollout."""
-        for name in ('obs', 'node_obs', 'adj_env', 'masks', 'active_masks'):
+        names = ['obs', 'node_obs', 'adj_env', 'masks', 'active_masks']
+        if self.value_preds is not None:
+            names += ['rnn_states', 'rnn_states_critic', 'bad_masks', 'available_actions']
+        for name in names:
             buf = getattr(self, name)
-            buf[0].copy_(buf[-1])
+            if buf is not None:
+                buf[0].copy_(buf[-1])
         self.step = 0
+
+    # the learner's side ------------------------------------------------------------------------------
+    def attach_policy(self, act_dim=1, recurrent_N=1, hidden_size=64, n_actions=5):
+        """The slots the policy fills, in the reference's shapes (graph_buffer.py:116-164): value_preds / returns / bad_masks
+        (T + 1, n, N, 1), actions / action_log_probs (T, n, N, act_dim), rnn_states / rnn_states_critic
+        (T + 1, n, N, recurrent_N, hidden_size), available_actions (T + 1, n, N, n_actions) of ones (None if n_actions is 0)."""
+        T, n, N, dev = self.T, self.engine.n_envs, self.engine.cfg.N, self.engine.device
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        self.value_preds, self.returns = z(T + 1, n, N, 1), z(T + 1, n, N, 1)
+        self.bad_masks = torch.ones(T + 1, n, N, 1, dtype=torch.float32, device=dev)
+        self.actions, self.action_log_probs = z(T, n, N, act_dim), z(T, n, N, act_dim)
+        self.rnn_states, self.rnn_states_critic = z(T + 1, n, N, recurrent_N, hidden_size), z(T + 1, n, N, recurrent_N, hidden_size)
+        self.available_actions = torch.ones(T + 1, n, N, n_actions, dtype=torch.float32, device=dev) if n_actions else None
+        self._adv_ws = torch.zeros(_lib.load().fmarl_advantages_workspace(), dtype=torch.uint8, device=dev)
+        return self
+
+    def insert_policy(self, t, value_preds, actions, action_log_probs, rnn_states=None, rnn_states_critic=None, bad_masks=None,
+                      available_actions=None):
+        """The policy's part of ``GraphReplayBuffer.insert`` for buffer step t (graph_buffer.py:233-248): values, actions and
+        log-probabilities at index t, the recurrent states / bad_masks / available_actions that follow the step at t + 1."""
+        self._need_policy()
+        self.value_preds[t].copy_(value_preds.reshape(self.value_preds[t].shape))
+        self.actions[t].copy_(actions.reshape(self.actions[t].shape))
+        self.action_log_probs[t].copy_(action_log_probs.reshape(self.action_log_probs[t].shape))
+        for dst, src in ((self.rnn_states, rnn_states), (self.rnn_states_critic, rnn_states_critic), (self.bad_masks, bad_masks),
+                         (self.available_actions, available_actions)):
+            if src is not None:
+                dst[t + 1].copy_(src.reshape(dst[t + 1].shape))
+
+    def _need_policy(self):
+        if self.value_preds is None:
+            raise RuntimeError('call attach_policy() first: the buffer holds only the env-facing arrays')
+
+    @staticmethod
+    def _mean_std(value_normalizer):
+        """(denormalize?, mean, stddev) of a value normaliser: None, a (mean, stddev) pair, or the reference's ValueNorm /
+        PopArt objects (``running_mean_var`` / ``debiased_mean_var``: onpolicy/utils/valuenorm.py:47-54,
+        onpolicy/algorithms/utils/popart.py:85-89) -- stddev = float32 sqrt of the debiased variance, as ``denormalize`` forms it."""
+        if value_normalizer is None:
+            return 0, 0.0, 1.0
+        if isinstance(value_normalizer, (tuple, list)):
+            return 1, float(value_normalizer[0]), float(value_normalizer[1])
+        fn = getattr(value_normalizer, 'running_mean_var', None) or getattr(value_normalizer, 'debiased_mean_var')
+        mean, var = fn()
+        return 1, float(mean.reshape(-1)[0]), float(torch.sqrt(var.to(torch.float32)).reshape(-1)[0])
+
+    def compute_returns(self, next_value, value_normalizer=None, gamma=0.99, gae_lambda=0.95, use_gae=True, use_proper_time_limits=False):
+        """``GraphReplayBuffer.compute_returns`` (graph_buffer.py:285-366) on the device, all branches: fills ``returns`` (and
+        ``value_preds[-1]`` with GAE) from rewards / value_preds / masks / bad_masks.  ``next_value`` (n, N, 1) float32;
+        ``value_normalizer``: see ``_mean_std``.  Equal to the reference's NumPy result bit for bit."""
+        self._need_policy()
+        dn, mean, std = self._mean_std(value_normalizer)
+        n, N = self.engine.n_envs, self.engine.cfg.N
+        nv = next_value.to(device=self.engine.device, dtype=torch.float32).reshape(n * N).contiguous()
+        args = _lib.FmarlReturns(float(gamma), float(gae_lambda), mean, std, dn, int(bool(use_gae)), int(bool(use_proper_time_limits)),
+                                 self.T, n * N)
+        rc = _lib.load().fmarl_compute_returns(C.byref(args), self.rewards.data_ptr(), self.value_preds.data_ptr(), self.masks.data_ptr(),
+                                               self.bad_masks.data_ptr(), nv.data_ptr(), self.returns.data_ptr(),
+                                               torch.cuda.current_stream(self.engine.device).cuda_stream)
+        _lib.check(rc, 'fmarl_compute_returns')
+        self._keep = nv
+        return self.returns
+
+    def advantages(self, value_normalizer=None):
+        """What ``GR_MAPPO.train`` hands to the generators (onpolicy/algorithms/graph_mappo.py:294-304): returns[:-1] minus the
+        (denormalised) value predictions, standardised over the entries with a non-zero active mask.  (T, n, N, 1) float32;
+        ``advantage_stats`` afterwards views the (mean, std) the kernel used."""
+        self._need_policy()
+        dn, mean, std = self._mean_std(value_normalizer)
+        adv = torch.empty_like(self.rewards)
+        rc = _lib.load().fmarl_advantages(self.returns.data_ptr(), self.value_preds.data_ptr(), self.active_masks.data_ptr(), adv.data_ptr(),
+                                          adv.numel(), dn, mean, std, self._adv_ws.data_ptr(),
+                                          torch.cuda.current_stream(self.engine.device).cuda_stream)
+        _lib.check(rc, 'fmarl_advantages')
+        self.advantage_stats = self._adv_ws[:8].view(torch.float32)
+        return adv
+
+    def _gather(self, adv, index, rows, mode, chunk, want):
+        eng, cfg = self.engine, self.engine.cfg
+        dev, n, N = eng.device, eng.n_envs, cfg.N
+        R = rows if mode == 0 else rows // chunk   # rows of the two rnn-state outputs
+        f = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        shapes = dict(share_obs=(rows, N * cfg.obs_dim), obs=(rows, cfg.obs_dim), node_obs=(rows, cfg.E, cfg.node_feat), adj=(rows, cfg.E, cfg.E),
+                      agent_id=(rows, 1), share_agent_id=(rows, N), rnn_states=(R,) + tuple(self.rnn_states.shape[3:]),
+                      rnn_states_critic=(R,) + tuple(self.rnn_states_critic.shape[3:]), actions=(rows, self.actions.shape[-1]),
+                      value_preds=(rows, 1), returns=(rows, 1), masks=(rows, 1), active_masks=(rows, 1),
+                      old_action_log_probs=(rows, self.action_log_probs.shape[-1]), adv_targ=(rows, 1),
+                      available_actions=(rows, self.available_actions.shape[-1]) if self.available_actions is not None else None,
+                      env_slot=(rows,))
+        out = {}
+        for k in _lib.BATCH_DST_ARRAYS:
+            if k not in want or shapes[k] is None or (k == 'adv_targ' and adv is None):
+                out[k] = None
+            else:
+                out[k] = f(*shapes[k], dtype=torch.int32 if k in ('agent_id', 'share_agent_id') else torch.int64 if k == 'env_slot' else torch.float32)
+        ptr = lambda x: x.data_ptr() if x is not None else None  # noqa: E731
+        src = _lib.FmarlBatchSrc(ptr(self.obs), ptr(self.node_obs), ptr(self.adj_env), ptr(self.rnn_states), ptr(self.rnn_states_critic),
+                                 ptr(self.actions), ptr(self.action_log_probs), ptr(self.value_preds), ptr(self.returns), ptr(self.masks),
+                                 ptr(self.active_masks), ptr(adv), ptr(self.available_actions), self.T, n, N, cfg.obs_dim, cfg.E, cfg.node_feat,
+                                 int(self.rnn_states[0, 0, 0].numel()), int(self.actions.shape[-1]),
+                                 int(self.available_actions.shape[-1]) if self.available_actions is not None else 0, 0)
+        dst = _lib.FmarlBatchDst(*[ptr(out[k]) for k in _lib.BATCH_DST_ARRAYS])
+        rc = _lib.load().fmarl_minibatch_gather(C.byref(src), C.byref(dst), index.data_ptr(), rows, mode, chunk,
+                                                torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, 'fmarl_minibatch_gather')
+        return out
+
+    GENERATOR_FIELDS = _lib.BATCH_DST_ARRAYS[:16]
+
+    def _generate(self, adv, perm, size, batches, mode, chunk, fields, with_env_slot):
+        self._need_policy()
+        dev = self.engine.device
+        if adv is not None:
+            adv = adv.to(device=dev, dtype=torch.float32).contiguous()
+            if adv.numel() != self.rewards.numel():
+                raise ValueError('advantages must have %d entries (T, n, N, 1)' % self.rewards.numel())
+        want = set(fields or self.GENERATOR_FIELDS) | ({'env_slot'} if with_env_slot else set())
+        perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+        for b in range(batches):
+            index = perm[b * size:(b + 1) * size]
+            out = self._gather(adv, index, size * (chunk if mode else 1), mode, chunk, want)
+            tup = tuple(out[k] for k in self.GENERATOR_FIELDS)
+            yield tup + (out['env_slot'],) if with_env_slot else tup
+
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None, perm=None, fields=None, with_env_slot=False):
+        """``GraphReplayBuffer.feed_forward_generator`` (graph_buffer.py:368-453): yields, per minibatch, the reference's
+        16-tuple (share_obs, obs, node_obs, adj, agent_id, share_agent_id, rnn_states, rnn_states_critic, actions, value_preds,
+        returns, masks, active_masks, old_action_log_probs, adv_targ, available_actions) as device tensors gathered by one
+        kernel.  ``perm``: the permutation of range(T n N) to use (default: ``torch.randperm`` on the host generator, like the
+        reference).  ``fields``: the subset to materialise (the others come back as None) -- at BASELINE scale a policy takes
+        ``with_env_slot=True`` and indexes ``adj_env.view(-1, E, E)`` instead of receiving N copies of every matrix."""
+        n, N = self.engine.n_envs, self.engine.cfg.N
+        batch = self.T * n * N
+        if mini_batch_size is None:
+            if batch < num_mini_batch:
+                raise ValueError('PPO requires processes (%d) * steps (%d) * agents (%d) >= mini batches (%d)' % (n, self.T, N, num_mini_batch))
+            mini_batch_size = batch // num_mini_batch
+        else:
+            num_mini_batch = num_mini_batch or batch // mini_batch_size
+        if perm is None:
+            perm = torch.randperm(batch)
+        return self._generate(advantages, perm, mini_batch_size, num_mini_batch, 0, 1, fields, with_env_slot)
+
+    def recurrent_generator(self, advantages, num_mini_batch, data_chunk_length, perm=None, fields=None, with_env_slot=False):
+        """``GraphReplayBuffer.recurrent_generator`` (graph_buffer.py:597-758): chunks of ``data_chunk_length`` consecutive
+        entries of the (n, N, T)-ordered series, ``data_chunks // num_mini_batch`` permuted chunks per minibatch, rows ordered
+        (L, chunk) like the reference's stack + flatten; rnn states one row per chunk.  ``perm`` permutes range(data_chunks)."""
+        n, N = self.engine.n_envs, self.engine.cfg.N
+        chunks = self.T * n * N // data_chunk_length
+        if perm is None:
+            perm = torch.randperm(chunks)
+        return self._generate(advantages, perm, chunks // num_mini_batch, num_mini_batch, 1, int(data_chunk_length), fields, with_env_slot)
 
 
 class _CapturedInserts(object):

@@ -375,6 +375,67 @@ int fmarl_rebuild_graph(void *handle, const float *obs, const void *record, int 
  * (= episode_length * dt, :212-215).  info f32 (FMARL_INFO_WIDTH, n, N) -> means f64 (FMARL_INFO_WIDTH, N). */
 int fmarl_info_means(const float *info, double *means, int n_envs, int num_agents, double unreached_time, void *stream);
 
+/* ---- the learner's side of the rollout buffer ---------------------------------------------------
+ * What the reference's trainer computes with NumPy on the filled GraphReplayBuffer before its first gradient step.  The
+ * arrays are the buffer's own, C-contiguous float32 with the trailing 1 of (T, n, N, 1) dropped: `columns` = n * N.
+ * Stateless; they run on the current device.
+ *
+ * fmarl_compute_returns = GraphReplayBuffer.compute_returns (onpolicy/utils/graph_buffer.py:285-366), every branch:
+ * use_gae x use_proper_time_limits x value normaliser (ValueNorm / PopArt: denormalize(x) = x * stddev + mean in float32,
+ * onpolicy/utils/valuenorm.py:92-104, onpolicy/algorithms/utils/popart.py:101-111; the caller passes the normaliser's
+ * current debiased mean and sqrt(var)).  rewards (T, columns); value_preds, masks, bad_masks, returns (T + 1, columns);
+ * next_value (columns).  With use_gae, value_preds[T] = next_value is written as the reference does and returns[T] is left
+ * alone; without, returns[T] = next_value.  bad_masks may be NULL unless use_proper_time_limits.  Float32 in the
+ * reference's order of operations: equal to NumPy's result bit for bit. */
+typedef struct FmarlReturns {
+    double gamma, gae_lambda;      /* args.gamma, args.gae_lambda (Python floats: their product is formed in double) */
+    float mean, stddev;            /* of the value normaliser; ignored unless denormalize */
+    int32_t denormalize, use_gae, use_proper_time_limits;
+    int32_t T;                     /* episode_length = rewards.shape[0] */
+    int64_t columns;               /* n_rollout_threads * num_agents */
+} FmarlReturns;
+int fmarl_compute_returns(const FmarlReturns *args, const float *rewards, float *value_preds, const float *masks,
+                          const float *bad_masks, const float *next_value, float *returns, void *stream);
+
+/* The advantages GR_MAPPO.train hands to the generators (onpolicy/algorithms/graph_mappo.py:294-304):
+ * returns[:T] - denormalize(value_preds[:T]), standardised by the mean / standard deviation over the entries whose active
+ * mask is not 0, (x - mean) / (std + 1e-5).  count = T * columns entries of each array.  Mean and deviation are
+ * accumulated in float64 in a fixed order (the reference: float32 pairwise sums; agreement to float32 rounding) and
+ * left as two floats at the start of `workspace` -- fmarl_advantages_workspace() bytes of device memory, zeroed once by the
+ * caller before the first call. */
+size_t fmarl_advantages_workspace(void);
+int fmarl_advantages(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
+                     int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream);
+
+/* The rows of one minibatch of GraphReplayBuffer.feed_forward_generator (mode 0, graph_buffer.py:368-453) or
+ * recurrent_generator (mode 1, :597-758) gathered from the buffer: FmarlBatchSrc = the buffer's arrays ((T + 1, n, N, ...)
+ * or (T, n, N, ...) as in the reference, adj stored once per env), FmarlBatchDst = the 16 arrays the generator yields, rows
+ * first (any NULL is skipped; a non-NULL output needs its source).  share_obs rows are the env's N obs rows back to back
+ * and share_agent_id rows 0..N-1 (what the runner's insert stores, graph_mpe_runner.py:470-484) -- neither is kept in the
+ * buffer.  env_slot (extra): t * n + env of every row, for a policy that indexes the per-env adj instead of receiving N
+ * copies of it.
+ *   mode 0: index[r] = flat position of row r over (T, n, N) in C order (the reference's torch.randperm entries).
+ *   mode 1: index[j] = a chunk of `chunk` consecutive entries of the (n, N, T)-ordered flat series; rows = chunk * chunks,
+ *           row l * chunks + j = entry index[j] * chunk + l; rnn_states / rnn_states_critic have `chunks` rows (the state at
+ *           each chunk's first entry). */
+typedef struct FmarlBatchSrc {
+    const float *obs, *node_obs, *adj_env, *rnn_states, *rnn_states_critic, *actions, *action_log_probs, *value_preds, *returns,
+        *masks, *active_masks, *advantages, *available_actions;
+    int32_t T, n, N, D, E, F;      /* episode_length, n_rollout_threads, num_agents, obs width, entities, node features */
+    int32_t rnn_elems;             /* recurrent_N * hidden_size */
+    int32_t act_dim, avail_dim;    /* last axis of actions / action_log_probs, of available_actions */
+    int32_t reserved0;
+} FmarlBatchSrc;
+typedef struct FmarlBatchDst {
+    float *share_obs, *obs, *node_obs, *adj;
+    int32_t *agent_id, *share_agent_id;
+    float *rnn_states, *rnn_states_critic, *actions, *value_preds, *returns, *masks, *active_masks, *old_action_log_probs,
+        *adv_targ, *available_actions;
+    int64_t *env_slot;
+} FmarlBatchDst;
+int fmarl_minibatch_gather(const FmarlBatchSrc *src, const FmarlBatchDst *dst, const int64_t *index, int64_t rows, int mode,
+                           int chunk, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

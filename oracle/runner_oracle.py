@@ -114,3 +114,103 @@ METRIC_PATTERNS = {'get_fairness_metric': 'mean_variance', 'get_dist_mean': 'dis
 def metric(env_infos, reader):
     pat = METRIC_PATTERNS[reader]
     return [v[0] for k, v in env_infos.items() if pat in k]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Learner side of the buffer (added in round 3): what the trainer computes on the filled buffer
+# before the first gradient step.  Pinned by tests/golden/learner_*.npz (tests/golden/gen_learner.py: the reference's own
+# compute_returns in all twelve branches, GR_MAPPO.train's advantages, both minibatch generators).
+
+def compute_returns(rewards, value_preds, masks, bad_masks, next_value, gamma, gae_lambda, use_gae=True, proper=False, norm=None):
+    """onpolicy/utils/graph_buffer.py:285-366.  ``rewards`` (T, ...), ``value_preds`` / ``masks`` / ``bad_masks`` (T + 1, ...)
+    float32; ``norm`` = None or (mean, stddev) float32 of the value normaliser, whose ``denormalize`` is ``x * stddev + mean``
+    in float32, product rounded before the sum (valuenorm.py:92-104, popart.py:101-111).  Float32 throughout, in the
+    reference's order of operations (Python scalars enter as float32; gamma * gae_lambda is formed in double first).
+    Returns (returns (T + 1, ...), value_preds with the last slot = next_value when use_gae)."""
+    f32 = np.float32
+    T = rewards.shape[0]
+    v = value_preds.astype(f32).copy()
+    ret = np.zeros_like(v)
+    g, gl = f32(gamma), f32(float(gamma) * float(gae_lambda))
+    if norm is None:
+        dn = lambda x: x  # noqa: E731
+    else:
+        mean, std = f32(norm[0]), f32(norm[1])
+        dn = lambda x: x * std + mean  # noqa: E731  (two float32 roundings)
+    if use_gae:
+        v[T] = next_value                                                       # :299 / :340
+        gae = np.zeros_like(v[0])
+        for t in range(T - 1, -1, -1):
+            m1 = masks[t + 1]
+            delta = rewards[t] + g * dn(v[t + 1]) * m1 - dn(v[t])              # :305-309 / :316-318 / :344-347 / :353-355
+            if proper and norm is not None:
+                gae = delta + gl * gae * m1                                     # :310-311
+            else:
+                gae = delta + gl * m1 * gae                                     # :319-320 / :348-349 / :356-357
+            if proper:
+                gae = gae * bad_masks[t + 1]                                    # :312 / :321
+            ret[t] = gae + dn(v[t])                                             # :313-314 / :322 / :350-351 / :358
+    else:
+        ret[T] = next_value                                                     # :324 / :360
+        for t in range(T - 1, -1, -1):
+            acc = ret[t + 1] * g * masks[t + 1] + rewards[t]                    # :327-328 / :333-334 / :362-364
+            if proper:
+                b = bad_masks[t + 1]
+                acc = acc * b + (f32(1) - b) * dn(v[t])                         # :329-331 / :335-337
+            ret[t] = acc
+    return ret, v
+
+
+def advantages(returns, value_preds, active_masks, norm=None):
+    """onpolicy/algorithms/graph_mappo.py:294-304: returns[:-1] - (denormalised) value_preds[:-1], then standardised by the
+    mean / std over the entries whose active mask is not 0 (np.nanmean / np.nanstd of the float32 array), eps 1e-5."""
+    f32 = np.float32
+    v = value_preds[:-1]
+    if norm is not None:
+        v = v * f32(norm[1]) + f32(norm[0])
+    adv = returns[:-1] - v
+    keep = active_masks[:-1] != 0.0
+    sel = adv[keep]
+    mean = sel.mean(dtype=np.float32)
+    std = np.sqrt(((sel - mean) ** 2).mean(dtype=np.float32))
+    return (adv - mean) / (std + 1e-5)
+
+
+def feed_forward_rows(perm, T, n, N, num_mini_batch):
+    """graph_buffer.py:384-400: the (t, env, agent) of every row of every minibatch -- the flat index over (T, n, N) in C
+    order is the permutation entry itself."""
+    size = (T * n * N) // num_mini_batch
+    out = []
+    for b in range(num_mini_batch):
+        idx = np.asarray(perm[b * size:(b + 1) * size], dtype=np.int64)
+        out.append((idx // (n * N), (idx // N) % n, idx % N))
+    return out
+
+
+def recurrent_rows(perm, T, n, N, num_mini_batch, chunk):
+    """graph_buffer.py:613-622, 673-700, 733-750: arrays are laid out (n, N, T) -> flat, cut into chunks of ``chunk``
+    consecutive entries (a chunk may run over the end of one (env, agent) series into the next), a minibatch is
+    ``data_chunks // num_mini_batch`` permuted chunks stacked on axis 1 and flattened (L, Nmb) -> rows l * Nmb + j.
+    Returns per minibatch ((t, env, agent) of the rows, (t, env, agent) of the first entry of each chunk: the rnn states)."""
+    chunks = (T * n * N) // chunk
+    size = chunks // num_mini_batch
+    out = []
+    for b in range(num_mini_batch):
+        c = np.asarray(perm[b * size:(b + 1) * size], dtype=np.int64)
+        flat = (c[None, :] * chunk + np.arange(chunk)[:, None]).reshape(-1)      # row l * Nmb + j <- entry c_j * L + l
+        split = lambda f: (f % T, f // (T * N), (f // T) % N)  # noqa: E731
+        out.append((split(flat), split(c * chunk)))
+    return out
+
+
+def gather_minibatch(buf, adv, rows, first=None):
+    """The 16 arrays a generator yields (graph_buffer.py:437-453 / :751-758) for rows (t, env, agent); ``buf`` = dict of the
+    buffer's arrays (``adj_env`` (T + 1, n, E, E): one matrix per env, as the runner's insert stores N copies of)."""
+    t, e, a = rows
+    ft, fe, fa = rows if first is None else first
+    share = buf['obs'].reshape(buf['obs'].shape[0], buf['obs'].shape[1], -1)
+    aid = buf.get('available_actions')
+    return (share[t, e], buf['obs'][t, e, a], buf['node_obs'][t, e, a], buf['adj_env'][t, e], buf['agent_id'][t, e, a],
+            buf['share_agent_id'][t, e, a], buf['rnn_states'][ft, fe, fa], buf['rnn_states_critic'][ft, fe, fa],
+            buf['actions'][t, e, a], buf['value_preds'][t, e, a], buf['returns'][t, e, a], buf['masks'][t, e, a],
+            buf['active_masks'][t, e, a], buf['action_log_probs'][t, e, a], adv[t, e, a], None if aid is None else aid[t, e, a])
