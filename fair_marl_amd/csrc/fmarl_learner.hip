@@ -116,60 +116,112 @@ __global__ __launch_bounds__(256) void advantage_scale_kernel(float *adv, size_t
         adv[i] = (adv[i] - m) / d;
 }
 
-// Rows of a minibatch: one wave per output row, lanes stride over the row's segments.  mode 0 (feed_forward_generator):
-// index[r] is the flat position of row r over (T, n, N) in C order.  mode 1 (recurrent_generator): index[j] is a chunk
-// of `chunk` consecutive entries of the (n, N, T)-ordered series; output row l * chunks + j is entry index[j] * chunk + l
-// (a chunk runs over the end of one (env, agent) series into the next, exactly as the reference's reshape does), and the
-// two rnn-state outputs have one row per chunk: the state at the chunk's first entry.
+// Rows of a minibatch: one wave per tile of (up to) 64 output rows.  Lane l first resolves row r0 + l to its buffer cell, so the
+// per-row scalars (value_preds, returns, masks, ...) leave as one coalesced store per field and the narrow fields (obs,
+// actions, available_actions, ...: a few floats per row) as one contiguous run for the whole tile; the wide fields
+// (share_obs, node_obs, adj, rnn states) are copied row by row with all 64 lanes on one row, 16 bytes per lane where the row
+// width allows.  mode 0 (feed_forward_generator): index[r] is the flat position of row r over (T, n, N) in C order.
+// mode 1 (recurrent_generator): index[j] is a chunk of `chunk` consecutive entries of the (n, N, T)-ordered series; output
+// row l * chunks + j is entry index[j] * chunk + l (a chunk runs over the end of one (env, agent) series into the next,
+// exactly as the reference's reshape does), and the two rnn-state outputs have one row per chunk: the state at the chunk's
+// first entry.
+// four loads in flight per lane before the first store (a wave copies one row at a time: without this a row's worth of
+// bandwidth is one 256-byte request per round trip)
+template <typename V>
+__device__ __forceinline__ void copy_vec(V *__restrict__ dst, const V *__restrict__ src, int count, int lane) {
+    int k = lane;
+    for (; k + 192 < count; k += 256) {
+        const V a = src[k], b = src[k + 64], c = src[k + 128], e = src[k + 192];
+        dst[k] = a; dst[k + 64] = b; dst[k + 128] = c; dst[k + 192] = e;
+    }
+    for (; k < count; k += 64) dst[k] = src[k];
+}
+
 __device__ __forceinline__ void copy_row(float *dst, const float *src, int count, int lane) {
-    for (int k = lane; k < count; k += 64) dst[k] = src[k];
+    if ((count & 3) == 0 && ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0) copy_vec((float4 *)dst, (const float4 *)src, count >> 2, lane);
+    else copy_vec(dst, src, count, lane);
+}
+
+// rows r0 .. r0 + cnt - 1 of a field that is w floats wide: dst is contiguous over the tile, lane k takes element k of it
+__device__ __forceinline__ void copy_narrow(float *dst, const float *src, int w, long long cell, int cnt, int lane) {
+    const int total = cnt * w;
+    for (int k0 = 0; k0 < total; k0 += 64) {   // every lane takes part in the shuffle
+        const int k = k0 + lane;
+        const int rr = min(k / w, cnt - 1);
+        const long long c = __shfl(cell, rr);
+        if (k < total) dst[k] = src[(size_t)c * w + (k - rr * w)];
+    }
+}
+
+__device__ __forceinline__ void batch_cell(const FmarlBatchSrc &s, const int64_t *index, int64_t r, int mode, int chunk, int64_t chunks,
+                                           long long &slot, long long &cell, int &agent) {
+    const int64_t T = s.T, n = s.n, N = s.N;
+    int64_t t, e, a;
+    if (mode == 0) {
+        const int64_t f = index[r];
+        a = f % N; e = (f / N) % n; t = f / (N * n);
+    } else {
+        const int64_t l = r / chunks, j = r - l * chunks;
+        const int64_t f = index[j] * chunk + l;
+        t = f % T; a = (f / T) % N; e = f / (T * N);
+    }
+    slot = t * n + e; cell = slot * N + a; agent = (int)a;
+}
+
+constexpr int kNarrow = 16;   // fields up to this many floats per row go out tile-wise
+
+__device__ __forceinline__ void copy_field(float *dst, const float *src, int w, long long cell_l, int64_t r0, int cnt, int lane) {
+    if (!dst) return;
+    if (w <= kNarrow) { copy_narrow(dst + (size_t)r0 * w, src, w, cell_l, cnt, lane); return; }
+    for (int i = 0; i < cnt; ++i) {
+        const long long c = __shfl(cell_l, i);
+        copy_row(dst + (size_t)(r0 + i) * w, src + (size_t)c * w, w, lane);
+    }
 }
 
 __global__ __launch_bounds__(256) void minibatch_gather_kernel(FmarlBatchSrc s, FmarlBatchDst d, const int64_t *index, int64_t rows,
-                                                               int mode, int chunk, int64_t chunks) {
+                                                               int mode, int chunk, int64_t chunks, int tile) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t T = s.T, n = s.n, N = s.N;
-    for (int64_t r = wave0; r < rows; r += nwaves) {
-        int64_t t, e, a;
-        if (mode == 0) {
-            const int64_t f = index[r];
-            a = f % N; e = (f / N) % n; t = f / (N * n);
-        } else {
-            const int64_t l = r / chunks, j = r - l * chunks;
-            const int64_t f = index[j] * chunk + l;
-            t = f % T; a = (f / T) % N; e = f / (T * N);
-        }
-        const size_t slot = (size_t)(t * n + e), cell = slot * N + a;
-        if (d.share_obs) copy_row(d.share_obs + (size_t)r * N * s.D, s.obs + slot * N * s.D, (int)(N * s.D), lane);   // all agents' obs of the env
-        if (d.obs) copy_row(d.obs + (size_t)r * s.D, s.obs + cell * s.D, s.D, lane);
-        if (d.node_obs) copy_row(d.node_obs + (size_t)r * s.E * s.F, s.node_obs + cell * s.E * s.F, s.E * s.F, lane);
-        if (d.adj) copy_row(d.adj + (size_t)r * s.E * s.E, s.adj_env + slot * s.E * s.E, s.E * s.E, lane);           // one matrix per env
-        if (d.actions) copy_row(d.actions + (size_t)r * s.act_dim, s.actions + cell * s.act_dim, s.act_dim, lane);
-        if (d.old_action_log_probs) copy_row(d.old_action_log_probs + (size_t)r * s.act_dim, s.action_log_probs + cell * s.act_dim, s.act_dim, lane);
-        if (d.available_actions) copy_row(d.available_actions + (size_t)r * s.avail_dim, s.available_actions + cell * s.avail_dim, s.avail_dim, lane);
-        if (d.share_agent_id) for (int k = lane; k < N; k += 64) d.share_agent_id[(size_t)r * N + k] = k;          // graph_mpe_runner.py:479-484
-        if (mode == 0) {
-            if (d.rnn_states) copy_row(d.rnn_states + (size_t)r * s.rnn_elems, s.rnn_states + cell * s.rnn_elems, s.rnn_elems, lane);
-            if (d.rnn_states_critic) copy_row(d.rnn_states_critic + (size_t)r * s.rnn_elems, s.rnn_states_critic + cell * s.rnn_elems, s.rnn_elems, lane);
-        }
-        if (lane == 0) {
-            if (d.agent_id) d.agent_id[r] = (int32_t)a;
+    const int N = s.N;
+    // tile = rows per wave: 64 for a large minibatch, fewer for a small one so that its wide rows still spread over the chip
+    for (int64_t r0 = wave0 * tile; r0 < rows; r0 += nwaves * tile) {
+        const int cnt = (int)min((int64_t)tile, rows - r0);
+        const int64_t r = r0 + lane;
+        long long slot = 0, cell = 0;
+        int agent = 0;
+        if (lane < cnt) batch_cell(s, index, r, mode, chunk, chunks, slot, cell, agent);
+        if (lane < cnt) {   // one value per row: coalesced over the tile
+            if (d.agent_id) d.agent_id[r] = agent;
             if (d.value_preds) d.value_preds[r] = s.value_preds[cell];
             if (d.returns) d.returns[r] = s.returns[cell];
             if (d.masks) d.masks[r] = s.masks[cell];
             if (d.active_masks) d.active_masks[r] = s.active_masks[cell];
             if (d.adv_targ) d.adv_targ[r] = s.advantages[cell];
-            if (d.env_slot) d.env_slot[r] = (int64_t)slot;
+            if (d.env_slot) d.env_slot[r] = slot;
+        }
+        if (d.share_agent_id)   // rows 0 .. N-1 (graph_mpe_runner.py:479-484)
+            for (int k = lane; k < cnt * N; k += 64) d.share_agent_id[(size_t)r0 * N + k] = k % N;
+        copy_field(d.obs, s.obs, s.D, cell, r0, cnt, lane);
+        copy_field(d.actions, s.actions, s.act_dim, cell, r0, cnt, lane);
+        copy_field(d.old_action_log_probs, s.action_log_probs, s.act_dim, cell, r0, cnt, lane);
+        copy_field(d.available_actions, s.available_actions, s.avail_dim, cell, r0, cnt, lane);
+        copy_field(d.node_obs, s.node_obs, s.E * s.F, cell, r0, cnt, lane);
+        copy_field(d.share_obs, s.obs, N * s.D, slot, r0, cnt, lane);   // all agents' obs of the env
+        copy_field(d.adj, s.adj_env, s.E * s.E, slot, r0, cnt, lane);    // one matrix per env
+        if (mode == 0) {
+            copy_field(d.rnn_states, s.rnn_states, s.rnn_elems, cell, r0, cnt, lane);
+            copy_field(d.rnn_states_critic, s.rnn_states_critic, s.rnn_elems, cell, r0, cnt, lane);
         }
     }
     if (mode == 1) {   // the chunks' initial recurrent states
-        for (int64_t j = wave0; j < chunks; j += nwaves) {
-            const int64_t f = index[j] * chunk;
-            const int64_t t = f % T, a = (f / T) % N, e = f / (T * N);
-            const size_t cell = (size_t)((t * n + e) * N + a);
-            if (d.rnn_states) copy_row(d.rnn_states + (size_t)j * s.rnn_elems, s.rnn_states + cell * s.rnn_elems, s.rnn_elems, lane);
-            if (d.rnn_states_critic) copy_row(d.rnn_states_critic + (size_t)j * s.rnn_elems, s.rnn_states_critic + cell * s.rnn_elems, s.rnn_elems, lane);
+        for (int64_t j0 = wave0 * tile; j0 < chunks; j0 += nwaves * tile) {
+            const int cnt = (int)min((int64_t)tile, chunks - j0);
+            long long slot = 0, cell = 0;
+            int agent = 0;
+            if (lane < cnt) batch_cell(s, index, j0 + lane, mode, chunk, chunks, slot, cell, agent);   // row l = 0 of chunk j
+            copy_field(d.rnn_states, s.rnn_states, s.rnn_elems, cell, j0, cnt, lane);
+            copy_field(d.rnn_states_critic, s.rnn_states_critic, s.rnn_elems, cell, j0, cnt, lane);
         }
     }
 }

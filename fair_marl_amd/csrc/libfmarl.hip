@@ -957,9 +957,11 @@ int fmarl_minibatch_gather(const FmarlBatchSrc *s, const FmarlBatchDst *d, const
     for (const auto &q : need)
         if (q.dst && !q.src) return fail(FMARL_EINVAL, "fmarl_minibatch_gather: output %s needs its source array", q.name);
     const int64_t chunks = mode == 1 ? rows / chunk : 0;
-    const int64_t want = (rows + 3) / 4;   // one wave per row, four per workgroup
+    int tile = 64;   // rows per wave: fewer for a small minibatch, so that 2 048 waves (8 per CU) still have work
+    while (tile > 1 && rows / tile < 2048) tile >>= 1;
+    const int64_t want = (rows + 4 * tile - 1) / (4 * tile);   // four waves per workgroup
     const int blocks = (int)(want < 16384 ? want : 16384);
-    hipLaunchKernelGGL(minibatch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *s, *d, index, rows, mode, chunk, chunks);
+    hipLaunchKernelGGL(minibatch_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *s, *d, index, rows, mode, chunk, chunks, tile);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }
