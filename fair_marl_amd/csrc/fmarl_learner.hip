@@ -64,56 +64,95 @@ __global__ __launch_bounds__(256) void returns_kernel(FmarlReturns a, const floa
 
 // advantages = returns[:-1] - denormalised value_preds[:-1]; mean / std over the entries whose active mask is not 0
 // (np.nanmean / np.nanstd after the masked entries were set to NaN, graph_mappo.py:300-303).  Pass 1 writes the raw
-// advantages and per-block (count, sum, sum of squares) in float64; the block that finishes last adds the partials in index
-// order (the same sum on every run) and leaves (mean, std) as float32 in stats[0..1].
-__global__ __launch_bounds__(256) void advantage_raw_kernel(const float *returns, const float *value_preds, const float *active_masks,
-                                                            float *adv, size_t total, float mean, float sd, int dn, double *partials,
-                                                            unsigned int *ticket, float *stats) {
-    __shared__ double red[3][4];
-    __shared__ bool last;
-    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const float v = value_preds[i];
-        const float x = returns[i] - (dn ? v * sd + mean : v);
-        adv[i] = x;
-        if (active_masks[i] != 0.f) { cnt += 1.0; s1 += (double)x; s2 += (double)x * (double)x; }
-    }
+// advantages and per-workgroup (count, sum, sum of squares) in float64.
+// (count, sum, sum of squares) of a workgroup of four waves, the same value in every thread; the order of the additions is fixed
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double (*red)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 32; off; off >>= 1) { cnt += __shfl_down(cnt, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
-    if (lane == 0) { red[0][wave] = cnt; red[1][wave] = s1; red[2][wave] = s2; }
+    for (int off = 32; off; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; red[2][wave] = c; }
     __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+}
+
+template <int V>   // V = 4: 16-byte lanes (all four arrays 16-byte aligned), V = 1: any alignment
+__global__ __launch_bounds__(256) void advantage_raw_kernel(const float *returns, const float *value_preds, const float *active_masks,
+                                                            float *adv, size_t total, float mean, float sd, int dn, double *partials) {
+    __shared__ double red[3][4];
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    auto one = [&](float r, float v, float m) {
+        const float x = r - (dn ? v * sd + mean : v);
+        if (m != 0.f) { cnt += 1.0; s1 += (double)x; s2 += (double)x * (double)x; }
+        return x;
+    };
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+    if (V == 4) {
+        // two 16-byte chunks per array in flight per lane before the first store: on gfx9 a load issued behind a store waits
+        // for that store's acknowledgement (one counter orders both), so a load - store - load chain pays both round trips
+        const float4 *r4 = (const float4 *)returns, *v4 = (const float4 *)value_preds, *m4 = (const float4 *)active_masks;
+        float4 *a4 = (float4 *)adv;
+        const size_t n4 = total >> 2;
+        size_t i = tid;
+        for (; i + nthreads < n4; i += 2 * nthreads) {
+            const float4 ra = r4[i], va = v4[i], ma = m4[i], rb = r4[i + nthreads], vb = v4[i + nthreads], mb = m4[i + nthreads];
+            a4[i] = make_float4(one(ra.x, va.x, ma.x), one(ra.y, va.y, ma.y), one(ra.z, va.z, ma.z), one(ra.w, va.w, ma.w));
+            a4[i + nthreads] = make_float4(one(rb.x, vb.x, mb.x), one(rb.y, vb.y, mb.y), one(rb.z, vb.z, mb.z), one(rb.w, vb.w, mb.w));
+        }
+        if (i < n4) {
+            const float4 ra = r4[i], va = v4[i], ma = m4[i];
+            a4[i] = make_float4(one(ra.x, va.x, ma.x), one(ra.y, va.y, ma.y), one(ra.z, va.z, ma.z), one(ra.w, va.w, ma.w));
+        }
+        const size_t k = (n4 << 2) + tid;   // the last total % 4 entries
+        if (k < total) adv[k] = one(returns[k], value_preds[k], active_masks[k]);
+    } else {
+        for (size_t i = tid; i < total; i += nthreads) adv[i] = one(returns[i], value_preds[i], active_masks[i]);
+    }
+    block_sum3(cnt, s1, s2, red);
     if (threadIdx.x == 0) {
         double *mine = partials + 3 * (size_t)blockIdx.x;
-        mine[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        mine[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        mine[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        __threadfence();
-        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    cnt = s1 = s2 = 0.0;
-    if (threadIdx.x < 64) {   // one wave, lane l takes the partials l, l + 64, ... in order: the same sum on every run
-        for (unsigned int b = threadIdx.x; b < gridDim.x; b += 64) {
-            const volatile double *q = partials + 3 * (size_t)b;
-            cnt += q[0]; s1 += q[1]; s2 += q[2];
-        }
-        for (int off = 32; off; off >>= 1) { cnt += __shfl_down(cnt, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
-        if (threadIdx.x == 0) {
-            const double m = cnt > 0.0 ? s1 / cnt : 0.0;
-            const double var = cnt > 0.0 ? s2 / cnt - m * m : 0.0;
-            stats[0] = (float)m;
-            stats[1] = (float)sqrt(var > 0.0 ? var : 0.0);
-            *ticket = 0;   // ready for the next call
-        }
+        mine[0] = cnt; mine[1] = s1; mine[2] = s2;
     }
 }
 
-__global__ __launch_bounds__(256) void advantage_scale_kernel(float *adv, size_t total, const float *stats) {
-    const float m = stats[0], d = stats[1] + 1e-5f;   // graph_mappo.py:304
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        adv[i] = (adv[i] - m) / d;
+// Pass 2: every workgroup adds the partials of pass 1 in the same fixed order (thread k takes k, k + 256, ...; then the wave
+// and block reduction) -- a few KB out of L2, and no fence or atomic ticket: an agent-scope release on this chip writes the
+// XCD's L2 back, which cost more than the whole pass -- and standardises its share of the entries.  Workgroup 0 leaves
+// (mean, std) in stats[0..1].
+__global__ __launch_bounds__(256) void advantage_scale_kernel(float *adv, size_t total, const double *partials, int nparts, float *stats) {
+    __shared__ double red[3][4];
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+        const double *q = partials + 3 * (size_t)b;
+        cnt += q[0]; s1 += q[1]; s2 += q[2];
+    }
+    block_sum3(cnt, s1, s2, red);
+    const double mu = cnt > 0.0 ? s1 / cnt : 0.0;
+    const double var = cnt > 0.0 ? s2 / cnt - mu * mu : 0.0;
+    const float m = (float)mu, sdev = (float)sqrt(var > 0.0 ? var : 0.0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = m; stats[1] = sdev; }
+    const float d = sdev + 1e-5f;   // graph_mappo.py:304
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)adv) & 15) == 0) {
+        float4 *a4 = (float4 *)adv;
+        const size_t n4 = total >> 2;
+        size_t i = tid;
+        for (; i + nthreads < n4; i += 2 * nthreads) {
+            float4 a = a4[i], b = a4[i + nthreads];
+            a.x = (a.x - m) / d; a.y = (a.y - m) / d; a.z = (a.z - m) / d; a.w = (a.w - m) / d;
+            b.x = (b.x - m) / d; b.y = (b.y - m) / d; b.z = (b.z - m) / d; b.w = (b.w - m) / d;
+            a4[i] = a; a4[i + nthreads] = b;
+        }
+        if (i < n4) {
+            float4 a = a4[i];
+            a.x = (a.x - m) / d; a.y = (a.y - m) / d; a.z = (a.z - m) / d; a.w = (a.w - m) / d;
+            a4[i] = a;
+        }
+        const size_t k = (n4 << 2) + tid;
+        if (k < total) adv[k] = (adv[k] - m) / d;
+    } else {
+        for (size_t i = tid; i < total; i += nthreads) adv[i] = (adv[i] - m) / d;
+    }
 }
 
 // Rows of a minibatch: one wave per tile of (up to) 64 output rows.  Lane l first resolves row r0 + l to its buffer cell, so the

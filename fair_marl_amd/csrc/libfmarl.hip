@@ -920,7 +920,7 @@ int fmarl_compute_returns(const FmarlReturns *a, const float *rewards, float *va
 }
 
 static_assert(sizeof(FmarlReturns) == 48 && sizeof(FmarlBatchSrc) == 144 && sizeof(FmarlBatchDst) == 136, "C-ABI layout (fair_marl_amd/_lib.py mirrors it)");
-static const int kAdvBlocks = 2048;   // 8 per CU: enough loads in flight for the read stream, few enough partials for one wave
+static const int kAdvBlocks = 2048;   // 8 per CU; their partials are one pass of the last block
 
 size_t fmarl_advantages_workspace(void) { return 16 + (size_t)kAdvBlocks * 3 * sizeof(double); }
 
@@ -929,13 +929,17 @@ int fmarl_advantages(const float *returns, const float *value_preds, const float
     if (!returns || !value_preds || !active_masks || !advantages || !workspace || count < 1)
         return fail(FMARL_EINVAL, "fmarl_advantages: bad argument");
     float *stats = (float *)workspace;
-    unsigned int *ticket = (unsigned int *)((char *)workspace + 8);
     double *partials = (double *)((char *)workspace + 16);
-    const int64_t want = (count + 255) / 256;
+    const bool wide = ((((uintptr_t)returns) | ((uintptr_t)value_preds) | ((uintptr_t)active_masks) | ((uintptr_t)advantages)) & 15) == 0;
+    const int64_t want = ((wide ? count / 4 : count) + 255) / 256 + 1;
     const int blocks = (int)(want < kAdvBlocks ? want : kAdvBlocks);
-    hipLaunchKernelGGL(advantage_raw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, returns, value_preds, active_masks,
-                       advantages, (size_t)count, mean, stddev, denormalize ? 1 : 0, partials, ticket, stats);
-    hipLaunchKernelGGL(advantage_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, advantages, (size_t)count, stats);
+    if (wide)
+        hipLaunchKernelGGL(advantage_raw_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, returns, value_preds, active_masks,
+                           advantages, (size_t)count, mean, stddev, denormalize ? 1 : 0, partials);
+    else
+        hipLaunchKernelGGL(advantage_raw_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, returns, value_preds, active_masks,
+                           advantages, (size_t)count, mean, stddev, denormalize ? 1 : 0, partials);
+    hipLaunchKernelGGL(advantage_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, advantages, (size_t)count, partials, blocks, stats);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

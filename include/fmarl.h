@@ -401,8 +401,7 @@ int fmarl_compute_returns(const FmarlReturns *args, const float *rewards, float 
  * returns[:T] - denormalize(value_preds[:T]), standardised by the mean / standard deviation over the entries whose active
  * mask is not 0, (x - mean) / (std + 1e-5).  count = T * columns entries of each array.  Mean and deviation are
  * accumulated in float64 in a fixed order (the reference: float32 pairwise sums; agreement to float32 rounding) and
- * left as two floats at the start of `workspace` -- fmarl_advantages_workspace() bytes of device memory, zeroed once by the
- * caller before the first call. */
+ * left as two floats at the start of `workspace` -- fmarl_advantages_workspace() bytes of device memory, 16-byte aligned. */
 size_t fmarl_advantages_workspace(void);
 int fmarl_advantages(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
                      int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream);
