@@ -274,6 +274,7 @@ template <bool STEP>
 __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
                                                const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N;
     const int env0 = blockIdx.x * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
@@ -331,9 +332,11 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     }
     __syncthreads();   // the only workgroup barrier: the entity tables are loaded by all four waves together
     if (active && socc != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
+    FMARL_TICK(0);   // loads issued, entity tables, the barrier
 
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, true, a_pre);
     wave_sync();   // every lane has finished reading the old positions
+    FMARL_TICK(1);   // physics
 
     double Tr_new = 0;
     const double2 L0 = active ? t.pos()[N] : make_double2(0, 0);   // landmark 0
@@ -379,6 +382,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         t.slot_new()[i] = P;
     }
     wave_sync();
+    FMARL_TICK(2);   // angle keys, ring test, slots
 
     double left = 0;
     if (active) {   // agent x slot distances (ff:650-655), nearest slot within thr, dist_left (ff:453)
@@ -406,6 +410,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         if (i == 0) *t.near_old0() = (int8_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
     }
     wave_sync();
+    FMARL_TICK(3);   // agent x slot distances
 
     if (active) {
         // occupancy recomputed in reward(agent 0): any agent within thr of slot i (ff:660-661)
@@ -415,6 +420,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         if (occ) atomicOr(&t.words()[1], 1u << i);
     }
     wave_sync();
+    FMARL_TICK(4);   // occupancy
     {   // the matchings (current slots; on a step also the previous slots for observation(0))
         const int per_env = FMARL_SKIP(p, 64) ? 0 : (STEP ? 2 : 1);
         if (N <= 4) hungarian_tasks<4>(p, lds, env0, el0w, nenv_w, per_env);
@@ -423,6 +429,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         else hungarian_tasks<32>(p, lds, env0, el0w, nenv_w, per_env);
     }
     wave_sync();
+    FMARL_TICK(5);   // matchings
 
     // Entity sets of the walk below, built by the agent lanes in parallel (the potentials' LDS table is free again):
     // sm[k] = agent entities sitting near slot k, sm[N] = all entities near some slot, sm[N + 1] = the slots they cover.
@@ -483,6 +490,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         tw.words()[2] = occ;
     }
     wave_sync();
+    FMARL_TICK(6);   // entity sets + walk
 
     if (active) {
         const uint32_t code = t.masks()[3 * i + 2];
@@ -510,6 +518,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             r[6] = t.masks()[3 * i]; r[7] = t.masks()[3 * i + 1];
             r[8] = (uint32_t)(uint8_t)t.near_new()[i] | ((uint32_t)(uint8_t)t.g_new()[i] << 8);
         }
+        FMARL_TICK(7);   // obs, record, potentials
         if (STEP) {
             const bool open = Tr_old == -1.0;
             const double Dg_new = open ? pd : Dg_old;
@@ -533,6 +542,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             rew += p.fair_rew * tanh_out(fairness - 5.0);
             rew = fmin(fmax(rew, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
+            FMARL_TICK(8);   // statistics, hits, reward
             const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
             p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
             p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left;
@@ -541,6 +551,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             if (i == 0) p.cur_step[env] = step;
             if (o.reward) o.reward[g] = (float)rew;
             if (o.done) o.done[g] = step >= p.episode_length;
+            FMARL_TICK(9);   // state stores
             if (o.info) {   // ff:477-499
                 double dm, ds;
                 travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i + 1, dm, ds);
@@ -563,10 +574,14 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             }
         }
     }
+    FMARL_TICK(10);   // info planes
     // ---- emission: node_obs (16 bytes per lane) and adj
-    if (FMARL_SKIP(p, 32)) return;
+    if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return; }
     formation_emit_rows(p, o, lds, env0, el0w, nenv_w, lane);
+    FMARL_TICK(11);   // node rows
     emit_adj(p, o, lds, env0, el0w, el0w + nenv_w, lane, 64);
+    FMARL_TICK(12);   // adj
+    FMARL_TICKS_END;
 }
 
 template <bool STEP>

@@ -510,7 +510,7 @@ __device__ __forceinline__ double2 agent_force(const Params &p, const char *base
     }
     // core.py:317-326 + :407-462 walls proper
     const double *wl = (const double *)(base + p.lds_wall);
-    for (int w = 0; w < p.W; ++w) {
+    for (int w = 0; w < (FMARL_SKIP(p, 256) ? 0 : p.W); ++w) {
         double axis = wl[w * 4], e0 = wl[w * 4 + 1], e1 = wl[w * 4 + 2];
         bool horiz = wl[w * 4 + 3] == 0.0;
         double ppar = horiz ? x.x : x.y, pperp = horiz ? x.y : x.x;

@@ -970,6 +970,20 @@ int fmarl_minibatch_gather(const FmarlBatchSrc *s, const FmarlBatchDst *d, const
     return FMARL_OK;
 }
 
+#ifdef FMARL_MEASURE
+// -DFMARL_MEASURE builds only (tools/phase_ticks.py): per-wave phase clocks of the last launch that carries FMARL_TICK sites,
+// summed over the first `rows` waves into out[FMARL_TICK_PHASES] (core-clock cycles); synchronises the device.
+extern "C" int fmarl_measure_ticks(double *out, int rows) {
+    static unsigned int host[FMARL_TICK_ROWS][FMARL_TICK_PHASES];
+    if (rows > FMARL_TICK_ROWS) rows = FMARL_TICK_ROWS;
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fmarl_ticks), sizeof(unsigned int) * FMARL_TICK_PHASES * rows));
+    for (int k = 0; k < FMARL_TICK_PHASES; ++k) out[k] = 0.0;
+    for (int r = 0; r < rows; ++r) for (int k = 0; k < FMARL_TICK_PHASES; ++k) out[k] += host[r][k];
+    return FMARL_OK;
+}
+#endif
+
 size_t fmarl_episode_record_words(const FmarlConfig *cfg) {
     const char *why;
     if (!config_ok(cfg, &why)) { fail(FMARL_EINVAL, "fmarl_episode_record_words: %s", why); return 0; }

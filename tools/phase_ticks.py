@@ -1,0 +1,40 @@
+"""measurement aid (GPU box): where a wave of formation_kernel<true> spends its cycles -- the FMARL_TICK sites of a
+-DFMARL_MEASURE build (tools/mkvariant.sh measure -DFMARL_MEASURE), summed over the waves of one launch under full load.
+usage: FMARL_LIB=fair_marl_amd/csrc/variants/libfmarl_measure.so python tools/phase_ticks.py [config]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import fair_marl_amd as fm  # noqa: E402
+from fair_marl_amd import _lib  # noqa: E402
+
+NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
+         'obs+record', 'stats+hits+reward', 'state stores', 'info planes', 'node rows', 'adj']
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else 'cfg4'
+    kw, n = bench.CONFIGS[name]['env'], bench.CONFIGS[name]['n_envs']
+    cfg = fm.EnvConfig(**kw)
+    eng = fm.RolloutEngine(cfg, n, device='cuda:0', seed=5, tune_placement=0)
+    gen = torch.Generator(device='cuda:0'); gen.manual_seed(2)
+    eng.reset()
+    for t in range(12):
+        eng.step(torch.randint(0, 5, (n, cfg.N), device='cuda:0', generator=gen, dtype=torch.int32))
+    lib = _lib.load()
+    waves = -(-n // eng.envs_per_workgroup) * 4
+    out = (C.c_double * 16)()
+    lib.fmarl_measure_ticks.argtypes = [C.POINTER(C.c_double), C.c_int]
+    assert lib.fmarl_measure_ticks(out, waves) == 0
+    tot = sum(out)
+    print('%s: %d waves, %.0f cycles per wave' % (name, waves, tot / waves))
+    for k, nm in enumerate(NAMES):
+        print('  %-26s %8.0f cycles  %5.1f %%' % (nm, out[k] / waves, 100 * out[k] / tot))
+
+
+if __name__ == '__main__':
+    main()
