@@ -13,9 +13,9 @@
 #define FMARL_TICK_PHASES 16
 #define FMARL_TICK_ROWS 65536
 __device__ unsigned int g_fmarl_ticks[FMARL_TICK_ROWS][FMARL_TICK_PHASES];
-#define FMARL_TICKS_BEGIN unsigned int ticks_[FMARL_TICK_PHASES] = {}; unsigned long long tick_ = clock64();
+#define FMARL_TICKS_BEGIN unsigned int ticks_[FMARL_TICK_PHASES] = {}; unsigned long long tick_ = wall_clock64(); ticks_[15] = (unsigned int)tick_; tick_ = clock64();
 #define FMARL_TICK(k) do { const unsigned long long now_ = clock64(); ticks_[k] += (unsigned int)(now_ - tick_); tick_ = now_; } while (0)
-#define FMARL_TICKS_END do { const unsigned int row_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+#define FMARL_TICKS_END do { ticks_[14] = (unsigned int)wall_clock64(); const unsigned int row_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
     if ((threadIdx.x & 63) == 0 && row_ < FMARL_TICK_ROWS) for (int k_ = 0; k_ < FMARL_TICK_PHASES; ++k_) g_fmarl_ticks[row_][k_] = ticks_[k_]; } while (0)
 #else
 #define FMARL_SKIP(p, bit) false

@@ -44,7 +44,7 @@ struct FairNavLds {
     __device__ double *D() const { return (double *)(dead + p.n_D); }               // [N][L] |x_a - goal_g|
     __device__ double *minprox() const { return (double *)(dead + p.n_minprox); }   // [L] min_a |x_a - goal_g|
     __device__ double *occ() const { return (double *)(dead + p.n_occ); }           // [L] landmark_poses_occupied
-    __device__ double *hist() const { return (double *)(dead + p.n_occ) + p.L; }    // [L] goal_history
+    __device__ int8_t *hist() const { return (int8_t *)(dead + p.n_occ + p.L * 8); }   // [L] goal_history (agent indices: one byte each, as in the state)
     __device__ int *match() const { return (int *)(dead + p.n_match); }             // [N] goal_match_index (this step)
     __device__ NavRow *rows() const { return (NavRow *)(base + p.n_rows); }         // [N ego][N entity]
     __device__ int *words() const { return (int *)(dead + p.n_words); }             // a*, all-done, free-empty
@@ -104,7 +104,7 @@ __device__ __forceinline__ bool wall_box_hit_pad15(double2 x, double axis, doubl
 struct ObsGoal { int goal, second; double g_occ, g_hist, second_occ; };
 
 // observation(i)'s walk over the occupancy / history vectors (nf:845-996); Drow = distances of agent i.
-__device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *occ, double *hist, int L, int i,
+__device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *occ, int8_t *hist, int L, int i,
                              double thr, double mod) {
     ObsGoal out;
     int c = 0, s2 = 0;
@@ -119,7 +119,7 @@ __device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *
         int chosen = c, goal = c;
         for (int g = 0; g < L; ++g)
             if (Drow[g] < mod && occ[g] == 1.0 && !(minprox[g] < thr)) occ[g] = minprox[g];
-        if (dmin < thr) { occ[chosen] = 1.0; hist[chosen] = (double)i; }
+        if (dmin < thr) { occ[chosen] = 1.0; hist[chosen] = (int8_t)i; }
         else {
             const double closest = minprox[chosen];
             if (occ[chosen] == 1.0) {
@@ -132,16 +132,16 @@ __device__ ObsGoal obs_event(const double *Drow, const double *minprox, double *
                 } else occ[chosen] = 1.0 - closest;
             } else occ[chosen] = 1.0 - closest;
         }
-        out.goal = goal; out.g_occ = occ[chosen]; out.g_hist = hist[chosen];
+        out.goal = goal; out.g_occ = occ[chosen]; out.g_hist = (double)hist[chosen];
     } else {
         int best = -1;
         double bd = 1e300;
         for (int g = 0; g < L; ++g)
             if (occ[g] != 1.0 && Drow[g] < bd) { bd = Drow[g]; best = g; }
-        if (best >= 0) { out.goal = best; out.g_occ = occ[best]; out.g_hist = hist[best]; }
+        if (best >= 0) { out.goal = best; out.g_occ = occ[best]; out.g_hist = (double)hist[best]; }
         else {
             for (int g = 0; g < L; ++g) occ[g] = 0.0;
-            out.goal = -1; out.g_occ = 0.0; out.g_hist = hist[i];
+            out.goal = -1; out.g_occ = 0.0; out.g_hist = (double)hist[i];
         }
     }
     return out;
@@ -274,6 +274,7 @@ struct PlacedEnvLds {
 template <bool STEP>
 __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
                              const float *action_vec, int auto_reset, bool second, bool flagged_in) {
+    FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int env0 = blockIdx.x * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
@@ -290,7 +291,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g]; status = (double)p.status[g];
         t.pos()[i] = x;
-        t.occ()[i] = p.goal_occ[g]; t.hist()[i] = (double)p.goal_history[g];   // L == N
+        t.occ()[i] = p.goal_occ[g]; t.hist()[i] = p.goal_history[g];   // L == N
         step = p.cur_step[env] + (STEP ? 1 : 0);
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
@@ -300,8 +301,10 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     if (!STEP && active && i == 0) *t.flag() = flagged ? 0 : 1;   // (a step knows it once the agents' done flags are in)
     load_statics(p, lds, env0, nenv);
     __syncthreads();
+    FMARL_TICK(0);   // state loads, entity tables, barrier
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
     __syncthreads();   // every lane has finished reading the old positions
+    FMARL_TICK(1);   // physics
     if (active) t.pos()[i] = x;
     __syncthreads();
 
@@ -312,6 +315,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         t.minprox()[i] = m;
     }
     __syncthreads();
+    FMARL_TICK(2);   // distance table
     if ((STEP || second) && !FMARL_SKIP(p, 64)) {
         // step: reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721);
         // in-kernel reset: the assignment of the new episode (nf:469), for the envs that were just placed
@@ -325,6 +329,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         t.match()[i] = p.goal_match[g];
     }
     __syncthreads();
+    FMARL_TICK(3);   // assignment
 
     // reward's status transition (nf:726-741) and the per-agent info bookkeeping (nf:489-573) only need
     // positions and the agent's own previous values
@@ -362,6 +367,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         if (STEP && i == 0) *t.flag() = emit ? 0 : 1;
     }
 
+    FMARL_TICK(4);   // status transition, bookkeeping (four state loads), barrier
     // ---- the sequential part: occupancy / history walk in agent order
     ObsGoal og;
     og.goal = -1; og.second = 0; og.g_occ = og.g_hist = og.second_occ = 0.0;
@@ -389,10 +395,10 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             const bool cleared = free_empty && astar < i;         // an earlier entity already cleared the flags
             NavRow r;
             r.pad = 0;
-            if (!far) { r.code = (int8_t)c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = (int8_t)t.hist()[c]; }
-            else if (!free_empty) { r.code = (int8_t)best; r.occ = (float)t.occ()[best]; r.hist = (int8_t)t.hist()[best]; }
-            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = (int8_t)t.hist()[i]; }
-            else { r.code = (int8_t)c; r.occ = 0.f; r.hist = (int8_t)t.hist()[c]; }   // after the clear every goal is free
+            if (!far) { r.code = (int8_t)c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = t.hist()[c]; }
+            else if (!free_empty) { r.code = (int8_t)best; r.occ = (float)t.occ()[best]; r.hist = t.hist()[best]; }
+            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = t.hist()[i]; }
+            else { r.code = (int8_t)c; r.occ = 0.f; r.hist = t.hist()[c]; }   // after the clear every goal is free
             t.rows()[a * N + i] = r;
         }
         __syncthreads();
@@ -403,6 +409,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         if (active && i == 0) t.words()[0] = N;
         // (the next iteration's first barrier orders this reset before the next atomicMin)
     }
+    FMARL_TICK(5);   // walk
 
     if (active) {
         const double2 goal = og.goal >= 0 ? t.pos()[N + og.goal] : x;
@@ -413,7 +420,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)og.g_occ; ob[7] = (float)og.g_hist;
             ob[8] = (float)(sec.x - x.x); ob[9] = (float)(sec.y - x.y); ob[10] = (float)og.second_occ;
         }
-        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = (int8_t)t.hist()[i]; }
+        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
         if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
             uint32_t *r = o.graph_record + g * (size_t)(5 + 3 * N);
             const float4 af = t.agentf()[i];
@@ -479,10 +486,14 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
             }
         }
     }
+    FMARL_TICK(6);   // obs, reward, statistics, state stores, info planes
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
-    if (FMARL_SKIP(p, 32)) return ended;
+    if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return ended; }
     fairnav_emit_rows(p, o, lds, env0, nenv);
+    FMARL_TICK(7);   // node rows
     emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    FMARL_TICK(8);   // adj
+    FMARL_TICKS_END;
     return ended;
 }
 

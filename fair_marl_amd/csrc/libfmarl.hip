@@ -350,9 +350,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         form_dead = p.lds2_bytes = d;
     }
     if (fnav) {   // fmarl_fairnav.hip FairNavLds
-        // the env's block packed to 8 bytes, 8-byte row records: 352 + 288 = 640 bytes per env at N = 3, i.e. 64 envs per
-        // workgroup in 40 KB = 1 024 workgroups for 65 536 envs (measured the same as 48 or 59 envs per workgroup: the launch
-        // time of this kernel stopped following the workgroup count beyond 36, profiles/r3_notes.md)
+        // the env's block packed to 8 bytes, 8-byte row records: 352 + 272 = 624 bytes per env at N = 3, i.e. 64 envs per
+        // workgroup in 39 KB = 1 024 workgroups for 65 536 envs, ALL resident at once (four per CU).  With 640 bytes per env the
+        // workgroup took exactly 40 960 bytes and only three fit a CU: 768 workgroups ran, then the other 256 -- two generations
+        // of a 31 us chain, 65 us per launch; 40 320 bytes is the most that was seen to fit four (profiles/r3_notes.md)
         int o2 = 0;
         p.lds_pos = o2;    o2 += p.E * 16;
         p.lds_agentf = o2; o2 += p.N * 16;
@@ -371,7 +372,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.lds_stat = d;    d += 5 * p.N * 8;        // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
         p.n_D = d;         d += p.N * p.L * 8;
         p.n_minprox = d;   d += p.L * 8;
-        p.n_occ = d;       d += 2 * p.L * 8;
+        p.n_occ = d;       d += p.L * 8 + (p.L + 7) / 8 * 8;   // occupancy (float64: fractional values occur), history (bytes)
         p.n_match = d;     d += p.N * 4;
         p.n_words = d;     d += 12;
         form_dead = p.lds2_bytes = (d + 7) / 8 * 8;
@@ -385,10 +386,11 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // per workgroup at three per CU: 0.082 ms per launch against 0.078 with 36 envs at four per CU (tools/epb_probe.sh fnav);
     // navigation_graph at 10 agents had gained 7 % from the same 3 -> 4 step.
     // fairnav: the windows alias the second region (the tables there are dead by then): the region holds whichever is larger
-    const int budget = 40 * 1024 - (fnav ? 0 : shared_bytes);
+    const int kFourPerCu = 40320;   // LDS of a workgroup such that four share a CU: 40 960 = 160 KB / 4 does NOT fit four (measured)
+    const int budget = (fnav ? kFourPerCu : 40 * 1024) - (fnav ? 0 : shared_bytes);
     const int env_lds = p.lds_env_bytes + form_dead;   // LDS of one env incl. its share of the second region (formation, fairnav)
     if (epb * env_lds > budget) epb = budget / env_lds;
-    if (fnav) while (epb > 1 && epb * p.lds_env_bytes + (epb * form_dead > shared_bytes ? epb * form_dead : shared_bytes) > 40 * 1024) --epb;
+    if (fnav) while (epb > 1 && epb * p.lds_env_bytes + (epb * form_dead > shared_bytes ? epb * form_dead : shared_bytes) > kFourPerCu) --epb;
     if (epb < 1) epb = 1;
     // fair_graph_formation: every env lives inside one wave (fmarl_formation.hip), 64 / N envs per wave, and no wave ever waits
     // for another one.  Workgroups of ONE wave (the scheduler placing 64-lane units) measured slower than four waves per
@@ -527,6 +529,13 @@ int fmarl_destroy(void *handle) {
 int fmarl_envs_per_workgroup(void *handle) {
     Handle *h = (Handle *)handle;
     return h ? h->base.epb : 0;
+}
+
+int fmarl_launch_geometry(void *handle, int64_t *geometry) {
+    Handle *h = (Handle *)handle;
+    if (!h || !geometry) return fail(FMARL_EINVAL, "fmarl_launch_geometry: null argument");
+    geometry[0] = h->grid; geometry[1] = h->threads; geometry[2] = (int64_t)h->lds_bytes; geometry[3] = h->base.epb;
+    return FMARL_OK;
 }
 
 int fmarl_launch_counts(void *handle, int64_t *counts) {
@@ -980,6 +989,13 @@ extern "C" int fmarl_measure_ticks(double *out, int rows) {
     HIP_OK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fmarl_ticks), sizeof(unsigned int) * FMARL_TICK_PHASES * rows));
     for (int k = 0; k < FMARL_TICK_PHASES; ++k) out[k] = 0.0;
     for (int r = 0; r < rows; ++r) for (int k = 0; k < FMARL_TICK_PHASES; ++k) out[k] += host[r][k];
+    return FMARL_OK;
+}
+// the raw rows: [14] / [15] = the constant-rate (100 MHz) clock at the wave's end / start
+extern "C" int fmarl_measure_rows(unsigned int *out, int rows) {
+    if (rows > FMARL_TICK_ROWS) rows = FMARL_TICK_ROWS;
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fmarl_ticks), sizeof(unsigned int) * FMARL_TICK_PHASES * rows));
     return FMARL_OK;
 }
 #endif

@@ -671,6 +671,12 @@ class RolloutEngine:
         ms = [buf[i] for i in range(cnt.value)]
         return (ms, [steps[i] for i in range(cnt.value)]) if with_steps else ms
 
+    def launch_geometry(self):
+        """(workgroups, threads per workgroup, LDS bytes per workgroup, envs per workgroup) of this engine's step kernels."""
+        g = (C.c_int64 * 4)()
+        _lib.check(self.lib.fmarl_launch_geometry(self.handle, g), 'fmarl_launch_geometry')
+        return tuple(int(x) for x in g)
+
     def launch_counts(self):
         """(step launches, of which folded episode ends, steps followed by separate auto-reset launches, stagings) so far."""
         buf = (C.c_int64 * 4)()

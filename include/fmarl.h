@@ -279,6 +279,10 @@ int fmarl_profile_read(void *handle, float *ms, int *steps, int max_count, int *
  * FMARL_FLAG_ASYNC_RESET above), counts[2] step calls followed by separate auto-reset launches, counts[3] stagings of a next
  * episode on the side stream.  bench.py derives the bytes a launch writes from these instead of from the configuration. */
 int fmarl_launch_counts(void *handle, int64_t *counts);
+/* The launch geometry of the step kernels of this handle: geometry[0] workgroups, [1] threads per workgroup, [2] dynamic LDS
+ * bytes per workgroup, [3] envs per workgroup.  (Residency: 160 KB of LDS per CU; a workgroup of exactly 40 960 bytes was
+ * measured to fit only three times, 40 320 four times.) */
+int fmarl_launch_geometry(void *handle, int64_t *geometry);
 
 /* Test hook (tests/test_hip_parity.py): fill the LDS of every CU with 0xFF bytes (one launch of workgroups that take
  * 64 KB each and write all of it).  LDS is not cleared between kernels, so a table a step kernel reads before writing

@@ -1,4 +1,4 @@
-"""measurement aid (GPU box): where a wave of formation_kernel<true> spends its cycles -- the FMARL_TICK sites of a
+"""measurement aid (GPU box): where a wave of formation_kernel<true> / fairnav_kernel<true> spends its cycles -- the FMARL_TICK sites of a
 -DFMARL_MEASURE build (tools/mkvariant.sh measure -DFMARL_MEASURE), summed over the waves of one launch under full load.
 usage: FMARL_LIB=fair_marl_amd/csrc/variants/libfmarl_measure.so python tools/phase_ticks.py [config]"""
 import ctypes as C
@@ -12,6 +12,8 @@ import bench  # noqa: E402
 import fair_marl_amd as fm  # noqa: E402
 from fair_marl_amd import _lib  # noqa: E402
 
+NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'obs+reward+state+info',
+              'node rows', 'adj']
 NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
          'obs+record', 'stats+hits+reward', 'state stores', 'info planes', 'node rows', 'adj']
 
@@ -30,10 +32,20 @@ def main():
     out = (C.c_double * 16)()
     lib.fmarl_measure_ticks.argtypes = [C.POINTER(C.c_double), C.c_int]
     assert lib.fmarl_measure_ticks(out, waves) == 0
-    tot = sum(out)
+    tot = sum(out[:14])
     print('%s: %d waves, %.0f cycles per wave' % (name, waves, tot / waves))
-    for k, nm in enumerate(NAMES):
+    for k, nm in enumerate(NAMES_FNAV if name == 'fnav' else NAMES):
         print('  %-26s %8.0f cycles  %5.1f %%' % (nm, out[k] / waves, 100 * out[k] / tot))
+    import numpy as np
+    rows = np.zeros((waves, 16), dtype=np.uint32)
+    lib.fmarl_measure_rows.argtypes = [C.c_void_p, C.c_int]
+    assert lib.fmarl_measure_rows(rows.ctypes.data, waves) == 0
+    start, end = rows[:, 15].astype(np.int64), rows[:, 14].astype(np.int64)
+    t0 = start.min()
+    print('wave starts (us after the first, 100 MHz clock): percentiles 10/50/90/99/100 = %s' % np.round(np.percentile((start - t0) / 100.0, [10, 50, 90, 99, 100]), 1))
+    print('wave ends: percentiles 10/50/90/100 = %s;  lifetime mean %.1f us' % (np.round(np.percentile((end - t0) / 100.0, [10, 50, 90, 100]), 1), ((end - start) / 100.0).mean()))
+    h, _ = np.histogram((start - t0) / 100.0, bins=12)
+    print('start histogram:', h.tolist())
 
 
 if __name__ == '__main__':
