@@ -584,8 +584,11 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     FMARL_TICKS_END;
 }
 
+#ifndef FMARL_FORM_MIN_BLOCKS
+#define FMARL_FORM_MIN_BLOCKS 1
+#endif
 template <bool STEP>
-__global__ __launch_bounds__(kThreads) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+__global__ __launch_bounds__(kThreads, FMARL_FORM_MIN_BLOCKS) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                              const float *action_vec, int auto_reset) {
     formation_body<STEP>(p, o, action_idx, action_vec, auto_reset);
 }

@@ -417,6 +417,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (const char *e = getenv("FMARL_EPB")) { const int v = atoi(e); if (v >= 1 && v <= epb) epb = v; }   // envs per workgroup (experiments)
 #endif
     if (form) { p.epw = (epb + form_waves - 1) / form_waves; epb = p.epw * form_waves; }
+#ifdef FMARL_MEASURE
+    // experiments: fewer envs in the LAST wave of a formation workgroup (the envs' blocks shrink, the waves' windows do not)
+    if (const char *e = getenv("FMARL_FORM_EPB")) { const int v = atoi(e); if (form && v > (form_waves - 1) * p.epw && v <= epb) epb = v; }
+#endif
     if ((size_t)env_lds > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
     p.lds_stage = align16(epb * p.lds_env_bytes);
