@@ -579,6 +579,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     double2 *s_pos = (double2 *)(base + p.lds_pos);
     double *s_stat = (double *)(lds + p.lds_stat + (size_t)el * p.stat_stride);   // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
 
+    FMARL_TICKS_BEGIN
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0, mtime = 0;
     int step = 0, match = 0;
@@ -604,6 +605,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         __syncthreads();
     }
 
+    FMARL_TICK(0);   // state loads, entity tables, barrier (a carried step: nothing)
     // ---- World.step (core.py:250-274) ---------------------------------------------------------
     double2 goal = make_double2(0, 0);
     if (active) {
@@ -612,6 +614,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         integrate_agent(p, F, x, v, pd);
     }
     __syncthreads();   // every lane has finished reading the old positions
+    FMARL_TICK(1);   // physics, barrier
 
     double dg = 0, Tr_new = 0;
     bool will_reset = false;
@@ -632,6 +635,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         if (i == 0) *(int *)(base + p.lds_flag) = will_reset ? 1 : 0;
     }
     __syncthreads();
+    FMARL_TICK(2);   // agent rows of the emission tables, statistics inputs, barrier
 
     // Statistics of the sequential agent loop.  N a power of two (an env = an aligned run of lanes of one wave):
     // wave scans of (mean, M2) runs, every lane taking part (idle lanes carry zeros); otherwise loops over LDS below.
@@ -647,6 +651,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         if (o.info && !FMARL_SKIP(p, 8)) seg_mixed_stats(p.N, i, Tr_new, Tr_old, tm, ts, bm, bs);
     }
 
+    FMARL_TICK(3);   // statistics as wave scans (N a power of two)
     if (active) {
         const bool open = Tr_old == -1.0;
         const double Dg_new = open ? pd : Dg_old;
@@ -787,8 +792,11 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         if (active && will_reset && i == 0) *(int *)(base + p.lds_flag) = 0;   // this env emits after all
         __syncthreads();
     }
+    FMARL_TICK(4);   // statistics from LDS (other N), hits, reward, state / obs / info stores
     // emission only reads pos / agentf / wall / flag, all final since the barrier above
     if (!FMARL_SKIP(p, 32)) emit_graph(p, o, lds, env0, nenv);
+    FMARL_TICK(5);   // node_obs + adj
+    FMARL_TICKS_END;
 }
 
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(

@@ -12,6 +12,7 @@ import bench  # noqa: E402
 import fair_marl_amd as fm  # noqa: E402
 from fair_marl_amd import _lib  # noqa: E402
 
+NAMES_NAV = ['loads+tables+barrier', 'physics+barrier', 'agent rows+barrier', 'scan statistics', 'stats+hits+reward+stores', 'node_obs+adj']
 NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'obs+reward+state+info',
               'node rows', 'adj']
 NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
@@ -34,7 +35,7 @@ def main():
     assert lib.fmarl_measure_ticks(out, waves) == 0
     tot = sum(out[:14])
     print('%s: %d waves, %.0f cycles per wave' % (name, waves, tot / waves))
-    for k, nm in enumerate(NAMES_FNAV if name == 'fnav' else NAMES):
+    for k, nm in enumerate(NAMES_FNAV if name == 'fnav' else (NAMES if name == 'cfg4' else NAMES_NAV)):
         print('  %-26s %8.0f cycles  %5.1f %%' % (nm, out[k] / waves, 100 * out[k] / tot))
     import numpy as np
     rows = np.zeros((waves, 16), dtype=np.uint32)
