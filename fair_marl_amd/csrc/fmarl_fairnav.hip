@@ -207,14 +207,20 @@ __device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds,
 
 // node_obs rows of the workgroup's envs (nf:1222-1334) from the LDS tables: shared by the step / reset passes and the
 // learner-side rebuild (fairnav_rebuild_kernel).
-__device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+// `all_rows` (the step pass): envs that ended in this step and are reset by the same launch get their rows written as well --
+// the reset pass that follows overwrites them -- so that one ended env does not send the whole workgroup down the per-lane
+// path (13 four-byte stores per row at a 52-byte stride: half the store rate; with episodes ending at all phases nearly every
+// workgroup has such an env in every step)
+__device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv, bool all_rows = false) {
     const int tid = threadIdx.x, N = p.N;
     if (o.node_obs) {
         // one lane per (ego, entity) row: the 13 features share their loads; the rows leave through the waves' LDS
         // windows (fmarl_step.hip flush_rows) unless some env of the workgroup keeps its previous rows
         const uint32_t NE = N * p.E, total = nenv * NE;
         float *dst = o.node_obs + (size_t)env0 * NE * 13;
-        const bool some_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
+        // (the barrier is also what separates the last readers of the second region's tables from the windows that alias it)
+        const bool any_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
+        const bool some_skip = !all_rows && any_skip;
         if (!some_skip) {
             // what the loop needs of the kernel arguments, pinned (fmarl_dev.h pin_sgpr)
             const uint32_t kN = pin_sgpr((uint32_t)p.N), kL = pin_sgpr((uint32_t)p.L), kO = pin_sgpr((uint32_t)p.O), kE = pin_sgpr((uint32_t)p.E);
@@ -279,11 +285,15 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     const int env0 = blockIdx.x * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / N, i = tid - el * N;
-    const bool active = el < nenv;
+    const bool in_range = el < nenv;
     const int env = env0 + el;
     const size_t g = (size_t)env * N + i;
     const FairNavLds t(p, lds, el);
     double *s_stat = t.stat();
+    const bool flagged = STEP ? false : (second ? flagged_in : (in_range && p.reset_flag[env] != 0));
+    // a reset pass only works on the freshly reset envs: with episodes ending at all phases every workgroup runs one behind
+    // every step, for two or three of its 64 envs
+    const bool active = in_range && (STEP || flagged);
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0, status = 0;
@@ -295,10 +305,9 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         step = p.cur_step[env] + (STEP ? 1 : 0);
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
-    const bool flagged = STEP ? false : (second ? flagged_in : (active && p.reset_flag[env] != 0));
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
     if (!STEP && !second && !__syncthreads_or(flagged)) return false;
-    if (!STEP && active && i == 0) *t.flag() = flagged ? 0 : 1;   // (a step knows it once the agents' done flags are in)
+    if (!STEP && in_range && i == 0) *t.flag() = flagged ? 0 : 1;   // (a step knows it once the agents' done flags are in)
     load_statics(p, lds, env0, nenv);
     __syncthreads();
     FMARL_TICK(0);   // state loads, entity tables, barrier
@@ -489,7 +498,8 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICK(6);   // obs, reward, statistics, state stores, info planes
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
     if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return ended; }
-    fairnav_emit_rows(p, o, lds, env0, nenv);
+    // (a step whose ended envs are reset by this launch writes all rows: every skipping env of a step pass is such an env)
+    fairnav_emit_rows(p, o, lds, env0, nenv, STEP && auto_reset != 0);
     FMARL_TICK(7);   // node rows
     emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
     FMARL_TICK(8);   // adj
@@ -526,7 +536,7 @@ __device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs
 }
 
 template <bool STEP>
-__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+__global__ __launch_bounds__(kThreads, 4) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                            const float *action_vec, int auto_reset) {
     fairnav_body<STEP>(p, o, action_idx, action_vec, auto_reset);
 }
