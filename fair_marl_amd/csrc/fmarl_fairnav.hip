@@ -207,11 +207,12 @@ __device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds,
 
 // node_obs rows of the workgroup's envs (nf:1222-1334) from the LDS tables: shared by the step / reset passes and the
 // learner-side rebuild (fairnav_rebuild_kernel).
-// `all_rows` (the step pass): envs that ended in this step and are reset by the same launch get their rows written as well --
+// ALL_ROWS (the step pass): envs that ended in this step and are reset by the same launch get their rows written as well --
 // the reset pass that follows overwrites them -- so that one ended env does not send the whole workgroup down the per-lane
 // path (13 four-byte stores per row at a 52-byte stride: half the store rate; with episodes ending at all phases nearly every
 // workgroup has such an env in every step)
-__device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv, bool all_rows = false) {
+template <bool ALL_ROWS = false>
+__device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x, N = p.N;
     if (o.node_obs) {
         // one lane per (ego, entity) row: the 13 features share their loads; the rows leave through the waves' LDS
@@ -220,7 +221,7 @@ __device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOu
         float *dst = o.node_obs + (size_t)env0 * NE * 13;
         // (the barrier is also what separates the last readers of the second region's tables from the windows that alias it)
         const bool any_skip = __syncthreads_or(tid < nenv && FairNavLds(p, lds, tid).skip());
-        const bool some_skip = !all_rows && any_skip;
+        const bool some_skip = !ALL_ROWS && any_skip;
         if (!some_skip) {
             // what the loop needs of the kernel arguments, pinned (fmarl_dev.h pin_sgpr)
             const uint32_t kN = pin_sgpr((uint32_t)p.N), kL = pin_sgpr((uint32_t)p.L), kO = pin_sgpr((uint32_t)p.O), kE = pin_sgpr((uint32_t)p.E);
@@ -291,9 +292,9 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     const FairNavLds t(p, lds, el);
     double *s_stat = t.stat();
     const bool flagged = STEP ? false : (second ? flagged_in : (in_range && p.reset_flag[env] != 0));
-    // a reset pass only works on the freshly reset envs: with episodes ending at all phases every workgroup runs one behind
-    // every step, for two or three of its 64 envs
-    const bool active = in_range && (STEP || flagged);
+    // (a reset pass restricted to the freshly reset envs -- two or three of the 64 -- measured the same: the pass is a dependent
+    // chain, not work, and the restriction cost three registers, i.e. the fourth workgroup per CU)
+    const bool active = in_range;
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
     double pd = 0, status = 0;
@@ -498,8 +499,8 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICK(6);   // obs, reward, statistics, state stores, info planes
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
     if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return ended; }
-    // (a step whose ended envs are reset by this launch writes all rows: every skipping env of a step pass is such an env)
-    fairnav_emit_rows(p, o, lds, env0, nenv, STEP && auto_reset != 0);
+    // (a step pass writes all rows: an env that skips in a step pass has ended and is reset by this same launch)
+    fairnav_emit_rows<STEP>(p, o, lds, env0, nenv);
     FMARL_TICK(7);   // node rows
     emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
     FMARL_TICK(8);   // adj
@@ -536,7 +537,7 @@ __device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs
 }
 
 template <bool STEP>
-__global__ __launch_bounds__(kThreads, 4) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                            const float *action_vec, int auto_reset) {
     fairnav_body<STEP>(p, o, action_idx, action_vec, auto_reset);
 }
