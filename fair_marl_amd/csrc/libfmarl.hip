@@ -382,12 +382,12 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     int epb = kThreads / p.N;
     int shared_bytes = (kThreads / 64) * p.stage_wave_bytes;   // the windows' region (also holds the shared statistics blocks)
     if (stat_shared && epb * 5 * p.N * 8 > shared_bytes) shared_bytes = epb * 5 * p.N * 8;
-    // 40 KB per workgroup = four workgroups per CU (160 KB).  With 48 KB the shipped nav_fairassign configuration took 47 envs
+    // about 40 KB per workgroup = four workgroups per CU (160 KB; kFourPerCu below: not the full quarter).  With 48 KB the shipped nav_fairassign configuration took 47 envs
     // per workgroup at three per CU: 0.082 ms per launch against 0.078 with 36 envs at four per CU (tools/epb_probe.sh fnav);
     // navigation_graph at 10 agents had gained 7 % from the same 3 -> 4 step.
     // fairnav: the windows alias the second region (the tables there are dead by then): the region holds whichever is larger
     const int kFourPerCu = 40320;   // LDS of a workgroup such that four share a CU: 40 960 = 160 KB / 4 does NOT fit four (measured)
-    const int budget = (fnav ? kFourPerCu : 40 * 1024) - (fnav ? 0 : shared_bytes);
+    const int budget = kFourPerCu - (fnav ? 0 : shared_bytes);
     const int env_lds = p.lds_env_bytes + form_dead;   // LDS of one env incl. its share of the second region (formation, fairnav)
     if (epb * env_lds > budget) epb = budget / env_lds;
     if (fnav) while (epb > 1 && epb * p.lds_env_bytes + (epb * form_dead > shared_bytes ? epb * form_dead : shared_bytes) > kFourPerCu) --epb;
