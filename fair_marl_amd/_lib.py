@@ -115,6 +115,8 @@ _SIGS = {
     'fmarl_compute_returns': (C.c_int, [C.POINTER(FmarlReturns), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'fmarl_advantages_workspace': (C.c_size_t, []),
     'fmarl_advantages': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'fmarl_advantages_sums': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'fmarl_advantages_apply': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'fmarl_minibatch_gather': (C.c_int, [C.POINTER(FmarlBatchSrc), C.POINTER(FmarlBatchDst), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

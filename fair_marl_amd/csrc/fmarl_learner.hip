@@ -115,6 +115,19 @@ __global__ __launch_bounds__(256) void advantage_raw_kernel(const float *returns
     }
 }
 
+// The partials of pass 1 as ONE triple (count, sum, sum of squares): for a caller that adds the triples of several processes
+// (data-parallel learners, one rollout shard per GPU) before pass 2 -- fmarl_advantages_sums / fmarl_advantages_apply.
+__global__ __launch_bounds__(256) void advantage_sum_kernel(const double *partials, int nparts, double *sums) {
+    __shared__ double red[3][4];
+    double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+        const double *q = partials + 3 * (size_t)b;
+        cnt += q[0]; s1 += q[1]; s2 += q[2];
+    }
+    block_sum3(cnt, s1, s2, red);
+    if (threadIdx.x == 0) { sums[0] = cnt; sums[1] = s1; sums[2] = s2; }
+}
+
 // Pass 2: every workgroup adds the partials of pass 1 in the same fixed order (thread k takes k, k + 256, ...; then the wave
 // and block reduction) -- a few KB out of L2, and no fence or atomic ticket: an agent-scope release on this chip writes the
 // XCD's L2 back, which cost more than the whole pass -- and standardises its share of the entries.  Workgroup 0 leaves

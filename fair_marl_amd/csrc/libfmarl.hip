@@ -935,24 +935,56 @@ int fmarl_compute_returns(const FmarlReturns *a, const float *rewards, float *va
 static_assert(sizeof(FmarlReturns) == 48 && sizeof(FmarlBatchSrc) == 144 && sizeof(FmarlBatchDst) == 136, "C-ABI layout (fair_marl_amd/_lib.py mirrors it)");
 static const int kAdvBlocks = 2048;   // 8 per CU; their partials are one pass of the last block
 
-size_t fmarl_advantages_workspace(void) { return 16 + (size_t)kAdvBlocks * 3 * sizeof(double); }
+// workspace: [mean, std (2 floats) | pad 8][sums: count, sum, sum of squares (3 doubles) | pad 8][partials: kAdvBlocks x 3 doubles]
+size_t fmarl_advantages_workspace(void) { return 48 + (size_t)kAdvBlocks * 3 * sizeof(double); }
 
-int fmarl_advantages(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
-                     int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream) {
-    if (!returns || !value_preds || !active_masks || !advantages || !workspace || count < 1)
-        return fail(FMARL_EINVAL, "fmarl_advantages: bad argument");
-    float *stats = (float *)workspace;
-    double *partials = (double *)((char *)workspace + 16);
+static int advantages_pass1(const float *returns, const float *value_preds, const float *active_masks, float *advantages, int64_t count,
+                            int denormalize, float mean, float stddev, void *workspace, hipStream_t st, const char *who) {
+    if (!returns || !value_preds || !active_masks || !advantages || !workspace || count < 1) { fail(FMARL_EINVAL, "%s: bad argument", who); return -1; }
+    double *partials = (double *)((char *)workspace + 48);
     const bool wide = ((((uintptr_t)returns) | ((uintptr_t)value_preds) | ((uintptr_t)active_masks) | ((uintptr_t)advantages)) & 15) == 0;
     const int64_t want = ((wide ? count / 4 : count) + 255) / 256 + 1;
     const int blocks = (int)(want < kAdvBlocks ? want : kAdvBlocks);
     if (wide)
-        hipLaunchKernelGGL(advantage_raw_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, returns, value_preds, active_masks,
-                           advantages, (size_t)count, mean, stddev, denormalize ? 1 : 0, partials);
+        hipLaunchKernelGGL(advantage_raw_kernel<4>, dim3(blocks), dim3(256), 0, st, returns, value_preds, active_masks, advantages, (size_t)count,
+                           mean, stddev, denormalize ? 1 : 0, partials);
     else
-        hipLaunchKernelGGL(advantage_raw_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, returns, value_preds, active_masks,
-                           advantages, (size_t)count, mean, stddev, denormalize ? 1 : 0, partials);
-    hipLaunchKernelGGL(advantage_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, advantages, (size_t)count, partials, blocks, stats);
+        hipLaunchKernelGGL(advantage_raw_kernel<1>, dim3(blocks), dim3(256), 0, st, returns, value_preds, active_masks, advantages, (size_t)count,
+                           mean, stddev, denormalize ? 1 : 0, partials);
+    return blocks;
+}
+
+static int advantages_blocks(int64_t count) {
+    const int64_t want = (count + 255) / 256 + 1;
+    return (int)(want < kAdvBlocks ? want : kAdvBlocks);
+}
+
+int fmarl_advantages(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
+                     int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream) {
+    const int blocks = advantages_pass1(returns, value_preds, active_masks, advantages, count, denormalize, mean, stddev, workspace,
+                                        (hipStream_t)stream, "fmarl_advantages");
+    if (blocks < 0) return FMARL_EINVAL;
+    hipLaunchKernelGGL(advantage_scale_kernel, dim3(advantages_blocks(count)), dim3(256), 0, (hipStream_t)stream, advantages, (size_t)count,
+                       (const double *)((char *)workspace + 48), blocks, (float *)workspace);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_advantages_sums(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
+                          int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream) {
+    const int blocks = advantages_pass1(returns, value_preds, active_masks, advantages, count, denormalize, mean, stddev, workspace,
+                                        (hipStream_t)stream, "fmarl_advantages_sums");
+    if (blocks < 0) return FMARL_EINVAL;
+    hipLaunchKernelGGL(advantage_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)((char *)workspace + 48), blocks,
+                       (double *)((char *)workspace + 16));
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_advantages_apply(float *advantages, int64_t count, void *workspace, void *stream) {
+    if (!advantages || !workspace || count < 1) return fail(FMARL_EINVAL, "fmarl_advantages_apply: bad argument");
+    hipLaunchKernelGGL(advantage_scale_kernel, dim3(advantages_blocks(count)), dim3(256), 0, (hipStream_t)stream, advantages, (size_t)count,
+                       (const double *)((char *)workspace + 16), 1, (float *)workspace);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

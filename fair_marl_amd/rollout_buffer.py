@@ -212,17 +212,34 @@ class DeviceRolloutBuffer(object):
         self._keep = nv
         return self.returns
 
-    def advantages(self, value_normalizer=None):
+    def advantages(self, value_normalizer=None, group=None):
         """What ``GR_MAPPO.train`` hands to the generators (onpolicy/algorithms/graph_mappo.py:294-304): returns[:-1] minus the
         (denormalised) value predictions, standardised over the entries with a non-zero active mask.  (T, n, N, 1) float32;
-        ``advantage_stats`` afterwards views the (mean, std) the kernel used."""
+        ``advantage_stats`` afterwards views the (mean, std) the kernel used.
+
+        ``group``: a ``torch.distributed`` process group (or True for the default one) of data-parallel learners, one rollout
+        shard and one buffer per GPU: the (count, sum, sum of squares) triples of the ranks are added (one 24-byte all-reduce)
+        and every rank standardises with the statistics of the whole batch, as one process holding all envs would."""
         self._need_policy()
         dn, mean, std = self._mean_std(value_normalizer)
         adv = torch.empty_like(self.rewards)
-        rc = _lib.load().fmarl_advantages(self.returns.data_ptr(), self.value_preds.data_ptr(), self.active_masks.data_ptr(), adv.data_ptr(),
-                                          adv.numel(), dn, mean, std, self._adv_ws.data_ptr(),
-                                          torch.cuda.current_stream(self.engine.device).cuda_stream)
-        _lib.check(rc, 'fmarl_advantages')
+        lib, st = _lib.load(), torch.cuda.current_stream(self.engine.device).cuda_stream
+        args = (self.returns.data_ptr(), self.value_preds.data_ptr(), self.active_masks.data_ptr(), adv.data_ptr(), adv.numel(), dn, mean, std,
+                self._adv_ws.data_ptr(), st)
+        if group is None:
+            _lib.check(lib.fmarl_advantages(*args), 'fmarl_advantages')
+        else:
+            import torch.distributed as dist
+            grp = None if group is True else group
+            _lib.check(lib.fmarl_advantages_sums(*args), 'fmarl_advantages_sums')
+            sums = self._adv_ws[16:40].view(torch.float64)
+            if dist.get_backend(grp) == 'gloo':      # (ranks sharing a GPU in the tests: through host memory)
+                host = sums.cpu()
+                dist.all_reduce(host, group=grp)
+                sums.copy_(host)
+            else:
+                dist.all_reduce(sums, group=grp)     # RCCL, on the current stream's successor: 24 bytes
+            _lib.check(lib.fmarl_advantages_apply(adv.data_ptr(), adv.numel(), self._adv_ws.data_ptr(), st), 'fmarl_advantages_apply')
         self.advantage_stats = self._adv_ws[:8].view(torch.float32)
         return adv
 

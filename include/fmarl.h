@@ -409,6 +409,14 @@ int fmarl_compute_returns(const FmarlReturns *args, const float *rewards, float 
 size_t fmarl_advantages_workspace(void);
 int fmarl_advantages(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
                      int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream);
+/* The same in two halves, for data-parallel learners (one rollout shard and one buffer per GPU, gradients averaged -- there is
+ * no trajectory to ship): fmarl_advantages_sums writes the raw advantages and leaves (count, sum, sum of squares) of the
+ * active entries as three doubles at workspace + 16; the caller adds the triples of all ranks in place (an all-reduce of 24
+ * bytes); fmarl_advantages_apply standardises with the mean / deviation of the summed triple -- every rank then normalises
+ * with the statistics of the WHOLE batch, as one process holding all envs would (and leaves them at the start of workspace). */
+int fmarl_advantages_sums(const float *returns, const float *value_preds, const float *active_masks, float *advantages,
+                          int64_t count, int denormalize, float mean, float stddev, void *workspace, void *stream);
+int fmarl_advantages_apply(float *advantages, int64_t count, void *workspace, void *stream);
 
 /* The rows of one minibatch of GraphReplayBuffer.feed_forward_generator (mode 0, graph_buffer.py:368-453) or
  * recurrent_generator (mode 1, :597-758) gathered from the buffer: FmarlBatchSrc = the buffer's arrays ((T + 1, n, N, ...)

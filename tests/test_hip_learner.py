@@ -186,3 +186,11 @@ def test_example_rollout_to_minibatches_runs():
     seen, buf = mod.main(n_envs=n, num_agents=N, iterations=2, num_mini_batch=2, data_chunk_length=10, hidden_size=8, device=DEV, verbose=False)
     assert seen == 2 * buf.T * n * N
     assert torch.isfinite(buf.returns).all() and float(buf.masks.min()) == 0.0   # an episode end fell inside the rollouts
+
+
+def test_data_parallel_advantages_equal_the_unsharded_buffer():
+    """Three ranks, one buffer shard each (ranks share the GPU, exchange over gloo): advantages(group=...) standardises with the
+    statistics of the whole batch -- equal to one buffer over all envs (tests/dist_learner_check.py)."""
+    from test_hip_parity import _run_ranks
+    out = _run_ranks([os.path.join(HERE, 'dist_learner_check.py')], world=3)
+    assert 'DIST_LEARNER_OK world=3' in out, out[-4000:]
