@@ -21,13 +21,17 @@ NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot dis
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else 'cfg4'
-    kw, n = bench.CONFIGS[name]['env'], bench.CONFIGS[name]['n_envs']
+    kw, n = dict(bench.CONFIGS[name]['env']), bench.CONFIGS[name]['n_envs']
+    if len(sys.argv) > 2:   # fnav with episodes ending at all phases: python tools/phase_ticks.py fnav 0.5 600  (then the table shows
+        kw['min_dist_thresh'] = float(sys.argv[2])   # the RESET pass of the last launch: it overwrites the step pass's rows)
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     cfg = fm.EnvConfig(**kw)
     eng = fm.RolloutEngine(cfg, n, device='cuda:0', seed=5, tune_placement=0)
     gen = torch.Generator(device='cuda:0'); gen.manual_seed(2)
     eng.reset()
-    for t in range(12):
-        eng.step(torch.randint(0, 5, (n, cfg.N), device='cuda:0', generator=gen, dtype=torch.int32))
+    tape = torch.randint(0, 5, (25, n, cfg.N), device='cuda:0', generator=gen, dtype=torch.int32)
+    for t in range(steps):
+        eng.step(tape[t % 25])
     lib = _lib.load()
     waves = -(-n // eng.envs_per_workgroup) * 4
     out = (C.c_double * 16)()
