@@ -794,8 +794,27 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     }
     FMARL_TICK(4);   // statistics from LDS (other N), hits, reward, state / obs / info stores
     // emission only reads pos / agentf / wall / flag, all final since the barrier above
+#ifdef FMARL_MEASURE
+    if (!FMARL_SKIP(p, 32)) {   // emit_graph with clocks between its parts (odd workgroups write adj first)
+        const bool adj_first = (blockIdx.x & 1) != 0;
+        if (adj_first) emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+        FMARL_TICK(6);   // adj (odd workgroups)
+        if (o.node_obs && p.vec_node) {
+            const uint32_t groups = (((p.E * p.F) >> 2) + 63) >> 6;
+            if (groups <= 1) emit_node_rows<1>(p, o, lds, env0, nenv);
+            else if (groups <= 2) emit_node_rows<2>(p, o, lds, env0, nenv);
+            else emit_node_rows<4>(p, o, lds, env0, nenv);
+        } else if (o.node_obs) {
+            if (p.feat_global) emit_node_rows_generic<true>(p, o, lds, env0, nenv);
+            else emit_node_rows_generic<false>(p, o, lds, env0, nenv);
+        }
+        FMARL_TICK(5);   // node_obs
+        if (!adj_first) emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+        FMARL_TICK(7);   // adj (even workgroups)
+    }
+#else
     if (!FMARL_SKIP(p, 32)) emit_graph(p, o, lds, env0, nenv);
-    FMARL_TICK(5);   // node_obs + adj
+#endif
     FMARL_TICKS_END;
 }
 

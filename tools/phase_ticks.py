@@ -12,7 +12,8 @@ import bench  # noqa: E402
 import fair_marl_amd as fm  # noqa: E402
 from fair_marl_amd import _lib  # noqa: E402
 
-NAMES_NAV = ['loads+tables+barrier', 'physics+barrier', 'agent rows+barrier', 'scan statistics', 'stats+hits+reward+stores', 'node_obs+adj']
+NAMES_NAV = ['loads+tables+barrier', 'physics+barrier', 'agent rows+barrier', 'scan statistics', 'stats+hits+reward+stores', 'node_obs',
+             'adj (odd workgroups: first)', 'adj (even workgroups: last)']
 NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'obs+reward+state+info',
               'node rows', 'adj']
 NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
