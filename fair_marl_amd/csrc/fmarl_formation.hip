@@ -272,7 +272,7 @@ __device__ __forceinline__ void travelled_stats(const double *pd, const double *
 // STEP = false: observation of freshly reset envs (MultiAgentGraphEnv.reset, environment.py:892-897)
 template <bool STEP>
 __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
-                                               const float *action_vec, int auto_reset) {
+                                               const float *action_vec, int auto_reset, const bool tables_loaded = false) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N;
@@ -320,7 +320,8 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     }
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
     if (!STEP && !__syncthreads_or(active && rf != 0)) return;
-    load_statics_range(p, lds, env0, 0, nenv, tid, blockDim.x);   // (its loads join the batch: nothing above has waited for a value yet)
+    // (a later step of a span: the static entities are still in the envs' tables -- no episode ends inside a span)
+    if (!tables_loaded) load_statics_range(p, lds, env0, 0, nenv, tid, blockDim.x);   // (its loads join the batch: nothing above has waited for a value yet)
     if (active) {
         t.pos()[i] = x;
         t.slot_old()[i] = so;
@@ -330,7 +331,10 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         emit = STEP ? !(auto_reset && step >= p.episode_length) : rf != 0;
         if (i == 0) *t.flag() = emit ? 0 : 1;
     }
-    __syncthreads();   // the only workgroup barrier: the entity tables are loaded by all four waves together
+    // the only workgroup barrier: the entity tables are loaded by all four waves together (a later step of a span has none:
+    // every env lives in one wave, and nothing a wave reads was written by another one)
+    if (!tables_loaded) __syncthreads();
+    else wave_sync();
     if (active && socc != 0.0) atomicOr(&t.words()[0], 1u << i);   // occupancy left by the previous pass
     FMARL_TICK(0);   // loads issued, entity tables, the barrier
 
@@ -600,8 +604,10 @@ __global__ __launch_bounds__(kThreads, 4) void formation_span_kernel(Params p, F
         const Params q = span_params(p);
         const FmarlOutputs ot = span_outputs(o, s, t);
         formation_body<true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr,
-                             action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0);
-        span_step_done();
+                             action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0, t > 0);
+        // a wave re-reads from global memory only what it wrote itself (every env inside one wave): its own stores complete,
+        // no workgroup barrier
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 
