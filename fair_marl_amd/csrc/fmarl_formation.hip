@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kThreads, FMARL_FORM_MIN_BLOCKS) void formation_ker
 __global__ __launch_bounds__(kThreads, 4) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx,
                                                                      const float *action_vec, int T) {
     for (int t = 0; t < T; ++t) {
-        const Params q = span_params(p);
+        const Params &q = span_params_reloaded();   // == p
         const FmarlOutputs ot = span_outputs(o, s, t);
         formation_body<true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr,
                              action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0, t > 0);
