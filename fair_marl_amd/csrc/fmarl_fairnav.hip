@@ -533,11 +533,13 @@ __device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs
     }
     __threadfence_block();   // the reset pass re-reads the state of the placed envs from global memory
     __syncthreads();
-    fairnav_pass<false>(p, o, lds, nullptr, nullptr, 0, true, ended);
+    // (the argument block re-read through an opaque pointer: nothing of it stays in scalar registers across the step pass for the
+    // sake of this one -- fmarl_dev.h span_params_reloaded)
+    fairnav_pass<false>(span_params_reloaded(), o, lds, nullptr, nullptr, 0, true, ended);
 }
 
 template <bool STEP>
-__global__ __launch_bounds__(kThreads) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+__global__ __launch_bounds__(kThreads, 4) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                            const float *action_vec, int auto_reset) {
     fairnav_body<STEP>(p, o, action_idx, action_vec, auto_reset);
 }
