@@ -222,7 +222,9 @@ __device__ __forceinline__ void batch_cell(const FmarlBatchSrc &s, const int64_t
 
 constexpr int kNarrow = 16;   // fields up to this many floats per row go out tile-wise
 
-__device__ __forceinline__ void copy_field(float *dst, const float *src, int w, long long cell_l, int64_t r0, int cnt, int lane) {
+// (not inlined: fifteen inlined copies of the two loops cost the kernel 179 VGPRs = two waves per SIMD; as a function the whole
+// kernel needs a third of that, and a call per field and tile of 64 rows is nothing beside the rows it copies)
+__device__ __attribute__((noinline)) void copy_field(float *dst, const float *src, int w, long long cell_l, int64_t r0, int cnt, int lane) {
     if (!dst) return;
     if (w <= kNarrow) { copy_narrow(dst + (size_t)r0 * w, src, w, cell_l, cnt, lane); return; }
     for (int i = 0; i < cnt; ++i) {
@@ -231,8 +233,18 @@ __device__ __forceinline__ void copy_field(float *dst, const float *src, int w, 
     }
 }
 
-__global__ __launch_bounds__(256) void minibatch_gather_kernel(FmarlBatchSrc s, FmarlBatchDst d, const int64_t *index, int64_t rows,
+__global__ __launch_bounds__(256) void minibatch_gather_kernel(FmarlBatchSrc s_arg, FmarlBatchDst d_arg, const int64_t *index, int64_t rows,
                                                                int mode, int chunk, int64_t chunks, int tile) {
+    // the two pointer blocks (35 pointers) are read from the kernel's argument segment where a field is used, through a pointer the
+    // compiler cannot see through: loaded up front they do not fit the scalar registers (286 of them were spilled into vector
+    // lanes, every use a v_readlane)
+    typedef const FmarlBatchSrc __attribute__((address_space(4))) *SrcArg;
+    typedef const FmarlBatchDst __attribute__((address_space(4))) *DstArg;
+    const uint64_t ka = pin_sgpr((uint64_t)__builtin_amdgcn_kernarg_segment_ptr());
+    const FmarlBatchSrc &s = *(const FmarlBatchSrc *)(SrcArg)ka;
+    const FmarlBatchDst &d = *(const FmarlBatchDst *)(DstArg)(ka + sizeof(FmarlBatchSrc));
+    static_assert(sizeof(FmarlBatchSrc) % 8 == 0, "the second argument follows the first without padding");
+    (void)s_arg; (void)d_arg;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int N = s.N;
