@@ -7,7 +7,10 @@
 A "step" is one env step of EVERY env of every rank (one pass of the hot path over one batch):
 action decode -> World.step physics -> obs / reward / info / node_obs / adj emission, plus the
 auto-reset (placement + fair assignment + reset observation) whenever an episode ends (every
-25th step).  Inputs (the random action tape) and all outputs stay resident in HBM.
+25th step).  Inputs (the random action tape) and all outputs stay resident in HBM; every step's
+outputs go to a time slot of their own (--slots ring: an episode-long ring of (T, n, ...) arrays, the
+layout of the reference's rollout storage), so the trajectory exists when the rollout is over and
+every byte of it is written once per pass.
 
 Metric (BASELINE.json): agent-steps/s = total envs x agents x K / wall seconds, where wall is
 the max over ranks of the time of exactly K steps bracketed by barrier + device sync.
@@ -56,8 +59,12 @@ CONFIGS = {   # workload: a format string, filled with the number of envs the ru
 KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
-SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'), ('cfg4', 'eager'), ('cfg4', 'span'),
-             ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'pipeline2'), ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
+SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg3', 'span5'), ('cfg3', 'span-same'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'),
+             ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'pipeline2'), ('fnav', 'steady'),
+             ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
+# nav_fairassign_fairrew_formation_graph where a training run is: a threshold at which goals are reached, so that episodes end
+# env by env, and enough untimed steps for the envs' episode phases to be uniform (mode 'steady'; tools/fnav_steady.py)
+STEADY = dict(min_dist_thresh=0.5, pre_steps=600)
 
 
 # The reference's OWN CPU path (GraphSubprocVecEnv, one process per env), timed in the build container where the reference
@@ -83,13 +90,61 @@ def algorithmic_bytes(cfg, emit=True):
     return 4.0 * words
 
 
-def store_ceiling_ms(eng, launches=10):
+def _scatter_order(chunks):
+    import math
+    o = int(chunks * 0.6180339887) | 1
+    while math.gcd(o, chunks) != 1:
+        o += 2
+    return o
+
+
+def store_ceiling(device, step_bytes, steps=1, launches=4):
+    """The box's write ceiling for a launch that writes `steps` steps' bytes: the best pure 16-byte store stream over that
+    byte count (fmarl_store_stream: kernels that do nothing but write, in the shapes the emission writes in -- a workgroup's
+    contiguous chunk, a wave's contiguous quarter of one -- in dispatch order and scattered over the buffer).  No step kernel
+    can be faster than its own store stream, so kernel time per step / this figure <= 1 by construction -- unlike the
+    emission-only launch of rounds 2-3 (`emission_only_ms`), which a span could beat.  Capped at 8 steps' bytes (66 GB at
+    cfg 3): a longer stream only amortises the same head and tail further (24 steps: 1.151 ms per step, one step: 1.163).
+    Returns dict(ms_per_step, TBps, shape, streams={shape: ms per step})."""
+    import ctypes as C
+    from fair_marl_amd import _lib
+    lib = _lib.load()
+    step_bytes = int(step_bytes) // 16 * 16
+    k = max(1, min(int(round(steps)), 8))
+    free, _ = torch.cuda.mem_get_info(device)
+    while k > 1 and k * step_bytes > free * 0.8:
+        k -= 1
+    nbytes = k * step_bytes
+    if nbytes < (1 << 16) or nbytes > free * 0.8:
+        return None
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {}
+    for shape, chunk, scat in ((1, 1 << 20, False), (1, 1 << 20, True), (2, 1 << 20, True), (2, 1 << 16, True)):
+        chunk = min(chunk, max(4096, nbytes // 64 // 16 * 16))
+        chunks = (nbytes // 16 + chunk // 16 - 1) // (chunk // 16)
+        order = _scatter_order(chunks) if scat and chunks >= 64 else 1
+        call = lambda: _lib.check(lib.fmarl_store_stream(buf.data_ptr(), nbytes, shape, chunk, order, 0, st), 'fmarl_store_stream')  # noqa: E731
+        call()
+        e0.record()
+        for _ in range(launches):
+            call()
+        e1.record()
+        e1.synchronize()
+        out['shape %d, %d KB chunks, %s' % (shape, chunk >> 10, 'scattered' if order > 1 else 'dispatch order')] = e0.elapsed_time(e1) / launches / k
+    del buf
+    torch.cuda.empty_cache()
+    best = min(out, key=out.get)
+    return dict(ms_per_step=out[best], TBps=step_bytes / out[best] / 1e9, shape=best, steps_per_launch=k, streams=out)
+
+
+def emission_only_ms(eng, launches=10):
     """What the emission alone costs on THIS box and THESE buffers: the pure emission kernel (fmarl_rebuild_graph: writes
-    node_obs + adj of every env from obs + the episode record, touches no env state) timed on the engine's own output
-    buffers.  The step kernel cannot be faster than its own store stream; kernel_avg_ms against this figure separates the
-    kernel from the box (HBM write rates differ by 10 % between boxes).  navigation_graph only (the two
-    formation scenarios rebuild from a per-step record the engine does not write by default); call it after the timed region,
-    it overwrites node_obs / adj."""
+    node_obs + adj of every env from obs + the episode record, touches no env state) timed on the engine's current output
+    buffers.  One launch per step's bytes incl. its head and tail -- a reference point for the one-launch-per-step mode, not a
+    ceiling (that is `store_ceiling`).  navigation_graph only (the two formation scenarios rebuild from a per-step record the
+    engine does not write by default); call it after the timed region, it overwrites node_obs / adj."""
     if eng.cfg.scenario_name != 'navigation_graph' or eng.node_obs is None:
         return None
     rec = eng.pack_episode()
@@ -104,6 +159,16 @@ def store_ceiling_ms(eng, launches=10):
     return e0.elapsed_time(e1) / launches
 
 
+def moved_bytes(cfg, agents, steps):
+    """Bytes a span launch of `steps` steps really moves by the formula's own terms: everything but the state per step, the state
+    (S = 2 x 12 words) and the static entity words once per launch -- the span kernels keep both on the chip between the steps
+    (the per-step formula counts them every step)."""
+    per_step = algorithmic_bytes(cfg)
+    C = 2 * (cfg.num_landmarks + cfg.num_obstacles) + 6 * cfg.num_walls
+    once = 4.0 * (2 * 12 + C / cfg.N)
+    return agents * ((per_step - once) * steps + once)
+
+
 def launch_bytes(cfg, agents, counts0, counts1):
     """Mean algorithmic bytes per step-kernel launch between two fmarl_launch_counts readings: a launch emits the full outputs
     unless it is an episode-ending step whose reset observation is written by separate reset launches (counts[2])."""
@@ -112,41 +177,79 @@ def launch_bytes(cfg, agents, counts0, counts1):
     return agents * (algorithmic_bytes(cfg) * (launches - quiet) + algorithmic_bytes(cfg, emit=False) * quiet) / max(1, launches)
 
 
-# envs per workgroup for the span launches of the secondary lines (0 = the library's choice): a span kernel keeps a workgroup's
-# slot for a whole run of steps, so the number of workgroups should be a multiple of what the chip holds at once
-SPAN_EPB = {'cfg3': 4}
+# envs per workgroup of span launches (0 / absent = the library's choice).  Spans into time slots (the default) run fastest at the
+# library's choice; spans that rewrite ONE output set every step (--slots same, round 3's mode) at one env per wave for cfg 3
+# (profiles/r4_span_slots.md: 1.24 ms per step at 8 envs per workgroup into slots, 1.33 at 4 / 1.41 at 8 into the same set)
+SPAN_EPB = {}
+SAME_SLOT_EPB = {'cfg3': 4}
+# steps per span launch when the records of a run travel to a learner rank (N > 1): a run's records can only leave when its launch
+# has ended, so the LAST run's gather of a timed region is exposed in full -- short runs keep it short, long runs save launches
+GATHER_SPAN_STEPS = 5
 
 
-def secondary_line(name, mode, device, steps=300, warmup=50):
+def _use_ring(cfg, n_envs, slots, device):
+    """Time slots for every step (an episode-long OutputRing) unless the caller asked for one output set or the ring would not fit."""
+    if slots != 'ring':
+        return False
+    per_slot = n_envs * cfg.N * 4.0 * (cfg.obs_dim + 1 + 0.25 + 14 + cfg.node_feat * cfg.E + cfg.E * cfg.E / cfg.N)
+    free, _ = torch.cuda.mem_get_info(device)
+    return per_slot * cfg.episode_length < free * 0.85
+
+
+def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
     """One more BASELINE config on this GPU: fresh engine, `warmup` untimed steps (whole episodes), `steps` timed steps (whole
-    episodes), synchronised on both sides, all through RolloutEngine.rollout(tape, mode):
+    episodes), synchronised on both sides, all through RolloutEngine.rollout(tape, mode, ring):
       'eager' = one fmarl_step call per step (what a policy in the loop gets);
       'span'  = fmarl_step_span: the steps between episode ends as ONE launch in which every workgroup walks its own envs through
                 time, the step that ends the episode as a launch of its own (random-action / scripted rollouts: actions known
                 ahead, the metric of BASELINE.json);
-      'graph' = one hipGraph replay per episode (launch-bound batches);
+      'span<S>' = the same in runs of at most S steps (the launch pattern of an N > 1 run, whose records leave run by run);
+      'span-same' = spans that rewrite ONE output set every step (stride 0: round 3's headline mode, kept for comparison);
+      'graph' = one hipGraph replay per episode (launch-bound batches; one output set);
+      'steady' (nav_fairassign_fairrew_formation_graph) = one launch per step with episodes ending at all phases (STEADY);
       'pipeline<k>' = k sub-batches on k streams.
+    Every step writes its own time slot of an episode-long ring (`slots`: 'ring') except where the mode says otherwise.
     kernel_avg_ms is per STEP in every mode (a span launch's duration divided by its steps)."""
     spec = CONFIGS[name]
-    cfg = fm.EnvConfig(**spec['env'])
+    env_kw = dict(spec['env'])
+    pre_steps = 0
+    if mode == 'steady':
+        env_kw['min_dist_thresh'] = STEADY['min_dist_thresh']
+        pre_steps = STEADY['pre_steps']
+    cfg = fm.EnvConfig(**env_kw)
     n = spec['n_envs']
     ep = cfg.episode_length
     steps, warmup = max(ep, steps // ep * ep), (warmup + ep - 1) // ep * ep
     if mode.startswith('pipeline'):
         spans = mode.endswith('span')
-        return secondary_pipeline(name, int(mode[len('pipeline'):].replace('span', '')), device, steps, warmup, spans)
-    eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=SPAN_EPB.get(name, 0) if mode == 'span' else 0)
+        return secondary_pipeline(name, int(mode[len('pipeline'):].replace('span', '')), device, steps, warmup, spans, slots)
+    same = mode == 'span-same'
+    run_len = int(mode[4:]) if mode.startswith('span') and mode[4:].isdigit() else 0
+    rmode = 'span' if mode.startswith('span') else ('eager' if mode == 'steady' else mode)
+    epb = (SAME_SLOT_EPB if same else SPAN_EPB).get(name, 0) if rmode == 'span' else 0
+    eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=epb, tune_placement=0)
+    ring = fm.OutputRing(eng, ep) if (not same and rmode != 'graph' and _use_ring(cfg, n, slots, device)) else None
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
     eng.reset()
-    timed = mode if mode != 'graph' else 'eager'   # hipEvents cannot live inside a graph: kernel time from an eager pass
-    for _ in range(max(1, warmup // ep)):
-        eng.rollout(tape, mode=timed)
+
+    def episode(m):
+        if run_len and m == 'span':   # runs of at most run_len steps (fnmarl_step_span splits at the episode end by itself)
+            for off in range(0, ep, run_len):
+                k = min(run_len, ep - off)
+                if ring is not None:
+                    eng.use_outputs(ring.sets[off])
+                eng.step_span(tape[off:off + k], strides=ring.strides if ring is not None else None)
+        else:
+            eng.rollout(tape, mode=m, ring=ring)
+    timed = rmode if rmode != 'graph' else 'eager'   # hipEvents cannot live inside a graph: kernel time from an eager pass
+    for _ in range(max(1, warmup // ep) + pre_steps // ep):
+        episode(timed)
     torch.cuda.synchronize(device)
     eng.profile_enable(steps)
     c0 = eng.launch_counts()
-    if mode == 'graph':
+    if rmode == 'graph':
         for _ in range(2):
             eng.rollout(tape, mode='eager')
         torch.cuda.synchronize(device)
@@ -156,34 +259,43 @@ def secondary_line(name, mode, device, steps=300, warmup=50):
         torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps // ep):
-        eng.rollout(tape, mode=mode)
+        episode(rmode)
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    if mode != 'graph':
+    if rmode != 'graph':
         kernel_ms, c1 = eng.profile_read(), eng.launch_counts()
     k_step = float(np.sum(kernel_ms)) / (c1[0] - c0[0])       # step-kernel time per step (a span launch covers many)
     per_step = launch_bytes(cfg, n * cfg.N, c0, c1)
-    ceil_ms = store_ceiling_ms(eng)
     folded = c1[1] - c0[1] > 0
     kern = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
-    if mode == 'span':
+    if rmode == 'span':
         kern = {'fair_graph_formation': 'formation_span_kernel + formation_kernel<true>'}.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel')
-    out = dict(config=name, mode=mode, workload=spec['workload'] % n,
-               launch={'eager': 'one fmarl_step call per step',
-                       'span': 'fmarl_step_span: one launch per run of steps between episode ends (%d envs per workgroup), the episode-ending '
-                               'step a launch of its own' % eng.envs_per_workgroup,
-                       'graph': 'one hipGraph replay per episode, the staged reset a forked branch of the graph (kernel_avg_ms from an eager pass)'}[mode],
-               value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup, ms_per_step=elapsed / steps * 1e3,
-               kernel=kern, kernel_avg_ms=k_step, kernel_launches=len(kernel_ms), frac=per_step / (k_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-               algorithmic_bytes_per_step=per_step, store_ceiling_ms=ceil_ms,
-               frac_of_box_ceiling=(ceil_ms / k_step if ceil_ms else None))
+    span_text = 'fmarl_step_span: one launch per run of steps between episode ends%s (%d envs per workgroup), the episode-ending step a launch of its own' \
+                % (' and at most %d steps' % run_len if run_len else '', eng.envs_per_workgroup)
+    steps_per_launch = (c1[0] - c0[0]) / max(1, len(kernel_ms))
+    epw = eng.envs_per_workgroup
+    ring_bytes = ring.nbytes if ring is not None else 0
     eng.close()
-    del eng, tape
+    del eng, tape, ring
     torch.cuda.empty_cache()
+    ceil = store_ceiling(device, per_step, steps_per_launch if rmode == 'span' else 1)
+    out = dict(config=name, mode=mode, workload=spec['workload'] % n,
+               launch={'eager': 'one fmarl_step call per step', 'span': span_text,
+                       'graph': 'one hipGraph replay per episode, the staged reset a forked branch of the graph (kernel_avg_ms from an eager pass)'}[rmode],
+               slots=('every step its own time slot of an episode-long ring (%.1f GB)' % (ring_bytes / 1e9) if ring_bytes
+                      else 'one output set, rewritten every step'),
+               value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup + pre_steps // ep * ep, ms_per_step=elapsed / steps * 1e3,
+               kernel=kern, kernel_avg_ms=k_step, kernel_launches=len(kernel_ms), envs_per_workgroup=epw,
+               frac=per_step / (k_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               algorithmic_bytes_per_step=per_step, store_ceiling_ms=ceil['ms_per_step'] if ceil else None,
+               store_ceiling_shape=ceil['shape'] if ceil else None,
+               frac_of_box_ceiling=(ceil['ms_per_step'] / k_step if ceil else None))
+    if mode == 'steady':
+        out['regime'] = 'min_dist_thresh %.2f, %d untimed steps first: episodes end env by env at all phases' % (STEADY['min_dist_thresh'], pre_steps)
     return out
 
 
-def secondary_pipeline(name, k, device, steps, warmup, spans=False):
+def secondary_pipeline(name, k, device, steps, warmup, spans=False, slots='ring'):
     """The same envs as k sub-batches on k streams (fair_marl_amd.PipelinedRollout; bit-identical results): the tail of one
     sub-batch's launch overlaps the head of another's.  What a random-action rollout -- actions known ahead -- or an
     alternating sampler gets out of the chip for the compute-heavy scenarios; with ``spans`` every sub-batch runs its steps as
@@ -193,6 +305,7 @@ def secondary_pipeline(name, k, device, steps, warmup, spans=False):
     cfg = fm.EnvConfig(**spec['env'])
     n, ep = spec['n_envs'], cfg.episode_length
     pipe = fm.PipelinedRollout(cfg, n, k=k, device=device, seed=1, tune_placement=0)
+    rings = pipe.new_rings(ep) if _use_ring(cfg, n, slots, device) else None
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
@@ -200,7 +313,7 @@ def secondary_pipeline(name, k, device, steps, warmup, spans=False):
     mode = 'span' if spans else 'eager'
     pipe.reset()
     for _ in range(max(1, warmup // ep)):
-        pipe.rollout(tapes, mode=mode)
+        pipe.rollout(tapes, mode=mode, rings=rings)
     pipe.synchronize()
     torch.cuda.synchronize(device)
     for e in pipe.engines:
@@ -208,7 +321,7 @@ def secondary_pipeline(name, k, device, steps, warmup, spans=False):
     c0 = [e.launch_counts() for e in pipe.engines]
     t0 = time.perf_counter()
     for _ in range(steps // ep):
-        pipe.rollout(tapes, mode=mode)
+        pipe.rollout(tapes, mode=mode, rings=rings)
     pipe.synchronize()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
@@ -219,13 +332,14 @@ def secondary_pipeline(name, k, device, steps, warmup, spans=False):
     out = dict(config=name, mode='pipeline%d%s' % (k, 'span' if spans else ''), workload=spec['workload'] % n,
                launch='%d sub-batches of %d envs on their own streams, each %s' % (k, n // k, 'running its steps as spans (fmarl_step_span)'
                                                                                    if spans else 'one fmarl_step call per step'),
+               slots=('every step its own time slot of an episode-long ring per sub-batch' if rings is not None else 'one output set per sub-batch, rewritten every step'),
                value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup,
                ms_per_step=elapsed / steps * 1e3, kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel' if spans else 'step_kernel / step_end_kernel'),
                kernel_avg_ms=float(np.sum(kernel_ms)) / sum(b[0] - a[0] for a, b in zip(c0, c1)), kernel_launches=len(kernel_ms), frac=job / HBM_PEAK_GBS,
                frac_basis='whole job: algorithmic bytes per step of all envs / time per step (kernel_avg_ms: a sub-batch\'s step kernels per step, while others run)',
                algorithmic_bytes_per_step=per_step_sub * k, store_ceiling_ms=None, frac_of_box_ceiling=None)
     pipe.close()
-    del pipe, tape, tapes
+    del pipe, tape, tapes, rings
     torch.cuda.empty_cache()
     return out
 
@@ -278,6 +392,20 @@ def cpu_baseline(env_kw, n_envs, episodes, workers):
                        'slowest worker %.1f s, %.1f s wall incl. process start' % (workers, n_envs, ep, units, busy, wall))
 
 
+def launch_plan(launch, pipeline, scenario_name, gather, span_steps, episode_length):
+    """(launch mode, most steps per span launch) of a run.  The launch mode never depends on the number of GPUs: spans wherever the
+    scenario has a span kernel (nav_fairassign_fairrew_formation_graph steps: its span is a loop of steps anyway).  What the exchange
+    changes is the LENGTH of a run: a run's records can only leave when its launch has ended, so with a gather the runs are
+    GATHER_SPAN_STEPS long -- the gather of one run crosses xGMI while the next one computes, and only the last run's gather of
+    a timed region is exposed -- instead of reaching to the episode end."""
+    if pipeline > 1:
+        launch = 'step'
+    if launch == 'auto':
+        launch = 'step' if scenario_name == 'nav_fairassign_fairrew_formation_graph' else 'span'
+    steps = span_steps if span_steps > 0 else (GATHER_SPAN_STEPS if gather else episode_length)
+    return launch, max(1, min(steps, episode_length))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -286,25 +414,31 @@ def main():
     ap.add_argument('--config', default='cfg3', choices=sorted(CONFIGS))
     ap.add_argument('--n-envs', type=int, default=0, help='envs per GPU (default: the config\'s)')
     ap.add_argument('--launch', default='auto', choices=['auto', 'span', 'step', 'graph'],
-                    help='how the K steps are enqueued.  span: fmarl_step_span -- the steps between episode ends as ONE launch in which '
+                    help='how the K steps are enqueued.  span: fmarl_step_span -- runs of steps as ONE launch in which '
                          'every workgroup walks its own envs through time, the episode-ending step a launch of its own (actions '
                          'come from a tape: BASELINE\'s random-action rollout); step: one fmarl_step call per step (what a policy in '
-                         'the loop gets); graph: one hipGraph replay per episode (N=1).  auto = span for N = 1 (except for '
-                         'nav_fairassign_fairrew_formation_graph: its span is a loop of steps anyway) and for N > 1 from four episodes of timed '
-                         'steps on, step for shorter N > 1 runs (a step\'s gather hides behind the next step; a run\'s gather can only '
-                         'start when its launch has ended and the last one is exposed)')
+                         'the loop gets); graph: one hipGraph replay per episode (N=1).  auto = span for every N (the same launch '
+                         'mode whatever the number of GPUs), except for nav_fairassign_fairrew_formation_graph (its span is a loop of '
+                         'steps anyway)')
+    ap.add_argument('--span-steps', type=int, default=0, help='most steps per span launch (0 = auto: up to the episode end for N = 1; '
+                    '%d when the records of a run are gathered to a learner rank -- a run\'s records can only leave when its launch has '
+                    'ended, and the last run\'s gather of the timed region is exposed)' % GATHER_SPAN_STEPS)
+    ap.add_argument('--slots', default='ring', choices=['ring', 'same'],
+                    help='ring: every step writes its own time slot of an episode-long ring of (T, n, ...) arrays (the trajectory exists '
+                         'afterwards; every byte is written once per pass); same: every step overwrites ONE output set (round 3\'s mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gather', action='store_true', help='multi-GPU: skip the RCCL trajectory gather')
+    ap.add_argument('--no-scaling-base', action='store_true', help='N > 1: skip the untimed-exchange pass that measures scaling_base')
     ap.add_argument('--record-path', action='store_true', help='N=1: write the step records / episode records as the '
                     'multi-GPU run does (the gather itself is a no-op with one rank)')
     ap.add_argument('--sync-reset', action='store_true', help='do not stage the next episode on a side stream')
-    ap.add_argument('--no-tune-placement', action='store_true', help='keep the first allocation of node_obs / adj instead of '
-                    'the fastest pair of a few (RolloutEngine tune_placement)')
+    ap.add_argument('--tune-placement', action='store_true', help='--slots same only: keep the fastest (node_obs, adj) allocation pair of a few '
+                    '(RolloutEngine tune_placement) instead of the first allocations')
     ap.add_argument('--graph', action='store_true', help='same as --launch graph')
     ap.add_argument('--eager', action='store_true', help='same as --launch step')
     ap.add_argument('--pipeline', type=int, default=1, help='step the env batch as this many sub-batches on their own streams '
                     '(fair_marl_amd.PipelinedRollout: the tail of one sub-batch\'s step kernel overlaps the head of the next one\'s); '
-                    'one fmarl_step call per sub-batch and step, no trajectory gather in this mode')
+                    'one fmarl_step call per sub-batch and step, one output set per sub-batch, no trajectory gather in this mode')
     ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
                     'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
     ap.add_argument('--no-secondary', action='store_true', help='N=1: skip the other BASELINE configs after the headline region')
@@ -370,22 +504,20 @@ def main():
     ep = cfg.episode_length
     workload = spec['workload'] % n_envs
     fnav_sc = cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph'
-    launch = 'graph' if args.graph else ('step' if args.eager else args.launch)
-    if args.pipeline > 1:
-        launch = 'step'
-    if launch == 'auto':
-        # N = 1: spans.  N > 1, short timed regions: one launch and one gather per step -- a run's records can only leave when
-        # its launch has ended, so the gather of the LAST run of the region is exposed in full (19 steps x 69 MB x 7 peers into
-        # rank 0 behind a 27 ms region at cfg 3), where a step's gather hides behind the next step; from four episodes of timed
-        # steps on the spans win again
-        launch = 'step' if (fnav_sc or (world > 1 and K < 4 * ep)) else 'span'
+    gather = (world > 1 or args.record_path) and not args.no_gather
+    launch, span_steps = launch_plan('graph' if args.graph else ('step' if args.eager else args.launch), args.pipeline, cfg.scenario_name,
+                                     gather, args.span_steps, ep)
     if launch == 'graph':
         if world > 1:
             raise SystemExit('bench.py: --launch graph is a single-GPU mode')
         K, W = max(ep, K // ep * ep), (W + ep - 1) // ep * ep   # whole episodes
-    gather = (world > 1 or args.record_path) and not args.no_gather
     pipe = None
-    epb_hint = SPAN_EPB.get(args.config, 0) if launch == 'span' and not args.n_envs else 0
+    slots = args.slots if (args.pipeline <= 1 and launch != 'graph') else 'same'   # (graph replays and sub-batch engines write one output set)
+    if slots == 'ring' and not _use_ring(cfg, n_envs, 'ring', device):
+        print('bench.py: an episode-long ring of time slots does not fit this GPU\'s free memory: every step overwrites one output set (--slots same)',
+              file=sys.stderr)
+        slots = 'same'
+    epb_hint = ((SAME_SLOT_EPB if slots == 'same' else SPAN_EPB).get(args.config, 0)) if launch == 'span' and not args.n_envs else 0
     if args.pipeline > 1:
         if args.rccl_selftest:
             raise SystemExit('bench.py: --pipeline does not combine with --rccl-selftest')
@@ -397,8 +529,9 @@ def main():
         eng = pipe.engines[0]
     else:
         eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
-                               tune_placement=0 if args.no_tune_placement else None, emit_graph_record=gather,
+                               tune_placement=(None if args.tune_placement and slots == 'same' else 0), emit_graph_record=gather,
                                envs_per_workgroup=epb_hint)
+    ring = fm.OutputRing(eng, ep) if slots == 'ring' else None   # step t writes slot t mod episode_length
     depth = 2
     # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for the two
     # formation scenarios, a per-step record of the step's scenario state (RolloutEngine.step_record_words)
@@ -406,7 +539,7 @@ def main():
     graph_words = eng.step_record_words if eng.emit_graph_record else 0
     tg = sg = None
     if gather and launch == 'span':   # the records of a whole run of steps travel in one collective (SURVEY section 8 e)
-        sg = tg = SpanGather(ep, n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
+        sg = tg = SpanGather(min(ep, span_steps), n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
                              episode_words=eng.episode_record_words if episodes else 0, graph_words=graph_words, timing=True)
     elif gather:
         tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
@@ -421,10 +554,17 @@ def main():
             rebuild_ranks = peers[:max(1, min(args.learner_rebuild, world))]
             lr_node = torch.empty(n_envs, cfg.N, cfg.E, cfg.node_feat, dtype=torch.float32, device=device)
             lr_adj = torch.empty(n_envs, cfg.E, cfg.E, dtype=torch.float32, device=device)
-    if gather and sg is None:
-        sets = [eng.new_output_set(obs=r.obs, reward=r.reward, done=r.done, graph_record=r.graph) for r in tg.records]
-    else:
-        sets = [eng.outs]
+    # Output sets.  The compact record of a step (obs, reward, done, + the graph record) goes into the exchange's buffers when
+    # there is one; node_obs / adj / info go to the step's time slot (ring) or to the engine's one set of them (same).
+    set_cache = {}
+
+    def record_set(key, slot, obs, rew, done, graph):
+        if (key, slot) not in set_cache:
+            kw = {}
+            if ring is not None:
+                kw = dict(node_obs=ring.node_obs[slot], adj_env=ring.adj_env[slot], info_planes=ring.info_planes[slot] if ring.info_planes is not None else None)
+            set_cache[(key, slot)] = eng.new_output_set(obs=obs, reward=rew, done=done, graph_record=graph if eng.emit_graph_record else None, **kw)
+        return set_cache[(key, slot)]
 
     # synthetic action tape: int32 U{0..4} per (step, env, agent), resident in HBM before timing; one episode long (step t
     # reads entry t mod episode_length: a span's steps are consecutive entries)
@@ -436,6 +576,8 @@ def main():
     inject_error = bool(os.environ.get('FMARL_BENCH_INJECT_GATHER_ERROR'))   # test hook: tests/test_hip_parity.py
     chunk = [0]          # runs of steps enqueued so far (span mode)
     chunk_ended = {}     # run index -> its last step ended an episode
+    exchange = [True]    # False during the scaling_base pass: same launches, same record writes, nothing submitted
+    submits = [0]        # records handed to the exchange so far
 
     def rebuild(obs_r, epi_r, graph_r):
         eng.rebuild_graph(obs_r, epi_r, node_obs=lr_node, adj_env=lr_adj, step_record=graph_r if eng.emit_graph_record else None)
@@ -447,13 +589,16 @@ def main():
             return
         for t in range(first, first + count):
             if gather:
-                tg.record(t)
-                eng.use_outputs(sets[t % depth])
+                r = tg.record(t)
+                eng.use_outputs(record_set(t % depth, t % ep if ring is not None else 0, r.obs, r.reward, r.done, r.graph))
+            elif ring is not None:
+                eng.use_outputs(ring.sets[t % ep])
             eng.step(tape[t % tape_len], auto_reset=True)
-            if gather:
-                if inject_error and t == 1 and rank == world - 1:
+            if gather and exchange[0]:
+                if inject_error and submits[0] == 1 and rank == world - 1:
                     raise RuntimeError('injected gather error (FMARL_BENCH_INJECT_GATHER_ERROR)')
                 tg.submit(t)
+                submits[0] += 1
                 if rebuild_ranks and t > first:
                     # step t - 1 has arrived (or is awaited here) while step t is in flight; its episode record is the latest
                     # one submitted -- this step's, if it started an episode, goes out below
@@ -470,22 +615,29 @@ def main():
         if gather:
             tg.finish()
 
-    def run_spans(first, count):   # fmarl_step_span: runs of steps that end at an episode end (or at the end of the region)
+    def run_spans(first, count):   # fmarl_step_span: runs of steps that end at an episode end, after span_steps steps or with the region
         t, end = first, first + count
         while t < end:
             off = t % ep
-            k = min(ep - off, end - t)
+            k = min(ep - off, end - t, span_steps)
             c = chunk[0]
             strides = None
             if gather:
                 rec = sg.span_record(c)          # waits for the gather that last used this buffer (run c - depth)
-                eng.use_outputs(sg.output_set(eng, c))
-                strides = rec.strides
+                obs0, rew0, done0, graph0 = rec.first_step_buffers()
+                eng.use_outputs(record_set(c % depth, off if ring is not None else 0, obs0, rew0, done0, graph0))
+                strides = dict(rec.strides)
+                if ring is not None:
+                    strides.update(node_obs=ring.strides['node_obs'], adj=ring.strides['adj'], info=ring.strides['info'])
+            elif ring is not None:
+                eng.use_outputs(ring.sets[off])
+                strides = ring.strides
             eng.step_span(tape[off:off + k], strides=strides)
-            if gather:
-                if inject_error and c == 1 and rank == world - 1:
+            if gather and exchange[0]:
+                if inject_error and submits[0] == 1 and rank == world - 1:
                     raise RuntimeError('injected gather error (FMARL_BENCH_INJECT_GATHER_ERROR)')
                 sg.submit_span(c, k)
+                submits[0] += 1
                 chunk_ended[c] = bool(eng.episode_started)
                 if rebuild_ranks and c - 1 in chunk_ended:
                     # run c - 1 has arrived (or is awaited here) while run c is in flight.  Its steps belong to the episode whose
@@ -497,7 +649,7 @@ def main():
                     ea.record()
                     steps = got[0][0].shape[0]
                     for j in range(steps):
-                        epi = epi_new if j == steps - 1 else epi_old
+                        epi = epi_new if (j == steps - 1 and chunk_ended[c - 1]) else epi_old
                         for r in rebuild_ranks:
                             rebuild(got[r][0][j], epi[r], got[r][3][j] if got[r][3] is not None else None)
                     eb.record()
@@ -541,6 +693,30 @@ def main():
         # A trajectory exchange that cannot run is a FAILED multi-GPU measurement, never a number without the exchange.
         print('bench.py: rank %d: rollout / trajectory gather failed: %s' % (rank, exc), file=sys.stderr, flush=True)
         sys.exit(1)
+    # N > 1: the base the scaling is measured against -- the SAME K steps in the same launch mode with the same record writes, only
+    # nothing is handed to the exchange: what every GPU does when it is alone.  Then untimed steps up to the same episode phase.
+    first = W
+    base_elapsed = None
+    if world > 1 and gather and launch != 'graph' and not args.no_scaling_base:
+        exchange[0] = False
+        dist.barrier()
+        torch.cuda.synchronize(device)
+        tb = time.perf_counter()
+        run(first, K)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        tb1 = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
+        dist.all_reduce(tb1, op=dist.ReduceOp.MAX)
+        base_elapsed = float(tb1.item())
+        first += K
+        pad = (-K) % ep
+        run(first, pad)
+        first += pad
+        exchange[0] = True
+        if episodes:   # the episode that is under way now: its record (the pass above submitted none)
+            eng.pack_episode(out=tg.episode_record())
+            tg.submit_episode()
+        torch.cuda.synchronize(device)
     if launch != 'graph':
         for e in (pipe.engines if pipe is not None else [eng]):
             e.profile_enable(K)
@@ -555,7 +731,7 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     try:
-        run(W, K)
+        run(first, K)
     except RuntimeError as exc:
         print('bench.py: rank %d: rollout / trajectory gather failed: %s' % (rank, exc), file=sys.stderr, flush=True)
         sys.exit(1)
@@ -591,7 +767,7 @@ def main():
                 got = sg.gathered_span(chunk[0] - 1)
                 bad = len(got) != world or any(tuple(o.shape[1:]) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _, _ in got)
             else:
-                got = tg.gathered(W + K - 1)
+                got = tg.gathered(first + K - 1)
                 bad = len(got) != world or any(tuple(o.shape) != (n_envs, cfg.N, cfg.obs_dim) for o, _, _ in got)
             if bad:
                 print('bench.py: gathered record has the wrong shape', file=sys.stderr, flush=True)
@@ -611,7 +787,7 @@ def main():
         # reset launches emits nothing itself (state + reward bytes only); with the staged reset of navigation_graph the launch
         # that ends an episode also commits the next one and emits its first observation (step_end_kernel), so every launch
         # writes the full outputs.  Which of the two happened is read from the library's launch counters, not assumed.
-        resets = sum(1 for t in range(W, W + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
+        resets = sum(1 for t in range(first, first + K) if (t + 1) % ep == 0)   # (fairnav episodes may also end earlier, env by env)
         ca, cb = counts_eager if launch == 'graph' else (counts0, counts1)
         sub = max(1, args.pipeline)
         if pipe is not None:
@@ -621,11 +797,13 @@ def main():
         folded = cb[1] - ca[1]
         kernel_ms, kernel_steps = np.asarray(kernel_ms, dtype=np.float64), np.asarray(kernel_steps, dtype=np.float64)
         span_launches = kernel_steps > 1
+        bytes_moved = None
         if launch == 'span' and span_launches.any():
             # the dominant kernel is the span kernel: a launch covers a run of steps, all of which emit
             k_avg_ms = float(kernel_ms[span_launches].mean())
             steps_per_launch = float(kernel_steps[span_launches].mean())
             bytes_per_launch = agents * algorithmic_bytes(cfg) * steps_per_launch
+            bytes_moved = moved_bytes(cfg, agents, steps_per_launch)
             kernel_name = 'formation_span_kernel' if cfg.scenario_name == 'fair_graph_formation' else 'step_span_kernel'
         else:
             k_avg_ms = float(kernel_ms.mean()) if kernel_ms.size else float('nan')
@@ -634,25 +812,36 @@ def main():
             kernel_name = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
         traffic = None
+        tkey = '%s/%s%s' % (args.config, launch, '-ring' if slots == 'ring' else '')
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(tpath) and pipe is None:   # (the committed counters are per STEP over all envs of the profiled run)
             with open(tpath) as f:
-                entry = json.load(f).get('%s/%s' % (args.config, launch), {})
+                entry = json.load(f).get(tkey, {})
             if entry.get('n_envs') == n_envs and entry.get('hbm_bytes_per_step'):
                 traffic = entry['hbm_bytes_per_step'] * steps_per_launch
-        ceiling_ms = store_ceiling_ms(eng) if pipe is None else None
+        step_k_ms = float(kernel_ms.sum() / max(1.0, kernel_steps.sum()))   # all step launches of the region / its steps
+        emis_ms = emission_only_ms(eng) if pipe is None else None
         launch_text = {
-            'span': 'fmarl_step_span: the steps between episode ends as ONE launch in which every workgroup walks its own envs through '
+            'span': 'fmarl_step_span: runs of steps (up to the episode end%s) as ONE launch each in which every workgroup walks its own envs through '
                     'time (%d envs per workgroup; state in registers, static entities in LDS between the steps), the step that ends an episode '
                     'as a launch of its own: %d launches for the %d timed steps'
-                    % (eng.envs_per_workgroup, len(kernel_ms), K),
+                    % ('' if span_steps >= ep else ', at most %d steps' % span_steps, eng.envs_per_workgroup, len(kernel_ms), K),
             'step': ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
                      % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step'),
             'graph': 'one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed region)' % ep}[launch]
         if gather and sg is not None:
-            exchange_text = 'one gather per run of steps (<= %d steps: %d B per agent-step, back to back)' % (ep, StepRecord.bytes_per_agent_step(cfg.obs_dim, graph_words))
+            exchange_text = 'one gather per run of steps (<= %d steps: %d B per agent-step, back to back)' % (min(ep, span_steps), StepRecord.bytes_per_agent_step(cfg.obs_dim, graph_words))
         else:
             exchange_text = 'gather of obs/reward/done to rank 0 every step, %d B per agent-step' % StepRecord.bytes_per_agent_step(cfg.obs_dim, graph_words)
+        ring_bytes = ring.nbytes if ring is not None else 0
+        # the box's write ceiling needs room: the engine and the time slots go first (the secondary lines build their own)
+        if pipe is None:
+            eng.close()
+            set_cache.clear()
+            del eng, ring, tape
+            lr_node = lr_adj = None
+            torch.cuda.empty_cache()
+        ceil = store_ceiling(device, bytes_per_step / sub, steps_per_launch) if pipe is None else None
         out = {
             'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), %s random-action rollout' % cfg.scenario_name,
             'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'n_ranks_seen': ranks_seen,
@@ -662,33 +851,41 @@ def main():
             'config': {'workload': workload, 'n_envs_per_gpu': n_envs, 'n_agents': cfg.N,
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
-                       'launch_mode': launch, 'launch': launch_text,
+                       'launch_mode': launch, 'launch': launch_text, 'span_steps': (min(ep, span_steps) if launch == 'span' else None),
+                       'slots': ('ring: every step writes its own time slot of an episode-long ring of (%d, n, ...) arrays (%.1f GB): the trajectory '
+                                 'exists afterwards, every byte is written once per pass' % (ep, ring_bytes / 1e9) if slots == 'ring'
+                                 else 'same: every step overwrites one output set'),
                        'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
                                  else 'next episode staged on a side stream, committed and observed by the launch that ends the episode'
                                       ' (%d of %d episode ends folded)' % (folded, cb[1] - ca[1] + cb[2] - ca[2])),
-                       'output_placement': ('fastest (node_obs, adj) allocation pair of %d x %d, emission-only launch ms %.3f '
-                                            '(first allocations %.3f, slowest pair %.3f)'
-                                            % (len(eng.placement_ms), len(eng.placement_ms[0]), min(map(min, eng.placement_ms)),
-                                               eng.placement_ms[0][0], max(map(max, eng.placement_ms)))
-                                            if eng.placement_ms else 'first allocations'),
                        'exchange': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
                                      else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' ' + exchange_text
                                     + ((' + %d B per env with EVERY step (goals, landmarks, obstacles, walls: this scenario\'s episodes end env by env, '
                                         'so the record is re-packed and gathered whenever an env may have been reset)' if fnav_sc else
                                         ' + %d B per env once per episode (goals, landmarks, obstacles, walls)')
-                                       % (4 * eng.episode_record_words) if episodes else '')) if gather else 'none'},
+                                       % (4 * episode_words_of(cfg)) if episodes else '')) if gather else 'none'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_source': ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier '
-                                            'run of this command, replayed here, not measured in this run') if traffic is not None else None,
+                         'traffic_source': ('profiles/pmc_traffic.json [%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier '
+                                            'run of this command, replayed here, not measured in this run' % tkey) if traffic is not None else None,
                          'kernel': kernel_name,
                          'kernel_avg_ms': k_avg_ms, 'kernel_launches': int(span_launches.sum()) if steps_per_launch > 1 else int(kernel_ms.size),
                          'kernel_steps_per_launch': steps_per_launch,
-                         'step_kernels_ms_per_step': float(kernel_ms.sum() / max(1.0, kernel_steps.sum())),   # all step launches of the region / its steps
-                         # the emission alone (node_obs + adj of every env, no env state) on the same buffers of the same box:
-                         # what one launch of this box's store stream takes; frac_of_box_ceiling = that time / the step kernels' per step
-                         'store_ceiling_ms': ceiling_ms,
-                         'frac_of_box_ceiling': (ceiling_ms / float(kernel_ms.sum() / max(1.0, kernel_steps.sum())) if ceiling_ms else None),
+                         'step_kernels_ms_per_step': step_k_ms,
+                         'slots': slots,
+                         # every step in a slot of its own (each byte written once per launch) / one output set rewritten every step:
+                         # the headline's own figure under its name, the other mode's from the 300-step secondary entry (below)
+                         'frac_distinct_slots': achieved / HBM_PEAK_GBS if slots == 'ring' else None,
+                         'frac_same_slot': achieved / HBM_PEAK_GBS if slots == 'same' else None,
+                         # the formula's bytes with the state and the static entity words counted once per span launch (they stay on the chip)
+                         'bytes_moved_per_launch': bytes_moved,
+                         'frac_bytes_moved': (bytes_moved / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if bytes_moved else None,
+                         # the box's write ceiling: the best pure 16-byte store stream over the byte count of the dominant kernel's
+                         # launch, per step; frac_of_box_ceiling = that / the step kernels' time per step (<= 1 by construction)
+                         'store_ceiling_ms': ceil['ms_per_step'] if ceil else None,
+                         'store_ceiling': ceil,
+                         'frac_of_box_ceiling': (ceil['ms_per_step'] / step_k_ms if ceil else None),
+                         'emission_only_ms': emis_ms,   # one fmarl_rebuild_graph launch on the last step's buffers (rounds 2-3's "ceiling")
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'algorithmic_bytes_per_agent_step': algorithmic_bytes(cfg)},
         }
@@ -713,7 +910,7 @@ def main():
                 'bytes_gathered_per_step': rec_bytes * world, 'bytes_received_by_rank0_per_step': recv_bytes,
                 'rank0_receive_GBps': recv_bytes / (elapsed / K) / 1e9,
                 'collectives': ('one per run of steps (%d in the timed region)' % (chunk[0] - chunk_start) if sg is not None else 'one per step'),
-                'episode_record_bytes_per_rank': 4 * eng.episode_record_words * n_envs if episodes else 0,
+                'episode_record_bytes_per_rank': 4 * episode_words_of(cfg) * n_envs if episodes else 0,
                 'episode_record_gathers_per_step': (1.0 if fnav_sc and sg is None else 1.0 / ep) if episodes else 0.0}
             if rebuild_ranks:
                 torch.cuda.synchronize(device)
@@ -726,24 +923,43 @@ def main():
                     'note': 'rank 0 rebuilds node_obs / adj of these ranks\' gathered steps (fmarl_rebuild_graph) inside the timed loop, '
                             'on the same stream as its own step kernels; the reference ships node_obs / adj instead '
                             '(onpolicy/envs/env_wrappers.py:983-996)'}
+        if base_elapsed is not None:
+            # weak scaling against what the same GPUs do when nothing is exchanged: the same K steps, launch mode, span length and
+            # record writes on every rank, timed the same way (barrier, max over ranks) just before the timed region
+            base = agents * K / base_elapsed
+            out['scaling_base'] = {'value_per_gpu': base, 'unit': 'agent-steps/s', 'ms_per_step': base_elapsed / K * 1e3,
+                                   'efficiency': out['value'] / (world * base),
+                                   'basis': 'the same %d steps in the same launch mode (%s%s, slots %s) with the same record writes and no exchange, '
+                                            'max over the %d ranks; efficiency = value / (n_gpus x value_per_gpu).  The N = 1 line of this '
+                                            'bench carries the same configuration as `secondary` entry (%s, span%d) next to its own headline'
+                                            % (K, launch, ' of at most %d steps' % span_steps if launch == 'span' else '', slots, world,
+                                               args.config, GATHER_SPAN_STEPS)}
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if args.config in REFERENCE_CPU:
             out['reference_cpu'] = REFERENCE_CPU[args.config]
-        if world == 1 and not args.no_secondary and pipe is None and launch == ('step' if fnav_sc else 'span') and not (args.record_path or args.n_envs):
-            eng.close()
-            del eng, tape
-            if sets:
-                sets.clear()
-            torch.cuda.empty_cache()
+        if (world == 1 and not args.no_secondary and pipe is None and launch == ('step' if fnav_sc else 'span') and slots == 'ring'
+                and args.span_steps == 0 and not (args.record_path or args.n_envs)):
             t_sec = time.perf_counter()
-            # first the same config one launch per step (what a policy in the loop gets; the launch mode of rounds 1 and 2)
-            out['secondary'] = [secondary_line(name, mode, device) for name, mode in SECONDARY if not (name == args.config and mode == {'step': 'eager'}.get(launch, launch))]
+            # the headline config again over 300 steps (as spans, one launch per step, in runs of GATHER_SPAN_STEPS, into one output
+            # set), then every other BASELINE config that fits one GPU
+            out['secondary'] = [secondary_line(name, mode, device) for name, mode in SECONDARY]
             out['secondary_wall_s'] = time.perf_counter() - t_sec
+            for e in out['secondary']:   # the other slot mode of the headline config, over 300 steps
+                if e['config'] == args.config and e['mode'] == 'span-same':
+                    out['roofline']['frac_same_slot'] = e['frac']
+                    out['roofline']['same_slot_ms_per_step'] = e['kernel_avg_ms']
+                if e['config'] == args.config and e['mode'] == 'span':
+                    out['roofline']['frac_distinct_slots_300_steps'] = e['frac']
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def episode_words_of(cfg):
+    """32-bit words per env of the episode record (fmarl_episode_record_words: goals + landmarks + obstacles + 6 per wall)."""
+    return 2 * cfg.N + 2 * (cfg.num_landmarks + cfg.num_obstacles) + 6 * cfg.num_walls
 
 
 if __name__ == '__main__':

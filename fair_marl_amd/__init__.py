@@ -7,7 +7,7 @@ fallback: importing works anywhere, but creating an engine without ``libfmarl.so
 GPU raises.
 """
 from .config import EnvConfig  # noqa: F401
-from .engine import RolloutEngine  # noqa: F401
+from .engine import OutputRing, RolloutEngine  # noqa: F401
 from .env_wrappers import (DummyVecEnv, GraphDummyVecEnv, GraphSubprocVecEnv,  # noqa: F401
                            ShareVecEnv, SubprocVecEnv)
 from .MPE_env import GraphMPEEnv, MPEEnv  # noqa: F401

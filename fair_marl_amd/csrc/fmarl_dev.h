@@ -67,6 +67,7 @@ struct Params {
     int n_envs, N, L, O, W, E, D, F;
     int episode_length, has_max_speed, env_offset, scenario;
     int epb;                 // environments per workgroup = kThreads / N
+    int order;               // workgroup b works on env block (b * order) mod gridDim.x (env_block below): 1 = dispatch order
     int epw;                 // formation scenario: environments per wave (every env inside one wave), epb = 4 epw
     int feat_global;   // FMARL_FLAG_GLOBAL_FEATURES: node rows are [vel, pos, goal, type] without the ego part
     int lds_pos, lds_agentf, lds_ego, lds_stat, lds_wall, lds_flag, lds_env_bytes;  // per-env LDS byte offsets
@@ -105,6 +106,16 @@ struct Params {
     int *st_wall_orient, *st_goal_match, *stage_valid, *stage_need;
     int *place_fails, *st_place_fails;   // placements accepted after kMaxTries colliding draws (live / staged episode)
 };
+
+// Which block of p.epb consecutive envs this workgroup works on.  Workgroups are dispatched in index order, so with the identity
+// mapping the ~1 000 workgroups resident at any time write one compact, moving window of the output arrays; HBM takes a store
+// stream 10-20 % faster when the concurrently written regions are scattered over the whole buffer instead (pure 16-byte store
+// streams on MI355X: 5.9-6.8 TB/s in dispatch order, 7.1 TB/s scattered, for every chunk size from 64 KB to 4 MB:
+// tools/store_ceiling.py, profiles/r4_store_ceiling.md).  `order` is coprime with the grid (a permutation; the host picks the
+// odd number nearest 0.618 x grid: scatter_order in libfmarl.hip), results never depend on it.
+__device__ __forceinline__ int env_block(const Params &p) {
+    return p.order > 1 ? (int)(((uint64_t)blockIdx.x * (uint32_t)p.order) % gridDim.x) : (int)blockIdx.x;
+}
 
 // fmarl_step_span: per-step strides (elements) of the outputs and of the action tape.
 struct SpanStrides { long long obs, node_obs, adj, reward, done, info, edge_nnz, graph_record, actions; };

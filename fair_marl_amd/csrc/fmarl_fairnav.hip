@@ -283,7 +283,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
                              const float *action_vec, int auto_reset, bool second, bool flagged_in) {
     FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N, L = p.L;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / N, i = tid - el * N;
     const bool in_range = el < nenv;
@@ -522,7 +522,7 @@ __device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs
     if (!STEP) return;
     if (!__syncthreads_or(ended)) return;   // (every lane of an env agrees; block-uniform)
     const int N = p.N, tid = threadIdx.x;
-    const int env0 = blockIdx.x * p.epb, nenv = min(p.epb, p.n_envs - env0);
+    const int env0 = env_block(p) * p.epb, nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / N, i = tid - el * N;
     if (el < nenv && i == 0) {
         p.reset_flag[env0 + el] = ended ? 1 : 0;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, Fma
                                                                    const uint32_t *step_rec, int n_envs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, N = p.N;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, n_envs - env0);
     const int el = tid / N, i = tid - el * N;
     const int LO = p.L + p.O, words = 2 * N + 2 * LO + 6 * p.W;   // episode_record_words (fmarl_rebuild.hip)

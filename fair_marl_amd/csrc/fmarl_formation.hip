@@ -268,15 +268,21 @@ __device__ __forceinline__ void travelled_stats(const double *pd, const double *
     sd = sqrt_pos(q / n);
 }
 
+// What one agent's thread carries from one step of a span to the next (formation_span_kernel): everything a step reads at its
+// head.  `carry` bit 0 = this step's state arrives here (left by the previous step of the span; the static entities are still in
+// the envs' LDS tables) -- nothing is loaded but the action; bit 1 = the new state stays here instead of going to global memory.
+struct FormCarry { double2 x, v, so; double pd, vd, Dg, Tr; int noc, nac, step; bool socc, fdone; };   // (constants -- rot, min_time -- are re-read: cached loads)
+
 // STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877)
 // STEP = false: observation of freshly reset envs (MultiAgentGraphEnv.reset, environment.py:892-897)
 template <bool STEP>
 __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
-                                               const float *action_vec, int auto_reset, const bool tables_loaded = false) {
+                                               const float *action_vec, int auto_reset, FormCarry &c, const int carry) {
+    const bool tables_loaded = (carry & 5) != 0;   // (bit 2: the tables only -- the measure builds' span without the register carry)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     // Every env lives inside ONE wave (p.epw = 64 / N envs per wave, p.epb = 4 p.epw): after the shared entity tables are
     // loaded no wave ever waits for another one -- all the ordering between the phases below is wave-local
@@ -303,7 +309,15 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     double Dg_old = 0, Tr_old = 0, fdone = 0, socc = 0, mtime = 0, vd = 0;
     double2 so = make_double2(0, 0), rot = make_double2(1, 0);
     int noc_old = 0, nac_old = 0, a_pre = -1, cs = 0, rf = 0;
-    if (active) {
+    if (STEP && (carry & 1)) {
+        x = c.x; v = c.v; pd = c.pd; so = c.so; vd = c.vd; socc = c.socc ? 1.0 : 0.0; cs = c.step;
+        Dg_old = c.Dg; Tr_old = c.Tr; fdone = c.fdone ? 1.0 : 0.0; noc_old = c.noc; nac_old = c.nac;
+        if (active) {
+            rot = p.rot_table[i];
+            if (o.info) mtime = p.min_time[g];
+            if (action_idx) a_pre = action_idx[g];
+        }
+    } else if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g];
         so = p.slot_pos[g];
         if (STEP) rot = p.rot_table[i];
@@ -509,7 +523,11 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             ob[0] = (float)(v.x + flag); ob[1] = (float)(v.y + flag); ob[2] = (float)(x.x + flag); ob[3] = (float)(x.y + flag);
             ob[4] = (float)(goal.x - x.x + flag); ob[5] = (float)(goal.y - x.y + flag);
         }
-        if (STEP || emit) {
+        const bool keep = STEP && (carry & 2) != 0;   // a span's inner step: the new state stays in registers
+        if (keep) {
+            c.socc = ((t.words()[2] >> i) & 1u) != 0;
+            c.vd = t.theta()[i];
+        } else if (STEP || emit) {
             p.slot_occ[g] = (double)((t.words()[2] >> i) & 1u);
             p.match_dual[g] = t.theta()[i];   // column potentials of the matching on the current slots: next step's warm start
         }
@@ -548,11 +566,16 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
 
             FMARL_TICK(8);   // statistics, hits, reward
             const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
-            p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
-            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left;
-            p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
-            p.slot_pos[g] = t.slot_new()[i]; p.slot_delta[g] = delta; p.formation_done[g] = fdone;
-            if (i == 0) p.cur_step[env] = step;
+            if (keep) {
+                c.x = x; c.v = v; c.pd = pd; c.Dg = Dg_new; c.Tr = Tr_new; c.noc = noc; c.nac = nac;
+                c.so = t.slot_new()[i]; c.fdone = fdone != 0.0; c.step = step;
+            } else {
+                p.agent_pos[g] = x; p.agent_vel[g] = v; p.p_dist[g] = pd;
+                p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left;
+                p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
+                p.slot_pos[g] = t.slot_new()[i]; p.slot_delta[g] = delta; p.formation_done[g] = fdone;
+                if (i == 0) p.cur_step[env] = step;
+            }
             if (o.reward) o.reward[g] = (float)rew;
             if (o.done) o.done[g] = step >= p.episode_length;
             FMARL_TICK(9);   // state stores
@@ -594,20 +617,32 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
 template <bool STEP>
 __global__ __launch_bounds__(kThreads, FMARL_FORM_MIN_BLOCKS) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                              const float *action_vec, int auto_reset) {
-    formation_body<STEP>(p, o, action_idx, action_vec, auto_reset);
+    FormCarry c;
+    formation_body<STEP>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
 // fmarl_step_span for fair_graph_formation: T steps of the workgroup's own envs in one launch (no episode ends inside).
-__global__ __launch_bounds__(kThreads, 4) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx,
+// Between the steps the agent's state stays in registers (FormCarry) and the static entities in the LDS tables: only the first
+// step loads the state, only the last one stores it; every env lives inside one wave, so wave-local ordering is all the steps
+// need (the next step's first LDS writes come behind this step's last reads of the emission window, in the wave's own order).
+#ifndef FMARL_FORM_SPAN_BLOCKS
+#define FMARL_FORM_SPAN_BLOCKS 4
+#endif
+__global__ __launch_bounds__(kThreads, FMARL_FORM_SPAN_BLOCKS) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx,
                                                                      const float *action_vec, int T) {
+    FormCarry c = {};
     for (int t = 0; t < T; ++t) {
         const Params &q = span_params_reloaded();   // == p
         const FmarlOutputs ot = span_outputs(o, s, t);
+#ifdef FMARL_FORM_NO_CARRY   // (A/B builds: the state through global memory every step, as before round 4)
         formation_body<true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr,
-                             action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0, t > 0);
-        // a wave re-reads from global memory only what it wrote itself (every env inside one wave): its own stores complete,
-        // no workgroup barrier
+                             action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0, c, t > 0 ? 4 : 0);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#else
+        formation_body<true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr,
+                             action_vec ? action_vec + (size_t)t * s.actions : nullptr, 0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));
+        wave_sync();
+#endif
     }
 }
 
@@ -619,7 +654,7 @@ __global__ __launch_bounds__(kThreads) void formation_rebuild_kernel(Params p, F
                                                                      const uint32_t *step_rec, int n_envs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, N = p.N;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, n_envs - env0);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int elw = lane / N, i = lane - elw * N;

@@ -254,6 +254,35 @@ __global__ __launch_bounds__(256) void info_mean_kernel(const float *info, doubl
     if (threadIdx.x == 0) out[blockIdx.x] = part[0] / n_envs;
 }
 
+// Measurement aid (fmarl_store_stream): pure 16-byte store streams over `n16` 16-byte words -- what the box's HBM takes when a kernel
+// does nothing but write.  The step kernels' output stream cannot beat the best of these on the same byte count (bench.py
+// `store_ceiling_ms`).  Shapes: 0 = flat grid-stride stream (consecutive workgroups write consecutive 4 KiB, 2 048 workgroups);
+// 1 = a workgroup streams a contiguous chunk of `chunk16` words front to back, 4 KiB per instruction round (the shape of the
+// adj emission); 2 = every WAVE streams its own contiguous quarter of the workgroup's chunk, 1 KiB per store instruction (the
+// shape of the node_obs emission: a wave owns an env's rows).  Workgroup b takes chunk (b * order) mod n_chunks, then -- `persist`
+// workgroups that live for the whole launch, as a span's do -- chunk ((b + k grid) * order) mod n_chunks for k = 1, 2, ...: order 1
+// is dispatch order (the resident workgroups write one compact window), a large odd order scatters them over the buffer.
+// The value depends on the address, so no two stores are equal.
+template <int SHAPE>
+__global__ __launch_bounds__(256) void store_stream_kernel(float4 *dst, size_t n16, uint32_t chunk16, uint32_t n_chunks, uint32_t order) {
+    if (SHAPE == 0) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+            dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+        return;
+    }
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const uint32_t chunk = (uint32_t)(((uint64_t)c * order) % n_chunks);
+        const size_t b0 = (size_t)chunk * chunk16, be = b0 + chunk16 < n16 ? b0 + chunk16 : n16;
+        if (SHAPE == 1) {
+            for (size_t i = b0 + threadIdx.x; i < be; i += 256) dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+        } else {
+            const uint32_t per_wave = (chunk16 + 3) / 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const size_t b = b0 + (size_t)wave * per_wave, e = b + per_wave < be ? b + per_wave : be;
+            for (size_t i = b + lane; i < e; i += 64) dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+        }
+    }
+}
+
 // test hook (fmarl_poison_lds): every workgroup writes 0xFF bytes over all the LDS it was given
 __global__ __launch_bounds__(256) void poison_lds_kernel(int words) {
     extern __shared__ __attribute__((aligned(16))) char lds[];

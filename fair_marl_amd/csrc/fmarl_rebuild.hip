@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kThreads) void rebuild_graph_kernel(Params p, Fmarl
                                                                  const uint32_t *rec, int n_envs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, n_envs - env0);
     const int LO = p.L + p.O, words = episode_record_words(p.N, p.L, p.O, p.W);
     const int el = tid / p.N, i = tid - el * p.N;

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
 // One thread per (env, agent), same workgroup shape as the step kernel.
 __global__ __launch_bounds__(kThreads) void reset_commit_kernel(Params p, int mode, const uint8_t *mask) {
     const int tid = threadIdx.x, N = p.N;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / N, i = tid - el * N;
     const bool active = el < nenv;
@@ -251,7 +251,7 @@ __global__ void stage_finish_kernel(Params p) {
 __global__ __launch_bounds__(kThreads) void reset_emit_kernel(Params p, FmarlOutputs o) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / p.N, i = tid - el * p.N;
     const bool active = el < nenv;

@@ -569,7 +569,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
                                           int auto_reset, StepCarry &c, const int carry) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
-    const int env0 = blockIdx.x * p.epb;
+    const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / p.N, i = tid - el * p.N;
     const bool active = el < nenv;

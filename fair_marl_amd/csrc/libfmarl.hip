@@ -159,6 +159,25 @@ struct DeviceGuard {
 
 int align16(int x) { return (x + 15) / 16 * 16; }
 
+// Params.order for a launch of `grid` workgroups (fmarl_dev.h env_block): the odd number nearest the golden section of the grid
+// that is coprime with it -- consecutive workgroups then work on env blocks far apart, and the blocks of any run of
+// consecutive workgroups are spread evenly over the batch.  Small grids keep dispatch order (nothing to scatter).
+int scatter_order(int grid) {
+    if (grid < 64) return 1;
+#ifdef FMARL_NO_SCATTER   // (A/B builds: tools/mkvariant.sh noscatter -DFMARL_NO_SCATTER)
+    return 1;
+#endif
+#ifdef FMARL_MEASURE
+    if (const char *e = getenv("FMARL_ORDER")) { const int v = atoi(e); if (v == 1) return 1; }
+#endif
+    int o = (int)(grid * 0.6180339887498949) | 1;
+    for (;; o += 2) {
+        int a = grid, b = o % grid;
+        while (b) { const int r = a % b; a = b; b = r; }
+        if (a == 1) return o;
+    }
+}
+
 Params bind(const Handle *h, void *state) {
     Params p = h->base;
     char *s = (char *)state;
@@ -441,6 +460,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (const char *pad = getenv("FMARL_LDS_PAD")) h->lds_bytes += atoi(pad);   // lower occupancy
 #endif
     h->grid = (p.n_envs + epb - 1) / epb;
+    // navigation_graph's launches are store streams: scattered env blocks (cfg 3 one launch per step 1.525 -> 1.475 ms, 10 agents
+    // 0.243 -> 0.216 ms on one box, spans into time slots unchanged: profiles/r4_scatter_ab.md).  The two formation scenarios'
+    // launches are bound by their dependent chains and measured 1-2 % slower scattered: dispatch order.
+    p.order = (form || fnav) ? 1 : scatter_order(h->grid);
     const uint64_t NEF = (uint64_t)p.N * p.E * p.F, maxq = (uint64_t)epb * NEF;
     if (maxq >= (1ull << 24) || maxq * NEF >= (1ull << 40)) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large"); }
     p.dNEF.set((uint32_t)NEF); p.dEF.set(p.E * p.F); p.dF.set(p.F); p.dEE.set(p.E * p.E); p.dE.set(p.E); p.dNE.set(p.N * p.E);
@@ -800,6 +823,29 @@ int fmarl_poison_lds(void *handle, void *stream) {
     return FMARL_OK;
 }
 
+int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, int order, int persist, void *stream) {
+    if (!dst || ((uintptr_t)dst & 15) || (bytes & 15) || shape < 0 || shape > 2 || order < 1 || persist < 0)
+        return fail(FMARL_EINVAL, "fmarl_store_stream: dst / bytes must be 16-byte multiples, shape 0..2, order >= 1, persist >= 0");
+    if (shape != 0 && (chunk_bytes < 4096 || (chunk_bytes & 15) || chunk_bytes > ((size_t)1 << 34)))
+        return fail(FMARL_EINVAL, "fmarl_store_stream: chunk_bytes must be a 16-byte multiple of at least 4096");
+    const size_t n16 = bytes / 16, c16 = shape ? chunk_bytes / 16 : 0;
+    if (!n16) return FMARL_OK;
+    const size_t chunks = shape ? (n16 + c16 - 1) / c16 : 0;
+    if (chunks > 0x7fffffffu) return fail(FMARL_EINVAL, "fmarl_store_stream: too many chunks");
+    if (shape) {   // the chunk order must be a permutation: order coprime with the number of chunks
+        size_t a = chunks, b = (size_t)order % chunks;
+        while (b) { const size_t r = a % b; a = b; b = r; }
+        if (chunks > 1 && a != 1) return fail(FMARL_EINVAL, "fmarl_store_stream: order must be coprime with the number of chunks");
+    }
+    const size_t grid = shape ? (persist && (size_t)persist < chunks ? (size_t)persist : chunks) : 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (shape == 0) hipLaunchKernelGGL(fmarl::store_stream_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, 0u, 0u, 1u);
+    else if (shape == 1) hipLaunchKernelGGL(fmarl::store_stream_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
+    else hipLaunchKernelGGL(fmarl::store_stream_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
 int fmarl_get_phase(void *handle) {
     Handle *h = (Handle *)handle;
     return h && h->lockstep ? h->host_step : -1;
@@ -1079,14 +1125,16 @@ int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_
     o.node_obs = node_obs; o.adj = adj;
     if (!outputs_aligned(h->base, &o)) return fail(FMARL_EINVAL, "fmarl_rebuild_graph: node_obs / adj must be 16-byte aligned for this shape");
     const int grid = (n_envs + h->base.epb - 1) / h->base.epb;
+    Params p = h->base;
+    p.order = sc == FMARL_SCENARIO_NAVIGATION_GRAPH ? scatter_order(grid) : 1;   // (the caller's n_envs: a grid of its own)
     if (sc == FMARL_SCENARIO_FAIRNAV)
-        hipLaunchKernelGGL(fairnav_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o,
+        hipLaunchKernelGGL(fairnav_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, p, o,
                            (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
     else if (sc == FMARL_SCENARIO_FORMATION)
-        hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, (hipStream_t)stream, h->base, o,
+        hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, (hipStream_t)stream, p, o,
                            (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
     else
-        hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, h->base, o, obs,
+        hipLaunchKernelGGL(rebuild_graph_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, p, o, obs,
                            (const uint32_t *)episode_record, n_envs);
     HIP_OK(hipGetLastError());
     return FMARL_OK;

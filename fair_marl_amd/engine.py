@@ -152,7 +152,8 @@ class RolloutEngine:
             torch.cuda.empty_cache()   # hand the losing allocations back to the driver
         self.placement_ms = times
 
-    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None, graph_record=None, info_planes=None):
+    def new_output_set(self, obs=None, reward=None, done=None, node_obs=None, adj_env=None, graph_record=None, info_planes=None,
+                       edge_nnz=None):
         """A set of per-step output buffers.  By default node_obs / adj are shared by all sets (large,
         consumed before the next step) while obs / reward / done / info are per set, so a set can still
         be read (e.g. by an in-flight RCCL gather, see sharding.py) while the next step writes another.
@@ -173,7 +174,7 @@ class RolloutEngine:
             o.info = o.info_planes.permute(1, 2, 0) if o.info_planes is not None else None
             o.node_obs = node_obs if node_obs is not None else self._default_graph[0]
             o.adj_env = adj_env if adj_env is not None else self._default_graph[1]
-            o.edge_nnz = torch.zeros(n, dtype=torch.int32, device=self.device) if self.count_edges else None
+            o.edge_nnz = edge_nnz if edge_nnz is not None else (torch.zeros(n, dtype=torch.int32, device=self.device) if self.count_edges else None)
             o.graph_record = graph_record
             if o.graph_record is None and self.emit_graph_record:
                 o.graph_record = torch.zeros(n, N, self.step_record_words, dtype=torch.int32, device=self.device)
@@ -613,7 +614,7 @@ class RolloutEngine:
             _lib.check(rc, 'fmarl_step_span')
         self._last_actions = tape
 
-    def rollout(self, action_tape, mode=None, use_graph=None):
+    def rollout(self, action_tape, mode=None, use_graph=None, ring=None):
         """Run ``len(action_tape)`` auto-resetting steps from a persistent device tape (T, n, N) int32: the random-action
         rollout of the reference's throughput runs, or a scripted tape.  Outputs of the last step are in the engine's current
         output set.  ``mode``:
@@ -625,8 +626,14 @@ class RolloutEngine:
           (default for the third scenario when the batch is launch-bound, ``n_envs * N < GRAPH_BELOW_AGENTS``);
         * ``'eager'``: one ``step`` call per step.
 
-        ``use_graph`` (older spelling): True = 'graph' where valid, False = 'eager'."""
+        ``use_graph`` (older spelling): True = 'graph' where valid, False = 'eager'.
+
+        ``ring`` (an ``OutputRing`` of at least ``len(action_tape)`` slots; modes 'span' and 'eager'): step t writes time slot t
+        instead of every step overwriting the engine's current output set -- the trajectory exists afterwards, as the
+        reference's runner keeps it (onpolicy/envs/env_wrappers.py:988-996 delivers every step's outputs)."""
         T = int(action_tape.shape[0])
+        if ring is not None and (T > ring.slots or mode == 'graph'):
+            raise ValueError('rollout: the ring holds %d slots, the tape %d steps (and graph replays write one output set)' % (ring.slots, T))
         if mode is None and use_graph is not None:
             mode = 'graph' if use_graph else 'eager'
         if mode is None:
@@ -635,7 +642,9 @@ class RolloutEngine:
             else:
                 mode = 'graph' if self.n_envs * self.cfg.N < self.GRAPH_BELOW_AGENTS else 'eager'
         if mode == 'span':
-            self.step_span(action_tape)
+            if ring is not None:
+                self.use_outputs(ring.sets[0])
+            self.step_span(action_tape, strides=ring.strides if ring is not None else None)
             return
         if mode == 'graph' and self._lean_capture_ok(T):
             key = (action_tape.data_ptr(), T, id(self.outs), self.phase)
@@ -645,6 +654,8 @@ class RolloutEngine:
             cache[key].replay()
             return
         for t in range(T):
+            if ring is not None:
+                self.use_outputs(ring.sets[t])
             self.step(action_tape[t], auto_reset=True)
 
     def poison_lds(self):
@@ -694,6 +705,44 @@ class RolloutEngine:
             self.close()
         except Exception:
             pass
+
+
+class OutputRing(object):
+    """``slots`` time slots of step outputs, laid out (slots, n, ...) like the reference's rollout storage
+    (onpolicy/utils/graph_buffer.py:84-110): slot t is an output set of the engine (``sets[t]``), and ``strides`` are the
+    per-step element strides ``RolloutEngine.step_span`` takes, so a run of steps that starts at slot t0 --
+    ``engine.use_outputs(ring.sets[t0]); engine.step_span(tape, strides=ring.strides)`` -- leaves step t in slot t0 + t.
+    Every step of a rollout has a slot of its own: its outputs exist afterwards and every byte is written once per pass over
+    the ring.  Nothing but the time slots (no masks, no policy arrays: ``DeviceRolloutBuffer`` is the runner's buffer).
+    At BASELINE config 3 a slot is 8.3 GB: an episode of 25 slots takes 208 of the 288 GB."""
+
+    def __init__(self, engine, slots):
+        eng, cfg = engine, engine.cfg
+        n, N, E, D, F = eng.n_envs, cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat
+        self.engine, self.slots = eng, int(slots)
+        T = self.slots
+        with torch.cuda.device(eng.device):
+            mk = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=eng.device)  # noqa: E731
+            self.obs = mk(T, n, N, D)
+            self.reward = mk(T, n, N)
+            self.done = mk(T, n, N, dtype=torch.uint8)
+            self.node_obs = mk(T, n, N, E, F) if eng.emit_graph else None
+            self.adj_env = mk(T, n, E, E) if eng.emit_graph else None
+            self.info_planes = mk(T, _lib.INFO_WIDTH, n, N) if eng.emit_info else None
+            self.edge_nnz = mk(T, n, dtype=torch.int32) if eng.count_edges else None
+            self.graph_record = mk(T, n, N, eng.step_record_words, dtype=torch.int32) if eng.emit_graph_record else None
+        pick = lambda a, t: a[t] if a is not None else None  # noqa: E731
+        self.sets = [eng.new_output_set(obs=self.obs[t], reward=self.reward[t], done=self.done[t], node_obs=pick(self.node_obs, t),
+                                        adj_env=pick(self.adj_env, t), info_planes=pick(self.info_planes, t),
+                                        edge_nnz=pick(self.edge_nnz, t), graph_record=pick(self.graph_record, t)) for t in range(T)]
+        per = lambda a: int(a[0].numel()) if a is not None else 0  # noqa: E731
+        self.strides = dict(obs=per(self.obs), node_obs=per(self.node_obs), adj=per(self.adj_env), reward=per(self.reward), done=per(self.done),
+                            info=per(self.info_planes), edge_nnz=per(self.edge_nnz), graph_record=per(self.graph_record))
+
+    @property
+    def nbytes(self):
+        return sum(a.numel() * a.element_size() for a in (self.obs, self.reward, self.done, self.node_obs, self.adj_env, self.info_planes,
+                                                          self.edge_nnz, self.graph_record) if a is not None)
 
 
 class _LockstepGraph(object):

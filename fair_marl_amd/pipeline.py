@@ -70,19 +70,25 @@ class PipelinedRollout:
             e.step(parts[j], auto_reset=auto_reset)
         self._each(one)
 
-    def rollout(self, action_tapes, mode=None):
+    def rollout(self, action_tapes, mode=None, rings=None):
         """``RolloutEngine.rollout`` of every sub-batch on its own stream: ``action_tapes`` = one contiguous (T, n_envs / k, N)
         int32 device tape per sub-batch (a slice of a (T, n_envs, N) tape along the env axis is not contiguous: split the
         tape once, ``split_tape``).  With spans (the engines' default mode) a sub-batch's run of steps is one launch, and the
         launch boundaries of one sub-batch -- the episode-ending step between two runs, where the chip drains and refills --
-        fall into the other's steady state: 10 agents x 65 536 envs 0.181 -> 0.163 ms per step (profiles/r3_notes.md)."""
+        fall into the other's steady state: 10 agents x 65 536 envs 0.181 -> 0.163 ms per step (profiles/r3_notes.md).
+        ``rings``: one ``OutputRing`` per sub-batch (``new_rings``) -- step t of every sub-batch goes to its time slot t."""
         if len(action_tapes) != self.k:
             raise ValueError('expected %d per-sub-batch tapes, got %d' % (self.k, len(action_tapes)))
 
         def one(j, e):
             action_tapes[j].record_stream(self.streams[j])
-            e.rollout(action_tapes[j], mode=mode)
+            e.rollout(action_tapes[j], mode=mode, ring=rings[j] if rings is not None else None)
         self._each(one)
+
+    def new_rings(self, slots):
+        """One ``OutputRing`` of ``slots`` time slots per sub-batch."""
+        from .engine import OutputRing
+        return [OutputRing(e, slots) for e in self.engines]
 
     def split_tape(self, action_tape):
         """(T, n_envs, N) -> k contiguous (T, n_envs / k, N) tapes, sub-batch j holding the envs [j n_envs / k, (j + 1) n_envs / k)."""

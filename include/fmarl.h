@@ -290,6 +290,16 @@ int fmarl_launch_geometry(void *handle, int64_t *geometry);
  * call a NaN pattern / all-ones words (it shows at once). */
 int fmarl_poison_lds(void *handle, void *stream);
 
+/* Measurement aid (bench.py `store_ceiling_ms`): a kernel that does nothing but write `bytes` bytes to `dst` with 16-byte
+ * stores, in the shapes the emission writes in -- shape 0: flat grid-stride stream; 1: a workgroup streams a contiguous chunk of
+ * `chunk_bytes`; 2: every wave streams its own contiguous quarter of such a chunk (1 KiB per store instruction).  Workgroup b
+ * writes chunk (b * order) mod n_chunks (order 1 = dispatch order; a large order coprime with the number of chunks scatters the
+ * resident workgroups over the buffer); persist > 0: that many workgroups live for the whole launch and take chunks round-robin
+ * (a span's long-lived workgroups), 0: one workgroup per chunk.  The best of them over the byte count of a step is the box's
+ * write ceiling for that step: no step kernel can be faster than its own store stream.  Replaces nothing in the reference
+ * (which has no device path); takes no handle. */
+int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, int order, int persist, void *stream);
+
 /* --- pieces exported on their own -------------------------------------------------------- */
 
 /* cdist(agent_pos, goal_pos) of navigation_graph.py:555: f64 (n, N, 2) x (n, L, 2) -> (n, N, L). */

@@ -60,17 +60,30 @@ def check(mod, got, ref, msg):
     np.testing.assert_allclose(info[..., FORM_INFO] if mod is fo else info, ref[6], err_msg=msg + ' info', **OUT)
 
 
-@pytest.mark.parametrize('case', list(CASES))
-def test_full_batch_rollout_through_episode_ends_vs_oracle(case):
+def _geometries():
+    """(case, envs per workgroup): the library's choice for every case + the geometry bench.py forces for spans that rewrite one
+    output set (bench.SAME_SLOT_EPB, read from bench.py so the two cannot drift) + whatever bench.SPAN_EPB forces for spans into
+    time slots."""
+    import bench
+    geo = [(case, 0) for case in CASES]
+    for table in (bench.SAME_SLOT_EPB, bench.SPAN_EPB):
+        for name, epb in table.items():
+            if name in CASES and (name, epb) not in geo:
+                geo.append((name, epb))
+    return geo
+
+
+@pytest.mark.parametrize('case,epb_hint', _geometries())
+def test_full_batch_rollout_through_episode_ends_vs_oracle(case, epb_hint):
     c = CASES[case]
     mod, seed = c['mod'], c['seed']
     cfg = fm.EnvConfig(**c['kw'])
     ocfg = mod.Config(**{k: getattr(cfg, k) for k in mod.Config.__dataclass_fields__})
     n, N = N_ENVS, cfg.N
     sample = np.unique(np.concatenate([np.arange(0, n, c['stride']), [n - 1]]))
-    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, async_reset=True, tune_placement=0)
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, async_reset=True, tune_placement=0, envs_per_workgroup=epb_hint)
     epb = eng.envs_per_workgroup
-    assert epb > 1 and len({int(e) % epb for e in sample}) == min(epb, len(sample)), 'sample must cover every position of a workgroup'
+    assert epb > 1 and (epb_hint == 0 or epb == epb_hint) and len({int(e) % epb for e in sample}) == min(epb, len(sample)), 'sample must cover every position of a workgroup'
     orc = make_oracle(mod, ocfg, sample, seed)
     s = torch.as_tensor(sample, device=DEV)
     pick = lambda res: tuple(x[s].cpu().numpy() for x in res)  # noqa: E731
@@ -111,15 +124,16 @@ def test_full_batch_rollout_through_episode_ends_vs_oracle(case):
     assert int(ep.min()) >= 3   # the hidden make_world reset + reset() + two episode ends
 
 
-@pytest.mark.parametrize('case', ['cfg3', 'n10', 'cfg4'])
-def test_full_batch_step_span_equals_step_by_step(case):
+@pytest.mark.parametrize('case,epb_hint', [g for g in _geometries() if g[0] != 'fnav'])
+def test_full_batch_step_span_equals_step_by_step(case, epb_hint):
     """fmarl_step_span at the benchmarked size: 65 536 envs, two episodes + 3 steps from one tape, against an engine stepping
     the same tape one launch per step (the path the test above pins against the oracle): final state and outputs bit for bit."""
     c = CASES[case]
     cfg = fm.EnvConfig(**c['kw'])
     n, N, T = N_ENVS, cfg.N, 2 * cfg.episode_length + 3
     a = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0)
-    b = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0, envs_per_workgroup=epb_hint)
+    assert epb_hint == 0 or b.envs_per_workgroup == epb_hint
     gen = torch.Generator(device=DEV); gen.manual_seed(9)
     tape = torch.randint(0, 5, (T, n, N), device=DEV, generator=gen, dtype=torch.int32)
     a.reset(); b.reset()
@@ -133,3 +147,49 @@ def test_full_batch_step_span_equals_step_by_step(case):
     for k in a._fields:
         if not k.startswith(('stage_', 'internal_')) and k != 'reset_flag':
             assert torch.equal(a.field(k), b.field(k)), k
+
+
+@pytest.mark.parametrize('case', ['cfg3', 'cfg4', 'n10'])
+def test_full_batch_spans_into_time_slots_vs_oracle(case):
+    """bench.py's headline mode at its own size and geometry: 65 536 envs, every step of an episode written to its own time slot
+    of an OutputRing by ONE span launch + the episode-ending launch (step_span with per-step strides), then a second pass over
+    the ring.  Every slot of both passes -- obs / node_obs / adj / reward / done / info of a strided sample covering every
+    position of a workgroup -- against the oracle stepping those envs (reference: every step's outputs are delivered,
+    onpolicy/envs/env_wrappers.py:988-996), and the slots of the first pass bit for bit against an engine that steps."""
+    c = CASES[case]
+    mod, seed = c['mod'], c['seed']
+    cfg = fm.EnvConfig(**c['kw'])
+    ocfg = mod.Config(**{k: getattr(cfg, k) for k in mod.Config.__dataclass_fields__})
+    n, N, T = N_ENVS, cfg.N, cfg.episode_length
+    sample = np.unique(np.concatenate([np.arange(0, n, c['stride']), [n - 1]]))
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()   # the ring takes 208 GB at cfg 3: nothing of an earlier test may linger in the allocator's cache
+    eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, tune_placement=0)
+    ref_eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, tune_placement=0)
+    ring = fm.OutputRing(eng, T)
+    orc = make_oracle(mod, ocfg, sample, seed)
+    s = torch.as_tensor(sample, device=DEV)
+    eng.reset(); ref_eng.reset(); orc.reset()
+    gen = torch.Generator(device=DEV); gen.manual_seed(11)
+    for rnd in range(2):
+        tape = torch.randint(0, 5, (T, n, N), device=DEV, generator=gen, dtype=torch.int32)
+        c0 = eng.launch_counts()[0]
+        eng.rollout(tape, mode='span', ring=ring)
+        assert eng.launch_counts()[0] - c0 == T and eng.phase == 0
+        host_tape = tape.cpu().numpy()
+        for t in range(T):
+            ref = orc.step(host_tape[t][sample])
+            got = (ring.obs[t][s], None, ring.node_obs[t][s], ring.adj_env[t][s], ring.reward[t][s], ring.done[t][s],
+                   ring.info_planes[t].permute(1, 2, 0)[s])
+            check(mod, tuple(x.cpu().numpy() if x is not None else None for x in got), ref, '%s pass %d slot %d' % (case, rnd, t))
+            if rnd == 0:   # the same steps one launch each, one output set: slot t == that set after step t
+                ref_eng.step(tape[t])
+                for k, slot in (('obs', ring.obs[t]), ('node_obs', ring.node_obs[t]), ('adj_env', ring.adj_env[t]), ('reward', ring.reward[t]),
+                                ('done', ring.done[t])):
+                    assert torch.equal(getattr(ref_eng, k), slot), (k, t)
+                assert torch.equal(ref_eng.outs.info_planes, ring.info_planes[t]), ('info', t)
+    eng.close(); ref_eng.close()
+    del ring, eng, ref_eng
+    gc.collect()
+    torch.cuda.empty_cache()

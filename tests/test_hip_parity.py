@@ -311,45 +311,78 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
         assert 'DIST_CHECK_OK steps=20 world=2' in out, out[-4000:]
 
 
-@pytest.mark.parametrize('world,extra', [(2, []), (4, ['--learner-rebuild', '2']), (2, ['--launch', 'span']),
-                                         (3, ['--launch', 'span', '--learner-rebuild', '1'])])
+@pytest.mark.parametrize('world,extra', [(2, []), (4, ['--learner-rebuild', '2']), (2, ['--launch', 'step']),
+                                         (3, ['--span-steps', '25', '--learner-rebuild', '1']), (2, ['--launch', 'step', '--learner-rebuild', '1'])])
 def test_bench_multi_rank_rehearsal(world, extra):
-    """bench.py's own multi-rank loops with ranks sharing the GPU over gloo -- one gather per step (the default for N > 1) and
-    --launch span: runs of steps as spans, their records gathered with ONE collective per run -- record rotation, gathers inside the timed
-    region, max over ranks, one JSON line from rank 0.  The line of an N > 1 run explains itself: every rank's own time per
-    step, what each waited for the exchange, what rank 0 receives, and -- with --learner-rebuild -- what it costs rank 0 to turn
-    peers' gathered steps back into node_obs / adj inside the timed loop."""
+    """bench.py's own multi-rank loops with ranks sharing the GPU over gloo -- runs of steps as spans, their records gathered with ONE
+    collective per run (the default for every N: the launch mode does not depend on the number of GPUs; with a gather the runs are
+    GATHER_SPAN_STEPS long), whole-episode runs (--span-steps 25) and --launch step: one gather per step -- record rotation, gathers
+    inside the timed region, max over ranks, one JSON line from rank 0.  The line of an N > 1 run explains itself: every rank's
+    own time per step, what each waited for the exchange, what rank 0 receives, the same steps without the exchange
+    (scaling_base) and -- with --learner-rebuild -- what it costs rank 0 to turn peers' gathered steps back into node_obs / adj
+    inside the timed loop."""
     import json
+    import bench
     out = _run_ranks([os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', str(world), '--backend', 'gloo', '--n-envs', '512',
                       '--steps', '30', '--warmup', '5'] + extra, world=world)
     lines = [l for l in out.splitlines() if l.startswith('{')]
     assert len(lines) == 1, out[-4000:]
     d = json.loads(lines[0])
-    span = '--launch' in extra
+    span = 'step' not in extra
+    whole = '--span-steps' in extra
     assert d['n_gpus'] == world and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
-    assert d['config']['launch_mode'] == ('span' if span else 'step')
+    assert d['config']['launch_mode'] == ('span' if span else 'step') and d['config']['slots'].startswith('ring')
     assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
     assert 'cpu_baseline' not in d and d['n_ranks_seen'] == world
-    if span:   # steps 5..34: [5, 25) = a run of 19 + the episode end, [25, 35) = a run of 10
+    # the timed steps are [55, 85): warm-up [0, 5), the same 30 steps without the exchange [5, 35), 20 steps back to episode phase 5
+    if span and whole:   # [55, 75) = a run of 19 + the episode end, [75, 85) = a run of 10
+        assert d['config']['span_steps'] == 25
         assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == 2
         assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(14.5) and 'one per run of steps (2 ' in d['multi_gpu']['collectives']
+    elif span:           # six runs of 5 steps, the fourth = a run of 4 + the episode end
+        assert d['config']['span_steps'] == bench.GATHER_SPAN_STEPS == 5
+        assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == 6
+        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(29 / 6) and 'one per run of steps (6 ' in d['multi_gpu']['collectives']
     else:
         assert d['roofline']['kernel_launches'] == 30 and d['roofline']['kernel_steps_per_launch'] == 1.0
     assert '512 envs per GPU' in d['config']['workload'] and d['roofline']['traffic'] is None   # --n-envs: no replayed 65 536-env counters
-    assert 'secondary' not in d
+    assert 'secondary' not in d and d['config']['auto_resets_timed'] == 1
     m = d['multi_gpu']
     assert len(m['per_rank_ms_per_step']) == world and all(0 < v <= d['ms_per_step'] * 1.001 for v in m['per_rank_ms_per_step'])
     assert len(m['gather_wait_ms']['host_blocked_per_step']) == world and len(m['gather_wait_ms']['stream_stalled_per_step']) == world
     rec = 512 * 32 * 33   # obs 28 + reward 4 + done 1 bytes per agent-step
     assert m['bytes_gathered_per_step'] == world * rec and m['bytes_received_by_rank0_per_step'] == (world - 1) * rec
     assert m['rank0_receive_GBps'] == pytest.approx((world - 1) * rec / (d['ms_per_step'] * 1e-3) / 1e9, rel=1e-6)
+    sb = d['scaling_base']   # the same steps, launch mode and record writes without the exchange: what the efficiency is measured against
+    assert sb['value_per_gpu'] > 0 and sb['efficiency'] == pytest.approx(d['value'] / (world * sb['value_per_gpu']), rel=1e-9)
     if '--learner-rebuild' in extra:
         lr = m['learner_rebuild']
         k = int(extra[extra.index('--learner-rebuild') + 1])
         assert lr['ranks_rebuilt_per_step'] == list(range(1, k + 1)) and lr['ms_per_step'] > 0
-        assert lr['steps_rebuilt'] == (25 if span else 29)   # span: the warm-up's run and [5, 25) are rebuilt while the next run is in flight
+        # span: every run but the last is rebuilt while the next one is in flight; step: every step but the last
+        assert lr['steps_rebuilt'] == ((20 if whole else 25) if span else 29)
     else:
         assert 'learner_rebuild' not in m
+
+
+def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus():
+    """The driver's command (--steps 20 --warmup 5) at one rank and at two (gloo ranks sharing this box's GPU): the same launch
+    mode, the same kernel, time slots on both sides -- a scaling figure compares like with like."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--n-envs', '1024',
+                          '--no-cpu-baseline'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stdout[-4000:]
+    one = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][0])
+    out = _run_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--n-envs', '1024', '--steps', '20', '--warmup', '5'], world=2)
+    two = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+    assert one['config']['launch_mode'] == two['config']['launch_mode'] == 'span'
+    assert one['roofline']['kernel'] == two['roofline']['kernel'] == 'step_span_kernel'
+    assert one['roofline']['slots'] == two['roofline']['slots'] == 'ring'
+    assert one['config']['auto_resets_timed'] == two['config']['auto_resets_timed'] == 1
+    assert one['config']['span_steps'] == 25 and two['config']['span_steps'] == 5 and 'scaling_base' in two and 'scaling_base' not in one
 
 
 def test_bench_exchange_through_rccl_with_one_rank():
