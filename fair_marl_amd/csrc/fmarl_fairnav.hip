@@ -273,14 +273,22 @@ struct PlacedEnvLds {
 };
 
 // One pass over the workgroup's envs.
-//   STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877); returns, per lane, whether the lane's
-//                 env has ended (all agents done) and auto_reset asks for its reset
-//   STEP = false: observation of freshly reset envs (MultiAgentGraphEnv.reset, environment.py:892-897).  `second`:
-//                 called by the step kernel itself for the envs that just ended (`flagged_in`), right after their
-//                 placement; the fair assignment of the new episode is then solved here as well (nf:469).
+//   STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877).  Envs whose agents are all done (stop-on-goal
+//                 `status` or the episode length) are reset INSIDE the pass when auto_reset is set (the vec-env worker's
+//                 behaviour, env_wrappers.py:859-865; episodes of this scenario end env by env, at any step: a reset pipeline
+//                 of its own would have to be launched behind every step -- three launches that nearly always find nothing to
+//                 do, 31 % of the step time at 65 536 x 3).  Everything the terminal step still owes -- reward, done, info, the
+//                 counters -- is computed BEFORE the sequential occupancy walk, which none of it depends on; then the ended
+//                 envs are placed (one lane per env, on the env's LDS entity table), their lanes re-seated on the new episode
+//                 (distance table, fair assignment nf:469), and the walk, the observation and the emission run ONCE for all
+//                 envs -- the ended ones on their new state.  (Rounds 2-3 ran a complete second pass over the workgroup for
+//                 the ended envs: a second dependent chain of a dozen barriers behind the first one in nearly every
+//                 workgroup of a training run, where episodes end at all phases -- 0.052 ms per launch when no env ends,
+//                 0.086 when two or three per workgroup do.)
+//   STEP = false: the observation part of an explicit reset (fmarl_reset: placement and assignment by their own kernels).
 template <bool STEP>
-__device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
-                             const float *action_vec, int auto_reset, bool second, bool flagged_in) {
+__device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
+                                             const float *action_vec, int auto_reset) {
     FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int env0 = env_block(p) * p.epb;
@@ -291,9 +299,7 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     const size_t g = (size_t)env * N + i;
     const FairNavLds t(p, lds, el);
     double *s_stat = t.stat();
-    const bool flagged = STEP ? false : (second ? flagged_in : (in_range && p.reset_flag[env] != 0));
-    // (a reset pass restricted to the freshly reset envs -- two or three of the 64 -- measured the same: the pass is a dependent
-    // chain, not work, and the restriction cost three registers, i.e. the fourth workgroup per CU)
+    const bool flagged = STEP ? false : (in_range && p.reset_flag[env] != 0);
     const bool active = in_range;
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
@@ -307,8 +313,8 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
-    if (!STEP && !second && !__syncthreads_or(flagged)) return false;
-    if (!STEP && in_range && i == 0) *t.flag() = flagged ? 0 : 1;   // (a step knows it once the agents' done flags are in)
+    if (!STEP && !__syncthreads_or(flagged)) return;
+    if (in_range && i == 0) *t.flag() = (STEP || flagged) ? 0 : 1;   // (a step emits every env: the ended ones after their reset)
     load_statics(p, lds, env0, nenv);
     __syncthreads();
     FMARL_TICK(0);   // state loads, entity tables, barrier
@@ -326,15 +332,12 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
     }
     __syncthreads();
     FMARL_TICK(2);   // distance table
-    if ((STEP || second) && !FMARL_SKIP(p, 64)) {
-        // step: reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721);
-        // in-kernel reset: the assignment of the new episode (nf:469), for the envs that were just placed
-        if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv, !STEP);
-        else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv, !STEP);
-        else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv, !STEP);
-        else fairnav_assign_tasks<32>(p, lds, nenv, !STEP);
-        __syncthreads();
-        if (!STEP && active && flagged) p.goal_match[g] = t.match()[i];
+    if (STEP && !FMARL_SKIP(p, 64)) {
+        // reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721)
+        if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv, false);
+        else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv, false);
+        else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv, false);
+        else fairnav_assign_tasks<32>(p, lds, nenv, false);
     } else if (active) {
         t.match()[i] = p.goal_match[g];
     }
@@ -370,79 +373,12 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
         t.posf()[i] = make_float2((float)x.x, (float)x.y);
     }
     __syncthreads();
-    bool emit = false, ended = false;
-    if (active) {
-        ended = STEP && auto_reset && t.words()[1] != 0;
-        emit = STEP ? !ended : flagged;
-        if (STEP && i == 0) *t.flag() = emit ? 0 : 1;
-    }
-
+    const bool ended = STEP && active && auto_reset && t.words()[1] != 0;   // every agent of the env is done: it is reset below
+    const bool emit = STEP ? true : flagged;
     FMARL_TICK(4);   // status transition, bookkeeping (four state loads), barrier
-    // ---- the sequential part: occupancy / history walk in agent order
-    ObsGoal og;
-    og.goal = -1; og.second = 0; og.g_occ = og.g_hist = og.second_occ = 0.0;
-    for (int a = 0; a < (FMARL_SKIP(p, 128) ? 0 : N); ++a) {
-        if (active && i == a)
-            og = obs_event(t.D() + i * L, t.minprox(), t.occ(), t.hist(), L, i, p.thr, p.min_obs_dist);
-        __syncthreads();
-        // graph_observation(a): row of entity i on the snapshot (nf:1255-1283)
-        bool far = false, free_empty = true;
-        int c = 0, best = -1;
-        if (active) {
-            const double *Drow = t.D() + i * L;
-            double dmin = Drow[0], bd = 1e300;
-            for (int k = 0; k < L; ++k) {
-                const double d = Drow[k];
-                if (d < dmin) { dmin = d; c = k; }
-                if (t.occ()[k] != 1.0) { free_empty = false; if (d < bd) { bd = d; best = k; } }
-            }
-            far = !(dmin < p.min_obs_dist);
-            if (far && free_empty) atomicMin(&t.words()[0], i);   // first entity that triggers the clear
-        }
-        __syncthreads();
-        if (active) {
-            const int astar = t.words()[0];                        // N = nobody
-            const bool cleared = free_empty && astar < i;         // an earlier entity already cleared the flags
-            NavRow r;
-            r.pad = 0;
-            if (!far) { r.code = (int8_t)c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = t.hist()[c]; }
-            else if (!free_empty) { r.code = (int8_t)best; r.occ = (float)t.occ()[best]; r.hist = t.hist()[best]; }
-            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = t.hist()[i]; }
-            else { r.code = (int8_t)c; r.occ = 0.f; r.hist = t.hist()[c]; }   // after the clear every goal is free
-            t.rows()[a * N + i] = r;
-        }
-        __syncthreads();
-        if (active && free_empty && t.words()[0] == i) {   // the clear itself (nf:1278), once per graph_observation
-            for (int k = 0; k < L; ++k) t.occ()[k] = 0.0;
-        }
-        __syncthreads();
-        if (active && i == 0) t.words()[0] = N;
-        // (the next iteration's first barrier orders this reset before the next atomicMin)
-    }
-    FMARL_TICK(5);   // walk
 
-    if (active) {
-        const double2 goal = og.goal >= 0 ? t.pos()[N + og.goal] : x;
-        const double2 sec = t.pos()[N + og.second];
-        if (o.obs && emit) {   // nf:997-1000
-            float *ob = o.obs + g * p.D;
-            ob[0] = (float)v.x; ob[1] = (float)v.y; ob[2] = (float)x.x; ob[3] = (float)x.y;
-            ob[4] = (float)(goal.x - x.x); ob[5] = (float)(goal.y - x.y); ob[6] = (float)og.g_occ; ob[7] = (float)og.g_hist;
-            ob[8] = (float)(sec.x - x.x); ob[9] = (float)(sec.y - x.y); ob[10] = (float)og.second_occ;
-        }
-        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
-        if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
-            uint32_t *r = o.graph_record + g * (size_t)(5 + 3 * N);
-            const float4 af = t.agentf()[i];
-            const float2 pf = t.posf()[i];
-            r[0] = __float_as_uint(pf.x); r[1] = __float_as_uint(pf.y); r[2] = __float_as_uint(af.x); r[3] = __float_as_uint(af.y);
-            r[4] = __float_as_uint(af.z);
-            for (int e = 0; e < N; ++e) {
-                const NavRow nr = t.rows()[i * N + e];
-                r[5 + 3 * e] = (uint32_t)(int32_t)nr.code; r[6 + 3 * e] = __float_as_uint(nr.occ); r[7 + 3 * e] = __float_as_uint((float)nr.hist);
-            }
-        }
-        if (STEP) {
+    if (STEP) {
+        if (active) {   // what the step owes besides the observation: reward, done, info, the state -- none of it depends on the walk
             double fairness, m, sd;   // nf:693-698, same stale / fresh rule as navigation_graph
             if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
             else mixed_stats(s_stat + 2 * N, s_stat + N, N, i, m, sd);
@@ -495,47 +431,134 @@ __device__ __forceinline__ bool fairnav_pass(const Params &p, const FmarlOutputs
                 inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
             }
         }
+        FMARL_TICK(6);   // reward, statistics, state stores, info planes
+        // ---- the envs that ended: the reset of env_wrappers.py:859-865, in place.  (The barrier also separates the terminal step's
+        // state stores and table reads above from the placement's stores to the same fields and its writes to the tables.)
+        if (__syncthreads_or(ended)) {
+            if (in_range && i == 0) {
+                p.reset_flag[env] = ended ? 1 : 0;
+                *t.flag() = ended ? 0 : 1;   // marks the envs the restricted assignment below works on
+                if (ended) {
+                    PlacedEnvLds pl{t.pos(), p, env};
+                    place_env(p, pl, kResetAuto, env, false);
+                }
+            }
+            __threadfence_block();   // the static entities of the placed envs are re-read from the state below
+            __syncthreads();
+            if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
+                load_statics_range(p, lds, env0, el, el + 1, i, N);   // f32 copies of the new landmarks / obstacles, wall tables
+                const double2 nx = t.pos()[i];   // (the placement wrote the env's float64 table)
+                t.occ()[i] = 0.0; t.hist()[i] = -1;
+                t.agentf()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                t.posf()[i] = make_float2((float)nx.x, (float)nx.y);
+            }
+            __syncthreads();
+            if (ended) {
+                const double2 nx = t.pos()[i];
+                for (int k = 0; k < L; ++k) t.D()[i * L + k] = dist2(nx, t.pos()[N + k]);
+                double m = 1e300;
+                for (int a = 0; a < N; ++a) m = fmin(m, dist2(t.pos()[a], t.pos()[N + i]));
+                t.minprox()[i] = m;
+            }
+            __syncthreads();
+            if (!FMARL_SKIP(p, 64)) {   // the assignment of the new episode (nf:469)
+                if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv, true);
+                else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv, true);
+                else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv, true);
+                else fairnav_assign_tasks<32>(p, lds, nenv, true);
+            }
+            __syncthreads();
+            if (ended) p.goal_match[g] = t.match()[i];
+            if (in_range && i == 0) *t.flag() = 0;   // every env emits (read again behind the walk's barriers)
+        }
+        FMARL_TICK(9);   // in-kernel reset of the ended envs
     }
-    FMARL_TICK(6);   // obs, reward, statistics, state stores, info planes
+
+    // ---- the sequential part: occupancy / history walk in agent order
+    ObsGoal og;
+    og.goal = -1; og.second = 0; og.g_occ = og.g_hist = og.second_occ = 0.0;
+    for (int a = 0; a < (FMARL_SKIP(p, 128) ? 0 : N); ++a) {
+        if (active && i == a)
+            og = obs_event(t.D() + i * L, t.minprox(), t.occ(), t.hist(), L, i, p.thr, p.min_obs_dist);
+        __syncthreads();
+        // graph_observation(a): row of entity i on the snapshot (nf:1255-1283)
+        bool far = false, free_empty = true;
+        int c = 0, best = -1;
+        if (active) {
+            const double *Drow = t.D() + i * L;
+            double dmin = Drow[0], bd = 1e300;
+            for (int k = 0; k < L; ++k) {
+                const double d = Drow[k];
+                if (d < dmin) { dmin = d; c = k; }
+                if (t.occ()[k] != 1.0) { free_empty = false; if (d < bd) { bd = d; best = k; } }
+            }
+            far = !(dmin < p.min_obs_dist);
+            if (far && free_empty) atomicMin(&t.words()[0], i);   // first entity that triggers the clear
+        }
+        __syncthreads();
+        if (active) {
+            const int astar = t.words()[0];                        // N = nobody
+            const bool cleared = free_empty && astar < i;         // an earlier entity already cleared the flags
+            NavRow r;
+            r.pad = 0;
+            if (!far) { r.code = (int8_t)c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = t.hist()[c]; }
+            else if (!free_empty) { r.code = (int8_t)best; r.occ = (float)t.occ()[best]; r.hist = t.hist()[best]; }
+            else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = t.hist()[i]; }
+            else { r.code = (int8_t)c; r.occ = 0.f; r.hist = t.hist()[c]; }   // after the clear every goal is free
+            t.rows()[a * N + i] = r;
+        }
+        __syncthreads();
+        if (active && free_empty && t.words()[0] == i) {   // the clear itself (nf:1278), once per graph_observation
+            for (int k = 0; k < L; ++k) t.occ()[k] = 0.0;
+        }
+        __syncthreads();
+        if (active && i == 0) t.words()[0] = N;
+        // (the next iteration's first barrier orders this reset before the next atomicMin)
+    }
+    FMARL_TICK(5);   // walk
+
+    if (active) {
+        // position and velocity as the tables hold them (an env that was reset above: its new episode's; agentf / posf are the
+        // float32 roundings the observation carries)
+        const double2 xo = t.pos()[i];
+        const double2 goal = og.goal >= 0 ? t.pos()[N + og.goal] : xo;
+        const double2 sec = t.pos()[N + og.second];
+        if (o.obs && emit) {   // nf:997-1000
+            float *ob = o.obs + g * p.D;
+            const float4 af = t.agentf()[i];
+            const float2 pf = t.posf()[i];
+            ob[0] = af.x; ob[1] = af.y; ob[2] = pf.x; ob[3] = pf.y;
+            ob[4] = (float)(goal.x - xo.x); ob[5] = (float)(goal.y - xo.y); ob[6] = (float)og.g_occ; ob[7] = (float)og.g_hist;
+            ob[8] = (float)(sec.x - xo.x); ob[9] = (float)(sec.y - xo.y); ob[10] = (float)og.second_occ;
+        }
+        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
+        if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
+            uint32_t *r = o.graph_record + g * (size_t)(5 + 3 * N);
+            const float4 af = t.agentf()[i];
+            const float2 pf = t.posf()[i];
+            r[0] = __float_as_uint(pf.x); r[1] = __float_as_uint(pf.y); r[2] = __float_as_uint(af.x); r[3] = __float_as_uint(af.y);
+            r[4] = __float_as_uint(af.z);
+            for (int e = 0; e < N; ++e) {
+                const NavRow nr = t.rows()[i * N + e];
+                r[5 + 3 * e] = (uint32_t)(int32_t)nr.code; r[6 + 3 * e] = __float_as_uint(nr.occ); r[7 + 3 * e] = __float_as_uint((float)nr.hist);
+            }
+        }
+    }
+    FMARL_TICK(7);   // obs, occupancy state, record
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
-    if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return ended; }
-    // (a step pass writes all rows: an env that skips in a step pass has ended and is reset by this same launch)
-    fairnav_emit_rows<STEP>(p, o, lds, env0, nenv);
-    FMARL_TICK(7);   // node rows
+    if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return; }
+    fairnav_emit_rows<STEP>(p, o, lds, env0, nenv);   // (a step pass writes all rows: no env keeps its previous ones)
+    FMARL_TICK(8);   // node rows
     emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
-    FMARL_TICK(8);   // adj
+    FMARL_TICK(10);   // adj
     FMARL_TICKS_END;
-    return ended;
 }
 
-// STEP = true : one env step; envs whose agents are all done (stop-on-goal `status` or the episode length) are reset
-//               HERE when auto_reset is set (the vec-env worker's behaviour, env_wrappers.py:859-865): placement by one
-//               lane per ended env on the env's LDS entity table, then the reset pass over those envs.  Episodes of this
-//               scenario end env by env, at any step: a reset pipeline of its own would have to be launched behind every
-//               step (three launches that nearly always find nothing to do: 31 % of the step time at 65 536 x 3).
-// STEP = false: the observation part of an explicit reset (fmarl_reset: placement and assignment by their own kernels).
 template <bool STEP>
 __device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
                                              const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const bool ended = fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset, false, false);
-    if (!STEP) return;
-    if (!__syncthreads_or(ended)) return;   // (every lane of an env agrees; block-uniform)
-    const int N = p.N, tid = threadIdx.x;
-    const int env0 = env_block(p) * p.epb, nenv = min(p.epb, p.n_envs - env0);
-    const int el = tid / N, i = tid - el * N;
-    if (el < nenv && i == 0) {
-        p.reset_flag[env0 + el] = ended ? 1 : 0;
-        if (ended) {
-            PlacedEnvLds pl{FairNavLds(p, lds, el).pos(), p, env0 + el};
-            place_env(p, pl, kResetAuto, env0 + el, false);
-        }
-    }
-    __threadfence_block();   // the reset pass re-reads the state of the placed envs from global memory
-    __syncthreads();
-    // (the argument block re-read through an opaque pointer: nothing of it stays in scalar registers across the step pass for the
-    // sake of this one -- fmarl_dev.h span_params_reloaded)
-    fairnav_pass<false>(span_params_reloaded(), o, lds, nullptr, nullptr, 0, true, ended);
+    fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset);
 }
 
 template <bool STEP>

@@ -32,7 +32,7 @@ constexpr double kTargetRadius = 0.5;   // ff:105
 // receives the final column potentials shifted so that their maximum is 0.
 template <int G>
 __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int8_t *ans, const double *rowmin, const double *vin,
-                                double *vout) {
+                                double *vout, const int which = 0) {
     const int lane = threadIdx.x & (G - 1);
     const double INF = 1e300;
     double u = 0.0, v = lane < N ? vin[lane] : 0.0;
@@ -53,6 +53,8 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int8_
     const bool unmatched = lane < N && __shfl(prow, mine, G) != lane;
     const unsigned long long um_all = __ballot(unmatched);
     uint32_t um = (uint32_t)(um_all >> ((threadIdx.x & 63) & ~(G - 1))) & (G == 32 ? ~0u : ((1u << G) - 1));
+    FMARL_HSTAT(which, 0, 1);
+    FMARL_HSTAT(which, 2, __builtin_popcount(um));
     while (um) {
         const int i = __builtin_ctz(um);
         um &= um - 1;
@@ -60,6 +62,7 @@ __device__ void hungarian_group(const double2 *x, const double2 *P, int N, int8_
         int way = -1, j0 = -1, i0 = i, j1;
         bool usedc = false, in_tree = lane == i;
         for (int it = 0; it <= N; ++it) {   // at most N columns can join the tree
+            FMARL_HSTAT(which, 3, 1);
             const double ui0 = __shfl(u, i0, G);
             const bool open = lane < N && !usedc;
             if (open) {
@@ -144,11 +147,11 @@ __device__ __forceinline__ void hungarian_tasks(const Params &p, char *lds, int 
         // (ff:707-739): not when agent 0 sits on a previous slot or every slot is taken (common once agents hold the ring)
         if (which == 1) {
             const uint32_t full = p.N >= 32 ? ~0u : ((1u << p.N) - 1);
-            if (*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0) continue;
+            if (*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0) { FMARL_HSTAT(1, 1, 1); continue; }
         }
         const double *vin = t.vdual();   // the state's copy in LDS: nobody writes it during the matchings
         hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
-                           which == 0 ? t.theta() : (const double *)t.masks(), vin, which == 0 ? t.theta() : nullptr);
+                           which == 0 ? t.theta() : (const double *)t.masks(), vin, which == 0 ? t.theta() : nullptr, which);
     }
 }
 

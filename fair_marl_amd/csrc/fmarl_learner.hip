@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void returns_kernel(FmarlReturns a, const floa
         value_preds[(size_t)T * C + c] = nv;                 // :299 / :340
         float v1 = dn ? nv * sd + mean : nv;                 // denormalised value of step t + 1
         float gae = 0.f;
-        float r = rewards[(size_t)(T - 1) * C + c], v = T > 0 ? value_preds[(size_t)(T - 1) * C + c] : 0.f;
+        float r = T > 0 ? rewards[(size_t)(T - 1) * C + c] : 0.f, v = T > 0 ? value_preds[(size_t)(T - 1) * C + c] : 0.f;
         float m1 = masks[(size_t)T * C + c], b1 = proper ? bad_masks[(size_t)T * C + c] : 1.f;
         for (int t = T - 1; t >= 0; --t) {
             // the next iteration's operands are requested before this one's arithmetic
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void advantage_raw_kernel(const float *returns
     double cnt = 0.0, s1 = 0.0, s2 = 0.0;
     auto one = [&](float r, float v, float m) {
         const float x = r - (dn ? v * sd + mean : v);
-        if (m != 0.f) { cnt += 1.0; s1 += (double)x; s2 += (double)x * (double)x; }
+        if (m != 0.f && x == x) { cnt += 1.0; s1 += (double)x; s2 += (double)x * (double)x; }   // (np.nanmean / np.nanstd skip a NaN advantage too)
         return x;
     };
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
@@ -140,9 +140,10 @@ __global__ __launch_bounds__(256) void advantage_scale_kernel(float *adv, size_t
         cnt += q[0]; s1 += q[1]; s2 += q[2];
     }
     block_sum3(cnt, s1, s2, red);
-    const double mu = cnt > 0.0 ? s1 / cnt : 0.0;
-    const double var = cnt > 0.0 ? s2 / cnt - mu * mu : 0.0;
-    const float m = (float)mu, sdev = (float)sqrt(var > 0.0 ? var : 0.0);
+    // no active entry at all: np.nanmean / np.nanstd of an all-NaN array give NaN (graph_mappo.py:302-304), and so does this
+    const double mu = cnt > 0.0 ? s1 / cnt : __longlong_as_double(0x7ff8000000000000ll);
+    const double var = cnt > 0.0 ? s2 / cnt - mu * mu : mu;
+    const float m = (float)mu, sdev = (float)(var != var ? var : sqrt(var > 0.0 ? var : 0.0));
     if (blockIdx.x == 0 && threadIdx.x == 0) { stats[0] = m; stats[1] = sdev; }
     const float d = sdev + 1e-5f;   // graph_mappo.py:304
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;

@@ -521,7 +521,7 @@ __device__ __forceinline__ double2 agent_force(const Params &p, const char *base
         // instructions, ran for every lane of a wave as soon as one of its agents was inside a wall's span)
         double sin_t = 0.0, cos_t = 1.0;
         if (ppar < e0 || ppar > e1) {
-            sin_t = (ppar < e0 ? ppar - e0 : ppar - e1) * (1.0 / s);
+            sin_t = (ppar < e0 ? ppar - e0 : ppar - e1) / s;   // (a true division: this is state; the reference's sin(arcsin(z)) is z to an ulp)
             cos_t = sqrt_pos(fmax(1.0 - sin_t * sin_t, 0.0));
         }
         const double dmin = cos_t * s + 0.5 * kWallWidth;

@@ -1073,6 +1073,12 @@ extern "C" int fmarl_measure_ticks(double *out, int rows) {
     for (int r = 0; r < rows; ++r) for (int k = 0; k < FMARL_TICK_PHASES; ++k) out[k] += host[r][k];
     return FMARL_OK;
 }
+extern "C" int fmarl_measure_hstat(unsigned long long *out, int reset) {
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fmarl_hstat), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = {}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_fmarl_hstat), z, sizeof z)); }
+    return FMARL_OK;
+}
 // the raw rows: [14] / [15] = the constant-rate (100 MHz) clock at the wave's end / start
 extern "C" int fmarl_measure_rows(unsigned int *out, int rows) {
     if (rows > FMARL_TICK_ROWS) rows = FMARL_TICK_ROWS;

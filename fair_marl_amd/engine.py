@@ -621,9 +621,10 @@ class RolloutEngine:
 
         * ``'span'`` (default for navigation_graph and fair_graph_formation): ``step_span`` -- one launch per run of steps
           between episode ends (10 agents x 65 536 envs: 0.250 -> 0.199 ms per step; 3 agents x 4 096 envs: 14.5 -> 11.5 us);
-        * ``'graph'``: one hipGraph replay per call, captured on first use and cached per (tape storage, length, output set)
-          -- valid while the caller refills the same tensor in place; needs a phase / length the lean capture covers
-          (default for the third scenario when the batch is launch-bound, ``n_envs * N < GRAPH_BELOW_AGENTS``);
+        * ``'graph'``: one hipGraph replay per call, captured on first use and cached per (tape tensor, length, output set,
+          episode phase) -- valid while the caller refills the same tensor in place; needs envs in lockstep and a phase / length
+          the lean capture covers, otherwise the call falls through to ``'eager'`` (always so for
+          nav_fairassign_fairrew_formation_graph, whose episodes end env by env: its default is ``'eager'``);
         * ``'eager'``: one ``step`` call per step.
 
         ``use_graph`` (older spelling): True = 'graph' where valid, False = 'eager'.
@@ -637,21 +638,25 @@ class RolloutEngine:
         if mode is None and use_graph is not None:
             mode = 'graph' if use_graph else 'eager'
         if mode is None:
-            if self.cfg.scenario_name != 'nav_fairassign_fairrew_formation_graph':
-                mode = 'span'
-            else:
-                mode = 'graph' if self.n_envs * self.cfg.N < self.GRAPH_BELOW_AGENTS else 'eager'
+            mode = 'span' if self.cfg.scenario_name != 'nav_fairassign_fairrew_formation_graph' else 'eager'
         if mode == 'span':
             if ring is not None:
                 self.use_outputs(ring.sets[0])
             self.step_span(action_tape, strides=ring.strides if ring is not None else None)
             return
         if mode == 'graph' and self._lean_capture_ok(T):
-            key = (action_tape.data_ptr(), T, id(self.outs), self.phase)
-            cache = self.__dict__.setdefault('_rollout_graphs', {})
-            if key not in cache:
-                cache[key] = self.capture_rollout(action_tape, None, True, True)
-            cache[key].replay()
+            # the cache holds the tape and the output set themselves (not their addresses: an address can be reused by another
+            # tensor once the first one is gone, and the old graph would write into freed buffers), at most 8 graphs
+            key = (action_tape.data_ptr(), T, self.phase)
+            cache = self.__dict__.setdefault('_rollout_graphs', [])
+            hit = next((e for e in cache if e[0] == key and e[2] is self.outs and e[1].data_ptr() == action_tape.data_ptr()
+                        and e[1].untyped_storage().data_ptr() == action_tape.untyped_storage().data_ptr()), None)
+            if hit is None:
+                hit = (key, action_tape, self.outs, self.capture_rollout(action_tape, None, True, True))
+                cache.append(hit)
+                if len(cache) > 8:
+                    cache.pop(0)
+            hit[3].replay()
             return
         for t in range(T):
             if ring is not None:

@@ -32,6 +32,9 @@ CASES = {
     'cfg3': dict(mod=no, seed=31, stride=1021, kw=dict(num_agents=32, num_landmarks=32, num_obstacles=8)),
     # the reference's own 10-agent scale (bench.py --config n10): odd row widths through the per-wave LDS windows
     'n10': dict(mod=no, seed=32, stride=1021, kw=dict(num_agents=10, num_landmarks=10, num_obstacles=3)),
+    # walls (the end-cap force takes cos / sin from past / size instead of arcsin -- state, not output): agents
+    # crowded between two walls for two episodes, every step against the oracle's asin / cos / sin, float64 state at 1e-9 at the end
+    'navw': dict(mod=no, seed=35, stride=509, kw=dict(num_agents=6, num_landmarks=6, num_obstacles=2, num_walls=2)),
     # BASELINE config 4 (bench.py --config cfg4): 24 envs per workgroup, six per wave, in-kernel reset
     'cfg4': dict(mod=fo, seed=33, stride=1021,
                  kw=dict(scenario_name='fair_graph_formation', num_agents=10, num_landmarks=1, num_obstacles=3)),

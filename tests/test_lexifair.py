@@ -75,3 +75,66 @@ def test_reference_procedure_with_highs_gives_the_same_assignment(n):
         x, objs = solve_fair_assignment_milp(cost_matrix(agents, goals))
         assert np.array_equal(np.where(x == 1)[1], [2, 1, 0])
         assert np.allclose(objs, [1.8439088915, 1.6643316977, 1.4396180049])
+
+
+@pytest.mark.parametrize('seed', [1, 2])
+def test_reference_procedure_with_highs_at_32_agents_on_the_reset_stream(seed):
+    """BASELINE config 3 solves 32 x 32 problems; the HiGHS restatement of the reference's procedure stopped at N = 16.
+    Here the inputs are what cfg 3 really solves: cdist(agent_pos, goal_pos) of episodes placed by the reset on the
+    device's own Philox stream (oracle twin: nav_oracle + PhiloxStream(seed, env, episode)), incl. a second episode.
+    The procedure (32 rounds of the min-max MILP, marl_fair_assign.py:32-52) must fix the same columns as the
+    definition-based solver -- and as the goal_match the reset stored (navigation_graph.py:555-561)."""
+    from oracle import nav_oracle as no
+    from oracle.lexifair_milp import lexifair_milp
+    from oracle.philox import PhiloxStream
+    cfg = no.Config(num_agents=32, num_landmarks=32, num_obstacles=8)
+    env = no.OracleGraphVecEnv(cfg, 1, mode='subproc', streams=lambda e, ep: PhiloxStream(seed, 7 * seed + e, ep))
+    env.reset()
+    c = cost_matrix(env.st.agent_pos[0], env.st.landmark_pos[0])
+    assert c.shape == (32, 32) and len(np.unique(c)) == 1024       # distinct costs: the assignment is solver-independent
+    p = lexifair_milp(c)
+    assert np.array_equal(p, lexifair(c)) and np.array_equal(p, env.st.goal_match[0])
+
+
+@pytest.mark.parametrize('n', [17, 24])
+def test_reference_procedure_with_highs_between_16_and_32_agents(n):
+    from oracle.lexifair_milp import lexifair_milp
+    rs = np.random.RandomState(300 + n)
+    c = cost_matrix(rs.uniform(-1, 1, (n, 2)), rs.uniform(-0.8, 0.8, (n, 2)))
+    assert np.array_equal(lexifair_milp(c), lexifair(c))
+
+
+def test_constructed_ties_where_the_order_is_a_choice():
+    """Where the reference's answer is NOT defined by its procedure: tied costs.  Each round's MILP only forces the bottleneck
+    VALUE; with ties (a) `argmin |costs - z*|` (marl_fair_assign.py:38) picks the first entry in row-major order that has the
+    value z*, whether or not the solver's assignment uses it, and (b) the solver may return any optimal assignment -- so the row
+    that gets fixed and its column depend on Gurobi's internals.  The oracle and the device resolve ties by the total order
+    (cost, row, col).  What IS defined either way is the sorted cost vector of the result: the lexicographic optimum's VALUE is
+    unique, and every tie-breaking rule must reach it.  Constructed cases: agents and goals mirrored about an axis (pairs of
+    equal costs), a square (four-fold ties), all-equal costs."""
+    from oracle.lexifair_milp import solve_fair_assignment_milp
+    cases = []
+    agents = np.array([[-0.5, 0.3], [-0.5, -0.3], [0.1, 0.6], [0.1, -0.6]])       # mirrored about y = 0
+    goals = np.array([[0.6, 0.2], [0.6, -0.2], [-0.1, 0.4], [-0.1, -0.4]])
+    cases.append(cost_matrix(agents, goals))
+    sq = np.array([[1.0, 1.0], [1.0, -1.0], [-1.0, -1.0], [-1.0, 1.0]])
+    cases.append(cost_matrix(0.5 * sq, 0.25 * sq[[1, 2, 3, 0]]))                   # square inside a square: four-fold ties
+    cases.append(np.full((5, 5), 0.7))                                             # every assignment is optimal
+    cases.append(np.array([[1.0, 2.0, 2.0], [2.0, 1.0, 2.0], [2.0, 2.0, 1.0]]))    # unique optimum despite ties off the diagonal
+    for c in cases:
+        n = c.shape[0]
+        p = lexifair(c)
+        assert sorted(p) == list(range(n))
+        ours = np.sort(c[np.arange(n), p])[::-1]
+        brute = np.sort(c[np.arange(n), lexifair_bruteforce(c)])[::-1]
+        assert np.array_equal(ours, brute)                     # the value (sorted cost vector) is the optimum ...
+        x, objs = solve_fair_assignment_milp(c)
+        q = np.where(x == 1)[1]
+        assert sorted(q) == list(range(n))
+        # ... the procedure with ANOTHER solver may end on a different assignment and -- since with ties it can zero an entry the
+        # solver's assignment does not use and fix a non-bottleneck row -- even on a worse vector below the first entry; the
+        # bottleneck itself (round 1's z*) is forced
+        assert objs[0] == ours[0]
+        eps = c + 1e-9 * np.arange(n * n).reshape(n, n)        # our choice, made explicit: ties broken by (row, col)
+        assert np.array_equal(p, lexifair_bruteforce(eps))
+    assert np.array_equal(lexifair(cases[3]), [0, 1, 2])

@@ -34,6 +34,17 @@ def main():
     for t in range(steps):
         eng.step(tape[t % 25])
     lib = _lib.load()
+    if name == 'cfg4':   # the slot matchings of the LAST step only
+        hs = (C.c_ulonglong * 8)()
+        lib.fmarl_measure_hstat.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        torch.cuda.synchronize()
+        assert lib.fmarl_measure_hstat(hs, 1) == 0
+        eng.step(tape[steps % 25])
+        assert lib.fmarl_measure_hstat(hs, 1) == 0
+        for w, label in ((0, 'current slots'), (1, 'previous slots')):
+            run, skip, rows, its = hs[4 * w:4 * w + 4]
+            print('matching on the %s: %d run, %d skipped; per run %.2f rows through the augmenting search, %.2f search iterations'
+                  % (label, run, skip, rows / max(1, run), its / max(1, run)))
     waves = -(-n // eng.envs_per_workgroup) * 4
     out = (C.c_double * 16)()
     lib.fmarl_measure_ticks.argtypes = [C.POINTER(C.c_double), C.c_int]
