@@ -15,14 +15,12 @@
 __device__ unsigned int g_fmarl_ticks[FMARL_TICK_ROWS][FMARL_TICK_PHASES];
 // counters of the slot matchings (tools/phase_ticks.py cfg4): [which][tasks run, tasks skipped, rows through the augmenting search, search iterations]
 __device__ unsigned long long g_fmarl_hstat[2][4];
-#define FMARL_HSTAT(w, k, v) do { if (((threadIdx.x & 63) & (G - 1)) == 0) atomicAdd(&g_fmarl_hstat[w][k], (unsigned long long)(v)); } while (0)
 #define FMARL_TICKS_BEGIN unsigned int ticks_[FMARL_TICK_PHASES] = {}; unsigned long long tick_ = wall_clock64(); ticks_[15] = (unsigned int)tick_; tick_ = clock64();
 #define FMARL_TICK(k) do { const unsigned long long now_ = clock64(); ticks_[k] += (unsigned int)(now_ - tick_); tick_ = now_; } while (0)
 #define FMARL_TICKS_END do { ticks_[14] = (unsigned int)wall_clock64(); const unsigned int row_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
     if ((threadIdx.x & 63) == 0 && row_ < FMARL_TICK_ROWS) for (int k_ = 0; k_ < FMARL_TICK_PHASES; ++k_) g_fmarl_ticks[row_][k_] = ticks_[k_]; } while (0)
 #else
 #define FMARL_SKIP(p, bit) false
-#define FMARL_HSTAT(w, k, v) do { } while (0)
 #define FMARL_TICKS_BEGIN
 #define FMARL_TICK(k) do { } while (0)
 #define FMARL_TICKS_END do { } while (0)

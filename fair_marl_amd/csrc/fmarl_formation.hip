@@ -21,83 +21,122 @@ namespace fmarl {
 
 constexpr double kTargetRadius = 0.5;   // ff:105
 
-// Min-sum assignment (Kuhn-Munkres with potentials, shortest augmenting paths) by a group of G lanes
-// (G = power of two >= N, G <= 32): lane c owns column c (v, minv, way, matched row) and row c (u, in-tree
-// flag); the only cross-lane traffic is the argmin reduction and a few broadcasts (shuffles of width G).
-// Costs are |x_row - P_col| computed on the fly (x: agent positions in LDS, P: slot positions; an N x N table per
-// group of lanes costs a workgroup per CU and was measured slower: 0.46 vs 0.42 ms at cfg 4).  ans[row] = col.  For generic real costs the optimum is unique, so it
-// equals SciPy's linear_sum_assignment (ff:615-618).
-// Warm start: vin[c] are column potentials left by an earlier matching on nearly the same costs (any values are
-// feasible once u = row minima of c - v, which is what rowmin[] / ans[] hold on entry); vout (LDS, may alias rowmin)
-// receives the final column potentials shifted so that their maximum is 0.
-template <int G>
-__device__ void hungarian_group(const double2 *x, const double2 *P, int N, int8_t *ans, const double *rowmin, const double *vin,
-                                double *vout, const int which = 0) {
-    const int lane = threadIdx.x & (G - 1);
-    const double INF = 1e300;
-    double u = 0.0, v = lane < N ? vin[lane] : 0.0;
-    int prow = -1;   // row matched to column `lane`
-    const double2 Pc = P[lane < N ? lane : 0];
-    // Start: u = row minima of c - v (feasible potentials), every row claims the column of its minimum, the lowest row
-    // wins a contested one (those edges are tight).  Only the rows left without a column go through the augmenting
-    // search; the optimum does not depend on the start.
-    // (row minima and their columns come from the kernel's agent x slot distance pass: rowmin[], ans[] on entry)
-    int mine = 0;
-    {
-        if (lane < N) { u = rowmin[lane]; mine = ans[lane]; }
-        for (int r = 0; r < N; ++r) {
-            const int cr = __shfl(mine, r, G);
-            if (lane == cr && prow < 0) prow = r;
+// Lane-to-lane reads inside a wave (ds_bpermute: `addr` = 4 x source lane).  A disabled source lane reads as 0: callers only
+// read lanes of their own env's segment, which share their control flow.
+__device__ __forceinline__ int bperm_i32(int addr, int v) { return __builtin_amdgcn_ds_bpermute(addr, v); }
+__device__ __forceinline__ double bperm_f64(int addr, double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)b), hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo));
+}
+
+// Min-sum assignment (Kuhn-Munkres with potentials, shortest augmenting paths) of ONE env by the env's own N agent lanes: lane
+// `li` of the segment [base, base + N) of the wave owns column li (v, minv, way, matched row) and row li (u, in-tree flag).
+// Every env of the wave runs its matching at the same time (64 / N envs: 60 of 64 lanes at ten agents), where rounds 2-3 dealt
+// (env, which) tasks to four 16-lane groups -- 40 of 64 lanes, three rounds per step at cfg 4 instead of two.  The cross-lane
+// traffic: the argmin as a rotation all-reduce (partners li + 1, 2, 4, ... mod N: ceil(log2 N) steps, every lane ends with the
+// minimum of a cyclic window >= N), a few single-lane reads (ds_bpermute).  Costs are |x_row - P_col| computed on the fly
+// (x: agent positions in LDS, Pc: the lane's own slot).  The optimum is unique for generic real costs, so it equals SciPy's
+// linear_sum_assignment (ff:615-618) whatever the start.
+// Warm start: `v` = column potential left by an earlier matching on nearly the same costs (any values are feasible once u = the
+// row minima of c - v: `u` / `mine` = reduced row minimum and its column, from the kernel's agent x slot distance pass);
+// every row claims the column of its minimum, the lowest row wins a contested one (`claim`: an LDS table of N ints of the
+// env), only the rows left without a column go through the augmenting search.  ans[row] = col; returns the final column
+// potential shifted so that the maximum over the columns is 0.
+struct SegLanes {
+    int N, li, base, self4, rot[5], steps;
+    uint32_t full;
+    __device__ __forceinline__ SegLanes(int N_, int li_, int base_) : N(N_), li(li_), base(base_) {
+        self4 = (base + li) << 2;
+        steps = 0;
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {   // (N <= 32; fixed trip count: rot[] stays in registers)
+            int q = li + (1 << s);
+            q = q >= N ? q - N : q;
+            rot[s] = (base + ((1 << s) < N ? q : li)) << 2;
+            steps += (1 << s) < N ? 1 : 0;
         }
+        full = N >= 32 ? ~0u : ((1u << N) - 1);
     }
-    const bool unmatched = lane < N && __shfl(prow, mine, G) != lane;
-    const unsigned long long um_all = __ballot(unmatched);
-    uint32_t um = (uint32_t)(um_all >> ((threadIdx.x & 63) & ~(G - 1))) & (G == 32 ? ~0u : ((1u << G) - 1));
-    FMARL_HSTAT(which, 0, 1);
-    FMARL_HSTAT(which, 2, __builtin_popcount(um));
+    __device__ __forceinline__ int at(int k) const { return (base + k) << 2; }   // bpermute address of segment lane k
+    template <bool MAX> __device__ __forceinline__ double extreme(double v) const {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            if (s < steps) {   // (uniform)
+                const double o = bperm_f64(rot[s], v);
+                if (MAX) asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
+                else asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
+            }
+        }
+        return v;
+    }
+    __device__ __forceinline__ uint32_t bits(bool pred) const {   // the segment's lanes whose predicate holds, bit k = lane k
+        return (uint32_t)(__ballot(pred) >> base) & full;
+    }
+};
+
+__device__ __forceinline__ double hungarian_seg(const SegLanes &sl, const bool act, const double2 *x, const double2 Pc, double u, const int mine,
+                                                double v, int8_t *ans, int *claim, const int which) {
+    const int N = sl.N, li = sl.li;
+    const double INF = 1e300;
+    // start: the lowest row that claims a column gets it (those edges are tight)
+    if (act) claim[li] = N;
+    wave_sync();
+    if (act) atomicMin(&claim[mine], li);
+    wave_sync();
+    int prow = -1;   // row matched to column li
+    bool unmatched = false;
+    if (act) {
+        const int c = claim[li];
+        prow = c < N ? c : -1;
+        unmatched = claim[mine] != li;
+    }
+    uint32_t um = sl.bits(unmatched);
+#ifdef FMARL_MEASURE
+    if (act && li == 0) { atomicAdd(&g_fmarl_hstat[which][0], 1ull); atomicAdd(&g_fmarl_hstat[which][2], (unsigned long long)__builtin_popcount(um)); }
+#endif
     while (um) {
         const int i = __builtin_ctz(um);
         um &= um - 1;
         double minv = INF;
-        int way = -1, j0 = -1, i0 = i, j1;
-        bool usedc = false, in_tree = lane == i;
+        int way = -1, j0 = -1, i0 = i, j1 = -1;
+        bool usedc = false, in_tree = li == i;
         for (int it = 0; it <= N; ++it) {   // at most N columns can join the tree
-            FMARL_HSTAT(which, 3, 1);
-            const double ui0 = __shfl(u, i0, G);
-            const bool open = lane < N && !usedc;
+#ifdef FMARL_MEASURE
+            if (li == 0) atomicAdd(&g_fmarl_hstat[which][3], 1ull);
+#endif
+            const double ui0 = bperm_f64(sl.at(i0), u);
+            const bool open = !usedc;
             if (open) {
                 const double cur = dist2(x[i0], Pc) - ui0 - v;
                 if (cur < minv) { minv = cur; way = j0; }
             }
-            double delta;
-            group_argmin<G>(minv, open, delta, j1);   // ties to the lowest column
+            const double delta = sl.extreme<false>(open ? minv : INF);
+            const uint32_t hit = sl.bits(open && minv == delta);   // ties to the lowest column
+            j1 = __builtin_ctz(hit);
             if (in_tree) u += delta;
-            if (usedc) v -= delta; else if (lane < N) minv -= delta;
-            if (lane == j1) usedc = true;
+            if (usedc) v -= delta; else minv -= delta;
+            if (li == j1) usedc = true;
             j0 = j1;
-            const int r1 = __shfl(prow, j1, G);
+            const int r1 = bperm_i32(sl.at(j1), prow);
             if (r1 < 0) break;
-            if (lane == r1) in_tree = true;
+            if (li == r1) in_tree = true;
             i0 = r1;
         }
         for (int j = j1; j >= 0;) {   // flip the augmenting path back to the root (row i)
-            const int jprev = __shfl(way, j, G);
-            const int row = jprev < 0 ? i : __shfl(prow, jprev, G);
-            if (lane == j) prow = row;
+            const int jprev = bperm_i32(sl.at(j), way);
+            const int row = jprev < 0 ? i : bperm_i32(sl.at(jprev < 0 ? 0 : jprev), prow);
+            if (li == j) prow = row;
             j = jprev;
         }
     }
-    if (lane < N) ans[prow] = (int8_t)lane;
-    if (vout) {
-        const double vmax = group_extreme<G, true>(lane < N ? v : -INF);
-        if (lane < N) vout[lane] = v - vmax;
+    double vout = 0.0;
+    if (act) {
+        ans[prow] = (int8_t)li;
+        vout = v - sl.extreme<true>(v);
     }
+    return vout;
 }
-
-// All matchings of the workgroup's envs: task = (env, which) with which 0 = current slots, 1 = previous
-// slots (needed by observation(0) of a step); groups of G lanes take tasks round-robin.
-template <int G>
-__device__ __forceinline__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env);
 
 // Per-env LDS tables of the formation kernels, after the common ones (byte offsets in Params.f_*).
 struct FormLds {
@@ -135,25 +174,6 @@ struct FormLds {
         return make_double2((double)pf.x, (double)pf.y);
     }
 };
-
-template <int G>
-__device__ __forceinline__ void hungarian_tasks(const Params &p, char *lds, int env0, int el0w, int nenv_w, int per_env) {
-    // the wave's own envs only: its 64 / G lane groups take the tasks round-robin, no other wave is involved
-    const int group = (threadIdx.x & 63) / G, ngroups = 64 / G;
-    for (int task = group; task < nenv_w * per_env; task += ngroups) {
-        const int elw = task / per_env, which = task - elw * per_env, el = el0w + elw;
-        const FormLds t(p, lds, el);
-        // the matching on the previous slots only serves observation(agent 0) in its "free slot left" branch
-        // (ff:707-739): not when agent 0 sits on a previous slot or every slot is taken (common once agents hold the ring)
-        if (which == 1) {
-            const uint32_t full = p.N >= 32 ? ~0u : ((1u << p.N) - 1);
-            if (*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0) { FMARL_HSTAT(1, 1, 1); continue; }
-        }
-        const double *vin = t.vdual();   // the state's copy in LDS: nobody writes it during the matchings
-        hungarian_group<G>(t.pos(), which == 0 ? t.slot_new() : t.slot_old(), p.N, which == 0 ? t.g_new() : t.g_old(),
-                           which == 0 ? t.theta() : (const double *)t.masks(), vin, which == 0 ? t.theta() : nullptr, which);
-    }
-}
 
 // ff:518-530: wall box WITHOUT the 1.05 factors of navigation_graph
 __device__ __forceinline__ bool wall_box_hit_plain(double2 x, double axis, double e0, double e1, int orient) {
@@ -383,8 +403,8 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     }
     wave_sync();
 
+    double2 P = make_double2(0, 0);   // this agent's own slot index i of the current ring (column i of the matching)
     if (active) {   // slots: ff:630-648 (step: inside reward(agent 0)); on reset they come from the state
-        double2 P;
         if (STEP) {
             // slot i = landmark 0 + radius (cos, sin)(theta_min + i 2 pi / N): the anchor agent's own direction (dx, dy) / r
             // is (cos, sin)(theta_min); turning it by the tabulated (cos, sin)(i 2 pi / N) needs no trigonometric call
@@ -406,12 +426,15 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     FMARL_TICK(2);   // angle keys, ring test, slots
 
     double left = 0;
+    // start of the matchings (hungarian_seg): this row's reduced minimum and its column, against the current / the previous slots
+    double rbest = 1e300, rbest_old = 1e300;
+    int rkb = 0, rkb_old = 0;
     if (active) {   // agent x slot distances (ff:650-655), nearest slot within thr, dist_left (ff:453)
         // row minima of c - v for the warm-started matchings (v: the potentials the previous matching of this env left;
         // for the previous slots they are the potentials of exactly those slots, one step of motion ago)
         const double *vg = t.vdual();   // (staged in LDS at kernel start: a global load per loop trip would stall every trip)
-        double best = 1e300, best_old = 1e300, rbest = 1e300, rbest_old = 1e300;
-        int kb = 0, kb_old = 0, rkb = 0, rkb_old = 0;
+        double best = 1e300, best_old = 1e300;
+        int kb = 0, kb_old = 0;
         for (int k = 0; k < N; ++k) {
             const double vk = vg[k];
             const double d = dist2(x, t.slot_new()[k]);
@@ -425,9 +448,6 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         }
         left = best;
         t.near_new()[i] = (int8_t)(best < p.thr ? kb : -1);
-        // start of the matchings (hungarian_group): reduced row minimum and its column, in tables that are idle until then
-        t.theta()[i] = rbest; t.g_new()[i] = (int8_t)rkb;
-        if (STEP) { ((double *)t.masks())[i] = rbest_old; t.g_old()[i] = (int8_t)rkb_old; }
         if (i == 0) *t.near_old0() = (int8_t)(STEP ? (best_old < p.thr ? kb_old : -1) : (best < p.thr ? kb : -1));
     }
     wave_sync();
@@ -442,12 +462,21 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
     }
     wave_sync();
     FMARL_TICK(4);   // occupancy
-    {   // the matchings (current slots; on a step also the previous slots for observation(0))
-        const int per_env = FMARL_SKIP(p, 64) ? 0 : (STEP ? 2 : 1);
-        if (N <= 4) hungarian_tasks<4>(p, lds, env0, el0w, nenv_w, per_env);
-        else if (N <= 8) hungarian_tasks<8>(p, lds, env0, el0w, nenv_w, per_env);
-        else if (N <= 16) hungarian_tasks<16>(p, lds, env0, el0w, nenv_w, per_env);
-        else hungarian_tasks<32>(p, lds, env0, el0w, nenv_w, per_env);
+    double vd_new = 0.0;   // column potential the matching on the current slots leaves: the next step's warm start
+    if (!FMARL_SKIP(p, 64)) {
+        // the matchings, every env of the wave at once on its own agent lanes: against the current slots, then (a step) against
+        // the previous ones -- that one only serves observation(agent 0) in its "free slot left" branch (ff:707-739): not when
+        // agent 0 sits on a previous slot or every slot is taken (common once agents hold the ring)
+        const SegLanes sl(N, i, elw * N);
+        int *claim = (int *)t.vdual();   // (the potentials' table: every lane has its own entry in `vd`, the distance pass is through)
+        vd_new = hungarian_seg(sl, active, t.pos(), P, rbest, rkb, vd, t.g_new(), claim, 0);
+        if (STEP) {
+            const bool need = active && !(*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0);
+#ifdef FMARL_MEASURE
+            if (active && !need && i == 0) atomicAdd(&g_fmarl_hstat[1][1], 1ull);
+#endif
+            (void)hungarian_seg(sl, need, t.pos(), so, rbest_old, rkb_old, vd, t.g_old(), claim, 1);
+        }
     }
     wave_sync();
     FMARL_TICK(5);   // matchings
@@ -529,10 +558,10 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         const bool keep = STEP && (carry & 2) != 0;   // a span's inner step: the new state stays in registers
         if (keep) {
             c.socc = ((t.words()[2] >> i) & 1u) != 0;
-            c.vd = t.theta()[i];
+            c.vd = vd_new;
         } else if (STEP || emit) {
             p.slot_occ[g] = (double)((t.words()[2] >> i) & 1u);
-            p.match_dual[g] = t.theta()[i];   // column potentials of the matching on the current slots: next step's warm start
+            p.match_dual[g] = vd_new;   // column potentials of the matching on the current slots: next step's warm start
         }
         if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
             uint32_t *r = o.graph_record + g * kFormationRecordWords;

@@ -143,7 +143,10 @@ struct Handle {
     int *ev_steps;      // env steps each profiled launch covers (a span launch: many)
     int ev_cap, ev_n;
     int64_t counts[4];  // fmarl_launch_counts
-    double rot[64];     // formation: (cos, sin) of i * 2 pi / N, copied into the state buffer by fmarl_init_state
+    double rot[64];     // formation: (cos, sin) of i * 2 pi / N
+    double *d_rot;      // ... on the device, owned by the handle (512 bytes; the kernels read THIS table: a caller that zeroes,
+                        // restores or copies its state buffer field by field cannot lose it -- ADVICE round 3).  The state
+                        // buffer's FMARL_F_ROT_TABLE field keeps a copy for readers of older layouts; nothing reads it back
 };
 
 // Entry points that take a handle run on the handle's device whatever the caller's current device is
@@ -201,7 +204,7 @@ Params bind(const Handle *h, void *state) {
     p.st_wall_orient = (int *)(s + o[FMARL_F_STAGE_WALL_ORIENT]);   p.st_goal_match = (int *)(s + o[FMARL_F_STAGE_GOAL_MATCH]);
     p.stage_valid = (int *)(s + o[FMARL_F_STAGE_VALID]);            p.stage_need = (int *)(s + o[FMARL_F_STAGE_NEED]);
     p.match_dual = (double *)(s + o[FMARL_F_MATCH_DUAL]);
-    p.rot_table = (const double2 *)(s + o[FMARL_F_ROT_TABLE]);
+    p.rot_table = h->d_rot ? (const double2 *)h->d_rot : (const double2 *)(s + o[FMARL_F_ROT_TABLE]);
     p.place_fails = (int *)(s + o[FMARL_F_PLACE_FAILS]);             p.st_place_fails = (int *)(s + o[FMARL_F_STAGE_PLACE_FAILS]);
     return p;
 }
@@ -521,6 +524,17 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
             return fail(FMARL_EHIP, "fmarl_create: cannot create the staging stream / events");
         }
     }
+    h->d_rot = nullptr;
+    if (form && h->device >= 0) {   // the slots' rotation table: handle-owned device memory, filled once
+        const int N = p.N;
+        for (int i = 0; i < N; ++i) { const double a = i * ((2 * M_PI) / N); h->rot[2 * i] = cos(a); h->rot[2 * i + 1] = sin(a); }
+        if (hipMalloc((void **)&h->d_rot, sizeof(double) * 2 * N) != hipSuccess ||
+            hipMemcpy(h->d_rot, h->rot, sizeof(double) * 2 * N, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->d_rot) (void)hipFree(h->d_rot);
+            h->d_rot = nullptr;   // (no usable device here: the handle still describes the layout; fmarl_init_state fills the state's copy)
+        }
+    }
     h->lockstep = false; h->host_step = 0; h->episode_started = false; h->captured = false;
     h->ev = nullptr; h->ev_steps = nullptr; h->ev_cap = h->ev_n = 0;
     memset(h->counts, 0, sizeof h->counts);
@@ -547,6 +561,7 @@ int fmarl_destroy(void *handle) {
         if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
         if (h->ev_commit) (void)hipEventDestroy(h->ev_commit);
         if (h->ev_staged) (void)hipEventDestroy(h->ev_staged);
+        if (h->d_rot) (void)hipFree(h->d_rot);
         (void)hipThreadExchangeStreamCaptureMode(&mode);
     }
     delete h;

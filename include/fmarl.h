@@ -173,7 +173,9 @@ enum {
     FMARL_F_MATCH_DUAL,        /* f64 (n, N)     internal (formation): column potentials of the last slot matching, the
                                                  warm start of the next one (any values are valid: the optimum is unique) */
     FMARL_F_ROT_TABLE,         /* f64 (N, 2)     internal (formation), ONE table for all envs: (cos, sin) of i * 2 pi / N -- the slots on
-                                                 the circle are the anchor direction rotated by these (fair_graph_formation.py:630-648) */
+                                                 the circle are the anchor direction rotated by these (fair_graph_formation.py:630-648).
+                                                 A copy only: the kernels read the handle's own table (512 bytes of device memory
+                                                 allocated by fmarl_create), so a caller may zero, restore or copy this field freely */
     FMARL_NUM_FIELDS
 };
 #define FMARL_DTYPE_F64 0

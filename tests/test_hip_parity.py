@@ -1543,6 +1543,9 @@ def test_formation_matchings_do_not_depend_on_their_warm_start():
     g = torch.Generator(device=DEV); g.manual_seed(5)
     a.reset(); b.reset()
     dual = b.field('internal_match_dual')
+    # ... and the state buffer's copy of the slots' rotation table is only a copy: the kernels read the handle's own table, so a
+    # caller that zeroes (or restores, or copies) its state field by field cannot collapse the ring onto landmark 0
+    b.field('internal_rot_table').zero_()
     for t in range(60):
         if t % 3 == 0:
             dual.zero_()

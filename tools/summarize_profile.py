@@ -49,7 +49,7 @@ traffic_full = (2.0 * f_max + w_max) * 1024.0
 tpath = os.path.join(dst, 'pmc_traffic.json')
 allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
 spl = bench['roofline'].get('kernel_steps_per_launch', 1.0)
-allt['%s/%s' % (cfg, mode)] = dict(n_envs=bench['config']['n_envs_per_gpu'], hbm_bytes_per_step=traffic_mean / spl, steps_per_launch=spl, hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
+allt['%s/%s%s' % (cfg, mode, '-ring' if bench['roofline'].get('slots') == 'ring' else '')] = dict(n_envs=bench['config']['n_envs_per_gpu'], hbm_bytes_per_step=traffic_mean / spl, steps_per_launch=spl, hbm_bytes_per_launch=traffic_mean, hbm_bytes_full_launch=traffic_full, fetch_kib_mean=f_mean,
                  write_kib_mean=w_mean, launches=nf, source='%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE '
                  '(separate passes), %s rows, (2*FETCH_SIZE + WRITE_SIZE)*1024' % (tag, ' + '.join(kname) if isinstance(kname, tuple) else kname))
 json.dump(allt, open(tpath, 'w'), indent=1, sort_keys=True)
