@@ -182,6 +182,7 @@ def launch_bytes(cfg, agents, counts0, counts1):
 # (profiles/r4_span_slots.md: 1.24 ms per step at 8 envs per workgroup into slots, 1.33 at 4 / 1.41 at 8 into the same set)
 SPAN_EPB = {}
 SAME_SLOT_EPB = {'cfg3': 4}
+EAGER_EPB = {}   # one launch per step: the library's choice everywhere (tools/ring_epb.py <config> <list> eager)
 # steps per span launch when the records of a run travel to a learner rank (N > 1): a run's records can only leave when its launch
 # has ended, so the LAST run's gather of a timed region is exposed in full -- short runs keep it short, long runs save launches
 GATHER_SPAN_STEPS = 5
@@ -226,7 +227,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
     same = mode == 'span-same'
     run_len = int(mode[4:]) if mode.startswith('span') and mode[4:].isdigit() else 0
     rmode = 'span' if mode.startswith('span') else ('eager' if mode == 'steady' else mode)
-    epb = (SAME_SLOT_EPB if same else SPAN_EPB).get(name, 0) if rmode == 'span' else 0
+    epb = (SAME_SLOT_EPB if same else SPAN_EPB).get(name, 0) if rmode == 'span' else EAGER_EPB.get(name, 0)
     eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=epb, tune_placement=0)
     ring = fm.OutputRing(eng, ep) if (not same and rmode != 'graph' and _use_ring(cfg, n, slots, device)) else None
     g = torch.Generator(device=device)

@@ -2,7 +2,7 @@
 
 A step kernel over 65 536 envs has a head (every workgroup loads, then computes, then stores at the same time) and a
 tail (the last workgroups of the grid run on a nearly empty chip); at BASELINE config 4 the two are about a sixth of the
-launch (``tools/archive/two_stream.py``: the launch time is 0.05 ms + 0.255 ms per 65 536 envs).  Envs are independent
+launch (profiles/NOTES.md, the two-stream probe of round 2: the launch time is 0.05 ms + 0.255 ms per 65 536 envs).  Envs are independent
 (the reference steps them in separate OS processes, onpolicy/envs/env_wrappers.py:951-1026), so consecutive steps of
 DIFFERENT envs need no ordering: the batch is split into k contiguous sub-batches, each a ``RolloutEngine`` on its own
 stream with ``env_offset`` so that the union is the same set of envs with the same random streams, and the tail of one

@@ -13,7 +13,7 @@ mode = sys.argv[3] if len(sys.argv) > 3 else 'span'
 dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
 for epb in epbs:
-    bench.SPAN_EPB[name] = epb
+    (bench.SPAN_EPB if mode.startswith('span') else bench.EAGER_EPB)[name] = epb
     d = bench.secondary_line(name, mode, dev, steps=150, warmup=25)
     print('%s %s epb hint %d -> %d envs per workgroup: kernel %.4f ms per step, frac %.3f, of the store ceiling %.3f (%.4f ms)'
           % (name, mode, epb, d['envs_per_workgroup'], d['kernel_avg_ms'], d['frac'], d['frac_of_box_ceiling'] or 0, d['store_ceiling_ms'] or 0), flush=True)
