@@ -13,7 +13,8 @@
 #define FMARL_TICK_PHASES 16
 #define FMARL_TICK_ROWS 65536
 __device__ unsigned int g_fmarl_ticks[FMARL_TICK_ROWS][FMARL_TICK_PHASES];
-// counters of the slot matchings (tools/phase_ticks.py cfg4): [which][tasks run, tasks skipped, rows through the augmenting search, search iterations]
+// counters of the slot matchings (tools/phase_ticks.py cfg4 with a -DFMARL_MEASURE -DFMARL_HSTAT build: the atomics distort the
+// clocks, so they have a switch of their own): [which][tasks run, tasks skipped, rows through the augmenting search, search iterations]
 __device__ unsigned long long g_fmarl_hstat[2][4];
 #define FMARL_TICKS_BEGIN unsigned int ticks_[FMARL_TICK_PHASES] = {}; unsigned long long tick_ = wall_clock64(); ticks_[15] = (unsigned int)tick_; tick_ = clock64();
 #define FMARL_TICK(k) do { const unsigned long long now_ = clock64(); ticks_[k] += (unsigned int)(now_ - tick_); tick_ = now_; } while (0)

@@ -92,7 +92,7 @@ __device__ __forceinline__ double hungarian_seg(const SegLanes &sl, const bool a
         unmatched = claim[mine] != li;
     }
     uint32_t um = sl.bits(unmatched);
-#ifdef FMARL_MEASURE
+#ifdef FMARL_HSTAT
     if (act && li == 0) { atomicAdd(&g_fmarl_hstat[which][0], 1ull); atomicAdd(&g_fmarl_hstat[which][2], (unsigned long long)__builtin_popcount(um)); }
 #endif
     while (um) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ double hungarian_seg(const SegLanes &sl, const bool a
         int way = -1, j0 = -1, i0 = i, j1 = -1;
         bool usedc = false, in_tree = li == i;
         for (int it = 0; it <= N; ++it) {   // at most N columns can join the tree
-#ifdef FMARL_MEASURE
+#ifdef FMARL_HSTAT
             if (li == 0) atomicAdd(&g_fmarl_hstat[which][3], 1ull);
 #endif
             const double ui0 = bperm_f64(sl.at(i0), u);
@@ -472,7 +472,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         vd_new = hungarian_seg(sl, active, t.pos(), P, rbest, rkb, vd, t.g_new(), claim, 0);
         if (STEP) {
             const bool need = active && !(*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0);
-#ifdef FMARL_MEASURE
+#ifdef FMARL_HSTAT
             if (active && !need && i == 0) atomicAdd(&g_fmarl_hstat[1][1], 1ull);
 #endif
             (void)hungarian_seg(sl, need, t.pos(), so, rbest_old, rkb_old, vd, t.g_old(), claim, 1);

@@ -14,8 +14,8 @@ from fair_marl_amd import _lib  # noqa: E402
 
 NAMES_NAV = ['loads+tables+barrier', 'physics+barrier', 'agent rows+barrier', 'scan statistics', 'stats+hits+reward+stores', 'node_obs',
              'adj (odd workgroups: first)', 'adj (even workgroups: last)']
-NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'obs+reward+state+info',
-              'node rows', 'adj']
+NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'reward+state+info (before the walk)',
+              'obs+occupancy state+record', 'node rows', 'in-kernel reset of the ended envs', 'adj']
 NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
          'obs+record', 'stats+hits+reward', 'state stores', 'info planes', 'node rows', 'adj']
 
@@ -34,7 +34,7 @@ def main():
     for t in range(steps):
         eng.step(tape[t % 25])
     lib = _lib.load()
-    if name == 'cfg4':   # the slot matchings of the LAST step only
+    if name == 'cfg4' and os.environ.get('FMARL_HSTAT'):   # (a -DFMARL_MEASURE -DFMARL_HSTAT build) the slot matchings of the last step
         hs = (C.c_ulonglong * 8)()
         lib.fmarl_measure_hstat.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
         torch.cuda.synchronize()
