@@ -220,57 +220,48 @@ __device__ __forceinline__ void emit_sync(uint32_t nthr) {
 
 // The caller's `nthr` threads (index `thr`) emit the envs [el_begin, el_end) of the workgroup.
 // MODE 0: no policy-edge count, 1: count, 2: decided at run time (`count`; one copy of the loop -- for kernels that inline
-// this more than once and would run out of registers with two copies each, i.e. fairnav_kernel's two passes)
+// this more than once and would run out of registers with two copies each, i.e. fairnav_kernel)
+// Any E, any alignment (round 4): every wave takes a contiguous share of the envs -- their matrices are one contiguous run of
+// floats in memory -- and walks it as a flat index space, 64 entries per store instruction (one dword per lane, 256 contiguous
+// bytes: plain stores of that shape run at the full store rate).  (env, a, b) of a lane's first entry come from two divisions,
+// every later one by stepping 64 = qe E^2 + qa E + qb entries with two carries; per entry two 8-byte LDS reads, one
+// v_sqrt_f32, one store.  (Rounds 1-3: a 16-byte chunk per lane over the whole workgroup's region, two divisions per chunk,
+// range tests and a carry chain per entry, 4-byte fallbacks at ragged ends -- about twice the instructions per entry; adj took
+// 60 % of node_obs's time for 21 % of its bytes at 10 agents, profiles/r4_notes.md.)
 template <int MODE>
 __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOutputs &o, const char *lds, int env0, int el_begin,
                                                  int el_end, uint32_t thr, uint32_t nthr, EdgeCount &ec, bool count) {
     // (what the loop needs of the kernel arguments is pinned in scalar registers: fmarl_dev.h pin_sgpr)
-    const uint32_t E = pin_sgpr((uint32_t)p.E), EE = E * E, total = (el_end - el_begin) * EE;
+    const uint32_t E = pin_sgpr((uint32_t)p.E), EE = E * E;
     const uint32_t k_env = pin_sgpr((uint32_t)p.lds_env_bytes), k_posf = pin_sgpr((uint32_t)p.lds_posf), k_flag = pin_sgpr((uint32_t)p.lds_flag);
     FastDiv dEE, dE;
     dEE.m = pin_sgpr(p.dEE.m); dEE.d = p.dEE.d; dE.m = pin_sgpr(p.dE.m); dE.d = p.dE.d;
-    float *dst = o.adj + ((size_t)env0 + el_begin) * EE;
-    const uint32_t shift = (uint32_t)(((uintptr_t)dst >> 2) & 15), end = shift + total;   // 64-byte aligned frame (lane quads = blocks)
-    float *gal = dst - shift;
-    const char *tb0 = lds + (size_t)el_begin * k_env;
-    for (uint32_t k = thr; k < ((end + 3) >> 2); k += nthr) {
-        // (env, a, b) of the chunk's first entry inside the region by two divisions, of the others by stepping; the loads of
-        // the four entries carry no branches, so they are all in flight together
-        const uint32_t first = 4 * k > shift ? 4 * k - shift : 0;
-        uint32_t elq = dEE.div(first), r = first - elq * EE, a = dE.div(r), b = r - a * E;
-        float v[4];
-        int el[4];
-        uint32_t okm = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t idx = 4 * k + j;
-            const bool in = idx >= shift && idx < end;
-            const char *tb = tb0 + (size_t)(in ? elq : 0u) * k_env;
-            const float2 pa = ((const float2 *)(tb + k_posf))[in ? a : 0u], pb = ((const float2 *)(tb + k_posf))[in ? b : 0u];
-            const bool emit = in && *(const int *)(tb + k_flag) == 0;   // the f32 position table (what a learner-side rebuild has)
-            v[j] = dist_f32(pa.x - pb.x, pa.y - pb.y);
-            el[j] = el_begin + (int)elq;
-            okm |= (emit ? 1u : 0u) << j;
-            if (idx >= shift) {   // step to the next entry
-                const bool wb = ++b == E;
-                b = wb ? 0u : b;
-                a += wb ? 1u : 0u;
-                const bool wa = a == E;
-                a = wa ? 0u : a;
-                elq += wa ? 1u : 0u;
-            }
+    const uint32_t lane = thr & 63, wave = __builtin_amdgcn_readfirstlane(thr >> 6), nwaves = nthr >> 6;
+    const uint32_t cnt = (uint32_t)(el_end - el_begin), per = (cnt + nwaves - 1) / nwaves;   // envs per wave (contiguous shares)
+    const uint32_t w0 = min(cnt, wave * per), w1 = min(cnt, w0 + per);
+    if (w0 >= w1) return;
+    const uint32_t total = (w1 - w0) * EE;
+    const uint32_t qe = dEE.div(64u), r64 = 64u - qe * EE, qa = dE.div(r64), qb = r64 - qa * E;   // 64 entries on: (+qe, +qa, +qb)
+    uint32_t elq = dEE.div(lane), r = lane - elq * EE, a = dE.div(r), b = r - a * E;             // this lane's first entry
+    const char *tb0 = lds + (size_t)(el_begin + w0) * k_env;
+    float *dst = o.adj + ((size_t)env0 + el_begin + w0) * EE;
+    bool any_skip = false;
+    for (uint32_t e = lane; e < w1 - w0; e += 64) any_skip |= *(const int *)(tb0 + (size_t)e * k_env + k_flag) != 0;
+    any_skip = __ballot(any_skip) != 0;   // (uniform: rare -- only reset emissions leave some envs' matrices alone)
+    for (uint32_t idx = lane; idx < total; idx += 64) {
+        const char *tb = tb0 + (size_t)elq * k_env;
+        const float2 pa = ((const float2 *)(tb + k_posf))[a], pb = ((const float2 *)(tb + k_posf))[b];   // the f32 position table (what a learner-side rebuild has)
+        const float d = dist_f32(pa.x - pb.x, pa.y - pb.y);
+        const bool emit = !any_skip || *(const int *)(tb + k_flag) == 0;
+        if (emit) {
+            dst[idx] = d;
+            if (MODE == 1 || (MODE == 2 && count)) ec.add(el_begin + (int)(w0 + elq), d);
         }
-        if (MODE == 1 || (MODE == 2 && count)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((okm >> j) & 1u) ec.add(el[j], v[j]);
-        }
-        if (okm == 15u) ((float4 *)gal)[k] = make_float4(v[0], v[1], v[2], v[3]);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((okm >> j) & 1u) gal[4 * k + j] = v[j];
-        }
+        b += qb; a += qa; elq += qe;
+        const bool cb = b >= E;
+        b -= cb ? E : 0u; a += cb ? 1u : 0u;
+        const bool ca = a >= E;
+        a -= ca ? E : 0u; elq += ca ? 1u : 0u;
     }
 }
 
