@@ -98,26 +98,37 @@ def _scatter_order(chunks):
     return o
 
 
-def store_ceiling(device, step_bytes, steps=1, launches=4):
+def store_ceiling(device, step_bytes, steps=1, launches=4, dst=None):
     """The box's write ceiling for a launch that writes `steps` steps' bytes: the best pure 16-byte store stream over that
     byte count (fmarl_store_stream: kernels that do nothing but write, in the shapes the emission writes in -- a workgroup's
     contiguous chunk, a wave's contiguous quarter of one -- in dispatch order and scattered over the buffer).  No step kernel
     can be faster than its own store stream, so kernel time per step / this figure <= 1 by construction -- unlike the
     emission-only launch of rounds 2-3 (`emission_only_ms`), which a span could beat.  Capped at 8 steps' bytes (66 GB at
     cfg 3): a longer stream only amortises the same head and tail further (24 steps: 1.151 ms per step, one step: 1.163).
+    `dst`: the tensor to write into -- the run's own output buffer (the node_obs slots of the ring, or the engine's node_obs): how
+    fast a store stream runs depends on the physical pages a buffer got (the same stream measured 5.6 and 7.1 TB/s in two
+    processes of one box, profiles/r4_notes.md), so the ceiling is taken on the pages the kernel itself wrote; a buffer smaller
+    than the byte count is written whole and the time scaled by bytes.  Without `dst` a scratch buffer is allocated.
     Returns dict(ms_per_step, TBps, shape, streams={shape: ms per step})."""
     import ctypes as C
     from fair_marl_amd import _lib
     lib = _lib.load()
     step_bytes = int(step_bytes) // 16 * 16
     k = max(1, min(int(round(steps)), 8))
-    free, _ = torch.cuda.mem_get_info(device)
-    while k > 1 and k * step_bytes > free * 0.8:
-        k -= 1
-    nbytes = k * step_bytes
-    if nbytes < (1 << 16) or nbytes > free * 0.8:
-        return None
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if dst is not None:
+        cap = dst.numel() * dst.element_size() // 16 * 16
+        nbytes = min(k * step_bytes, cap)
+        if nbytes < (1 << 16):
+            return None
+        buf = dst.view(-1).view(torch.uint8)[:nbytes]
+    else:
+        free, _ = torch.cuda.mem_get_info(device)
+        while k > 1 and k * step_bytes > free * 0.8:
+            k -= 1
+        nbytes = k * step_bytes
+        if nbytes < (1 << 16) or nbytes > free * 0.8:
+            return None
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = {}
@@ -132,11 +143,13 @@ def store_ceiling(device, step_bytes, steps=1, launches=4):
             call()
         e1.record()
         e1.synchronize()
-        out['shape %d, %d KB chunks, %s' % (shape, chunk >> 10, 'scattered' if order > 1 else 'dispatch order')] = e0.elapsed_time(e1) / launches / k
+        out['shape %d, %d KB chunks, %s' % (shape, chunk >> 10, 'scattered' if order > 1 else 'dispatch order')] = e0.elapsed_time(e1) / launches * step_bytes / nbytes
     del buf
-    torch.cuda.empty_cache()
+    if dst is None:
+        torch.cuda.empty_cache()
     best = min(out, key=out.get)
-    return dict(ms_per_step=out[best], TBps=step_bytes / out[best] / 1e9, shape=best, steps_per_launch=k, streams=out)
+    return dict(ms_per_step=out[best], TBps=step_bytes / out[best] / 1e9, shape=best, bytes_per_launch=nbytes,
+                destination='the run\'s own node_obs buffer' if dst is not None else 'a scratch buffer', streams=out)
 
 
 def emission_only_ms(eng, launches=10):
@@ -276,10 +289,12 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
     steps_per_launch = (c1[0] - c0[0]) / max(1, len(kernel_ms))
     epw = eng.envs_per_workgroup
     ring_bytes = ring.nbytes if ring is not None else 0
+    # (on the pages the kernel wrote: the ring's node_obs slots, else the engine's node_obs)
+    ceil = store_ceiling(device, per_step, steps_per_launch if rmode == 'span' else 1,
+                         dst=(ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs))
     eng.close()
     del eng, tape, ring
     torch.cuda.empty_cache()
-    ceil = store_ceiling(device, per_step, steps_per_launch if rmode == 'span' else 1)
     out = dict(config=name, mode=mode, workload=spec['workload'] % n,
                launch={'eager': 'one fmarl_step call per step', 'span': span_text,
                        'graph': 'one hipGraph replay per episode, the staged reset a forked branch of the graph (kernel_avg_ms from an eager pass)'}[rmode],
@@ -835,14 +850,17 @@ def main():
         else:
             exchange_text = 'gather of obs/reward/done to rank 0 every step, %d B per agent-step' % StepRecord.bytes_per_agent_step(cfg.obs_dim, graph_words)
         ring_bytes = ring.nbytes if ring is not None else 0
-        # the box's write ceiling needs room: the engine and the time slots go first (the secondary lines build their own)
+        # the box's write ceiling, on the pages the kernel itself wrote (the ring's node_obs slots, else the engine's node_obs);
+        # then the engine and the time slots go (the secondary lines build their own)
+        ceil = None
         if pipe is None:
+            ceil = store_ceiling(device, bytes_per_step / sub, steps_per_launch,
+                                 dst=(ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs))
             eng.close()
             set_cache.clear()
             del eng, ring, tape
             lr_node = lr_adj = None
             torch.cuda.empty_cache()
-        ceil = store_ceiling(device, bytes_per_step / sub, steps_per_launch) if pipe is None else None
         out = {
             'metric': 'env agent-steps/sec (n_envs x n_agents / wall-s), %s random-action rollout' % cfg.scenario_name,
             'value': world * agents * K / elapsed, 'unit': 'agent-steps/s', 'n_gpus': world, 'n_ranks_seen': ranks_seen,

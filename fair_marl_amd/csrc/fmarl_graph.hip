@@ -263,22 +263,26 @@ __global__ __launch_bounds__(256) void info_mean_kernel(const float *info, doubl
 // workgroups that live for the whole launch, as a span's do -- chunk ((b + k grid) * order) mod n_chunks for k = 1, 2, ...: order 1
 // is dispatch order (the resident workgroups write one compact window), a large odd order scatters them over the buffer.
 // The value depends on the address, so no two stores are equal.
-template <int SHAPE>
+typedef float fmarl_f4 __attribute__((ext_vector_type(4)));
+template <int SHAPE>   // shapes 3 / 4: 1 / 2 with non-temporal stores (experiments: no faster than plain stores on MI355X)
 __global__ __launch_bounds__(256) void store_stream_kernel(float4 *dst, size_t n16, uint32_t chunk16, uint32_t n_chunks, uint32_t order) {
+    auto put = [&](size_t i) {
+        if (SHAPE >= 3) { const fmarl_f4 w = {(float)(uint32_t)i, 1.f, 2.f, 3.f}; __builtin_nontemporal_store(w, (fmarl_f4 *)&dst[i]); }
+        else dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+    };
     if (SHAPE == 0) {
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
-            dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) put(i);
         return;
     }
     for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
         const uint32_t chunk = (uint32_t)(((uint64_t)c * order) % n_chunks);
         const size_t b0 = (size_t)chunk * chunk16, be = b0 + chunk16 < n16 ? b0 + chunk16 : n16;
-        if (SHAPE == 1) {
-            for (size_t i = b0 + threadIdx.x; i < be; i += 256) dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+        if (SHAPE == 1 || SHAPE == 3) {
+            for (size_t i = b0 + threadIdx.x; i < be; i += 256) put(i);
         } else {
             const uint32_t per_wave = (chunk16 + 3) / 4, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
             const size_t b = b0 + (size_t)wave * per_wave, e = b + per_wave < be ? b + per_wave : be;
-            for (size_t i = b + lane; i < e; i += 64) dst[i] = make_float4((float)(uint32_t)i, 1.f, 2.f, 3.f);
+            for (size_t i = b + lane; i < e; i += 64) put(i);
         }
     }
 }

@@ -839,8 +839,8 @@ int fmarl_poison_lds(void *handle, void *stream) {
 }
 
 int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, int order, int persist, void *stream) {
-    if (!dst || ((uintptr_t)dst & 15) || (bytes & 15) || shape < 0 || shape > 2 || order < 1 || persist < 0)
-        return fail(FMARL_EINVAL, "fmarl_store_stream: dst / bytes must be 16-byte multiples, shape 0..2, order >= 1, persist >= 0");
+    if (!dst || ((uintptr_t)dst & 15) || (bytes & 15) || shape < 0 || shape > 4 || order < 1 || persist < 0)
+        return fail(FMARL_EINVAL, "fmarl_store_stream: dst / bytes must be 16-byte multiples, shape 0..4, order >= 1, persist >= 0");
     if (shape != 0 && (chunk_bytes < 4096 || (chunk_bytes & 15) || chunk_bytes > ((size_t)1 << 34)))
         return fail(FMARL_EINVAL, "fmarl_store_stream: chunk_bytes must be a 16-byte multiple of at least 4096");
     const size_t n16 = bytes / 16, c16 = shape ? chunk_bytes / 16 : 0;
@@ -856,7 +856,9 @@ int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, i
     hipStream_t st = (hipStream_t)stream;
     if (shape == 0) hipLaunchKernelGGL(fmarl::store_stream_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, 0u, 0u, 1u);
     else if (shape == 1) hipLaunchKernelGGL(fmarl::store_stream_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
-    else hipLaunchKernelGGL(fmarl::store_stream_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
+    else if (shape == 2) hipLaunchKernelGGL(fmarl::store_stream_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
+    else if (shape == 3) hipLaunchKernelGGL(fmarl::store_stream_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
+    else hipLaunchKernelGGL(fmarl::store_stream_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

@@ -294,7 +294,8 @@ int fmarl_poison_lds(void *handle, void *stream);
 
 /* Measurement aid (bench.py `store_ceiling_ms`): a kernel that does nothing but write `bytes` bytes to `dst` with 16-byte
  * stores, in the shapes the emission writes in -- shape 0: flat grid-stride stream; 1: a workgroup streams a contiguous chunk of
- * `chunk_bytes`; 2: every wave streams its own contiguous quarter of such a chunk (1 KiB per store instruction).  Workgroup b
+ * `chunk_bytes`; 2: every wave streams its own contiguous quarter of such a chunk (1 KiB per store instruction); 3 / 4: shapes
+ * 1 / 2 with non-temporal stores.  Workgroup b
  * writes chunk (b * order) mod n_chunks (order 1 = dispatch order; a large order coprime with the number of chunks scatters the
  * resident workgroups over the buffer); persist > 0: that many workgroups live for the whole launch and take chunks round-robin
  * (a span's long-lived workgroups), 0: one workgroup per chunk.  The best of them over the byte count of a step is the box's
