@@ -98,13 +98,17 @@ def _scatter_order(chunks):
     return o
 
 
-def store_ceiling(device, step_bytes, steps=1, launches=4, dst=None):
+def store_ceiling(device, step_bytes, steps=1, launches=2, dst=None, earlier=None):
     """The box's write ceiling for a launch that writes `steps` steps' bytes: the best pure 16-byte store stream over that
     byte count (fmarl_store_stream: kernels that do nothing but write, in the shapes the emission writes in -- a workgroup's
     contiguous chunk, a wave's contiguous quarter of one -- in dispatch order and scattered over the buffer).  No step kernel
     can be faster than its own store stream, so kernel time per step / this figure <= 1 by construction -- unlike the
-    emission-only launch of rounds 2-3 (`emission_only_ms`), which a span could beat.  Capped at 8 steps' bytes (66 GB at
+    emission-only launch of rounds 2-3 (`emission_only_ms`), which a span could beat.  Capped at 4 steps' bytes (33 GB at
     cfg 3): a longer stream only amortises the same head and tail further (24 steps: 1.151 ms per step, one step: 1.163).
+    A ceiling is the FASTEST the box writes: every launch is timed on its own and the best one counts, and `earlier` (the same
+    measurement taken before the run's warm-up) is merged in -- boxes slow down under sustained store load (a 300-step region ran
+    at 1.51 ms per step on a box whose 20-step region ran at 1.23, profiles/r4_notes.md), and a ceiling taken only after the
+    timed region would be beaten by a short region.
     `dst`: the tensor to write into -- the run's own output buffer (the node_obs slots of the ring, or the engine's node_obs): how
     fast a store stream runs depends on the physical pages a buffer got (the same stream measured 5.6 and 7.1 TB/s in two
     processes of one box, profiles/r4_notes.md), so the ceiling is taken on the pages the kernel itself wrote; a buffer smaller
@@ -114,7 +118,7 @@ def store_ceiling(device, step_bytes, steps=1, launches=4, dst=None):
     from fair_marl_amd import _lib
     lib = _lib.load()
     step_bytes = int(step_bytes) // 16 * 16
-    k = max(1, min(int(round(steps)), 8))
+    k = max(1, min(int(round(steps)), 4))
     if dst is not None:
         cap = dst.numel() * dst.element_size() // 16 * 16
         nbytes = min(k * step_bytes, cap)
@@ -130,26 +134,31 @@ def store_ceiling(device, step_bytes, steps=1, launches=4, dst=None):
             return None
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = {}
     for shape, chunk, scat in ((1, 1 << 20, False), (1, 1 << 20, True), (2, 1 << 20, True), (2, 1 << 16, True)):
         chunk = min(chunk, max(4096, nbytes // 64 // 16 * 16))
         chunks = (nbytes // 16 + chunk // 16 - 1) // (chunk // 16)
         order = _scatter_order(chunks) if scat and chunks >= 64 else 1
         call = lambda: _lib.check(lib.fmarl_store_stream(buf.data_ptr(), nbytes, shape, chunk, order, 0, st), 'fmarl_store_stream')  # noqa: E731
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
         call()
-        e0.record()
-        for _ in range(launches):
+        ev[0].record()
+        for j in range(launches):
             call()
-        e1.record()
-        e1.synchronize()
-        out['shape %d, %d KB chunks, %s' % (shape, chunk >> 10, 'scattered' if order > 1 else 'dispatch order')] = e0.elapsed_time(e1) / launches * step_bytes / nbytes
+            ev[j + 1].record()
+        ev[-1].synchronize()
+        best_ms = min(ev[j].elapsed_time(ev[j + 1]) for j in range(launches))
+        out['shape %d, %d KB chunks, %s' % (shape, chunk >> 10, 'scattered' if order > 1 else 'dispatch order')] = best_ms * step_bytes / nbytes
     del buf
     if dst is None:
         torch.cuda.empty_cache()
+    if earlier:
+        for key, ms in earlier['streams'].items():
+            out[key] = min(out.get(key, ms), ms)
     best = min(out, key=out.get)
     return dict(ms_per_step=out[best], TBps=step_bytes / out[best] / 1e9, shape=best, bytes_per_launch=nbytes,
-                destination='the run\'s own node_obs buffer' if dst is not None else 'a scratch buffer', streams=out)
+                destination='the run\'s own node_obs buffer' if dst is not None else 'a scratch buffer',
+                basis='best single launch per stream, before the warm-up and after the timed region' if earlier else 'best single launch per stream', streams=out)
 
 
 def emission_only_ms(eng, launches=10):
@@ -247,6 +256,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
     eng.reset()
+    agents_bytes = algorithmic_bytes(cfg) * n * cfg.N
+    ceil_dst = ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs
+    ceil0 = store_ceiling(device, agents_bytes, (run_len or ep - 1) if rmode == 'span' else 1, dst=ceil_dst) if ceil_dst is not None else None
 
     def episode(m):
         if run_len and m == 'span':   # runs of at most run_len steps (fnmarl_step_span splits at the episode end by itself)
@@ -290,10 +302,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
     epw = eng.envs_per_workgroup
     ring_bytes = ring.nbytes if ring is not None else 0
     # (on the pages the kernel wrote: the ring's node_obs slots, else the engine's node_obs)
-    ceil = store_ceiling(device, per_step, steps_per_launch if rmode == 'span' else 1,
-                         dst=(ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs))
+    ceil = store_ceiling(device, agents_bytes, steps_per_launch if rmode == 'span' else 1, dst=ceil_dst, earlier=ceil0) if ceil_dst is not None else None
     eng.close()
-    del eng, tape, ring
+    del eng, tape, ring, ceil_dst
     torch.cuda.empty_cache()
     out = dict(config=name, mode=mode, workload=spec['workload'] % n,
                launch={'eager': 'one fmarl_step call per step', 'span': span_text,
@@ -683,6 +694,10 @@ def main():
         pipe.reset()
     else:
         eng.reset()
+    # the box's write ceiling, first reading: before the warm-up, on the buffer the run writes (second reading after the timed region)
+    ceil_dst = None if pipe is not None else (ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs)
+    ceil0 = (store_ceiling(device, algorithmic_bytes(cfg) * n_envs * cfg.N, min(span_steps, ep - 1) if launch == 'span' else 1, dst=ceil_dst)
+             if rank == 0 and ceil_dst is not None else None)
     if gather and episodes and pipe is None:   # the first episode's record
         eng.pack_episode(out=tg.episode_record())
         tg.submit_episode()
@@ -854,11 +869,11 @@ def main():
         # then the engine and the time slots go (the secondary lines build their own)
         ceil = None
         if pipe is None:
-            ceil = store_ceiling(device, bytes_per_step / sub, steps_per_launch,
-                                 dst=(ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs))
+            if ceil_dst is not None:
+                ceil = store_ceiling(device, algorithmic_bytes(cfg) * agents, steps_per_launch, dst=ceil_dst, earlier=ceil0)
             eng.close()
             set_cache.clear()
-            del eng, ring, tape
+            del eng, ring, tape, ceil_dst
             lr_node = lr_adj = None
             torch.cuda.empty_cache()
         out = {
