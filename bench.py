@@ -120,8 +120,11 @@ def store_ceiling(device, step_bytes, steps=1, launches=2, dst=None, earlier=Non
     step_bytes = int(step_bytes) // 16 * 16
     k = max(1, min(int(round(steps)), 4))
     if dst is not None:
+        # a span writes all its time slots at once (its workgroups drift apart in time): the comparable stream covers the whole
+        # buffer -- the same footprint over the HBM stacks -- not only its first slots (a 33 GB corner of the ring took a stream at
+        # 5.97 TB/s on a box whose span kernel wrote the 205 GB ring at 6.88: profiles/r4_notes.md)
         cap = dst.numel() * dst.element_size() // 16 * 16
-        nbytes = min(k * step_bytes, cap)
+        nbytes = min((24 if steps > 1 else 1) * step_bytes, cap)
         if nbytes < (1 << 16):
             return None
         buf = dst.view(-1).view(torch.uint8)[:nbytes]
@@ -135,7 +138,7 @@ def store_ceiling(device, step_bytes, steps=1, launches=2, dst=None, earlier=Non
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
     st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     out = {}
-    for shape, chunk, scat in ((1, 1 << 20, False), (1, 1 << 20, True), (2, 1 << 20, True), (2, 1 << 16, True)):
+    for shape, chunk, scat in ((1, 1 << 20, False), (2, 1 << 20, True), (2, 1 << 16, True)):
         chunk = min(chunk, max(4096, nbytes // 64 // 16 * 16))
         chunks = (nbytes // 16 + chunk // 16 - 1) // (chunk // 16)
         order = _scatter_order(chunks) if scat and chunks >= 64 else 1
@@ -219,7 +222,7 @@ def _use_ring(cfg, n_envs, slots, device):
     return per_slot * cfg.episode_length < free * 0.85
 
 
-def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
+def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena=None):
     """One more BASELINE config on this GPU: fresh engine, `warmup` untimed steps (whole episodes), `steps` timed steps (whole
     episodes), synchronised on both sides, all through RolloutEngine.rollout(tape, mode, ring):
       'eager' = one fmarl_step call per step (what a policy in the loop gets);
@@ -231,7 +234,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
       'graph' = one hipGraph replay per episode (launch-bound batches; one output set);
       'steady' (nav_fairassign_fairrew_formation_graph) = one launch per step with episodes ending at all phases (STEADY);
       'pipeline<k>' = k sub-batches on k streams.
-    Every step writes its own time slot of an episode-long ring (`slots`: 'ring') except where the mode says otherwise.
+    Every step writes its own time slot of an episode-long ring (`slots`: 'ring') except where the mode says otherwise; `arena` = a
+    ring of the same shape whose arrays are taken over (the headline's: a large allocation made after another one was freed is, on
+    some boxes, 15 % slower to stream into than the first one of the process -- profiles/r4_notes.md).
     kernel_avg_ms is per STEP in every mode (a span launch's duration divided by its steps)."""
     spec = CONFIGS[name]
     env_kw = dict(spec['env'])
@@ -251,13 +256,17 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring'):
     rmode = 'span' if mode.startswith('span') else ('eager' if mode == 'steady' else mode)
     epb = (SAME_SLOT_EPB if same else SPAN_EPB).get(name, 0) if rmode == 'span' else EAGER_EPB.get(name, 0)
     eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=epb, tune_placement=0)
-    ring = fm.OutputRing(eng, ep) if (not same and rmode != 'graph' and _use_ring(cfg, n, slots, device)) else None
+    ring = None
+    if not same and rmode != 'graph' and (arena is not None or _use_ring(cfg, n, slots, device)):
+        ring = fm.OutputRing(eng, ep, like=arena)
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
     eng.reset()
     agents_bytes = algorithmic_bytes(cfg) * n * cfg.N
-    ceil_dst = ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs
+    # (the write ceiling is read where the run writes time slots: a stream into ONE output set's 6.6 GB covers a smaller footprint than
+    # the kernel's own node_obs + adj and is no ceiling for it)
+    ceil_dst = ring.node_obs if ring is not None else None
     ceil0 = store_ceiling(device, agents_bytes, (run_len or ep - 1) if rmode == 'span' else 1, dst=ceil_dst) if ceil_dst is not None else None
 
     def episode(m):
@@ -873,6 +882,7 @@ def main():
                 ceil = store_ceiling(device, algorithmic_bytes(cfg) * agents, steps_per_launch, dst=ceil_dst, earlier=ceil0)
             eng.close()
             set_cache.clear()
+            arena = ring   # (its arrays serve the headline config's secondary entries)
             del eng, ring, tape, ceil_dst
             lr_node = lr_adj = None
             torch.cuda.empty_cache()
@@ -977,7 +987,12 @@ def main():
             t_sec = time.perf_counter()
             # the headline config again over 300 steps (as spans, one launch per step, in runs of GATHER_SPAN_STEPS, into one output
             # set), then every other BASELINE config that fits one GPU
-            out['secondary'] = [secondary_line(name, mode, device) for name, mode in SECONDARY]
+            out['secondary'] = []
+            for name, mode in SECONDARY:
+                if name != args.config and arena is not None:   # the headline config's entries come first: then its slots go
+                    arena = None
+                    torch.cuda.empty_cache()
+                out['secondary'].append(secondary_line(name, mode, device, arena=arena if name == args.config else None))
             out['secondary_wall_s'] = time.perf_counter() - t_sec
             for e in out['secondary']:   # the other slot mode of the headline config, over 300 steps
                 if e['config'] == args.config and e['mode'] == 'span-same':

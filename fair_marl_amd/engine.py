@@ -719,23 +719,41 @@ class OutputRing(object):
     ``engine.use_outputs(ring.sets[t0]); engine.step_span(tape, strides=ring.strides)`` -- leaves step t in slot t0 + t.
     Every step of a rollout has a slot of its own: its outputs exist afterwards and every byte is written once per pass over
     the ring.  Nothing but the time slots (no masks, no policy arrays: ``DeviceRolloutBuffer`` is the runner's buffer).
-    At BASELINE config 3 a slot is 8.3 GB: an episode of 25 slots takes 208 of the 288 GB."""
+    At BASELINE config 3 a slot is 8.3 GB: an episode of 25 slots takes 205 of the 288 GB.
 
-    def __init__(self, engine, slots):
+    ``like``: another ring of the same shape (same n_envs, config, slots) whose ARRAYS are taken over instead of allocating new
+    ones -- a second engine over the same memory.  Worth it for large rings: the first large allocation of a process comes out
+    of pristine device memory; one made after it has been freed is, on some boxes, 15 % slower to stream into
+    (profiles/r4_notes.md), so allocate the big buffers first and keep them."""
+
+    def __init__(self, engine, slots, like=None):
         eng, cfg = engine, engine.cfg
         n, N, E, D, F = eng.n_envs, cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat
         self.engine, self.slots = eng, int(slots)
         T = self.slots
+        taken = iter(())
+        if like is not None:
+            taken = iter([like.obs, like.reward, like.done, like.node_obs, like.adj_env, like.info_planes, like.edge_nnz, like.graph_record])
+
+        def mk(*shape, dtype=torch.float32):
+            old = next(taken, None)
+            if like is not None:
+                if old is None or tuple(old.shape) != tuple(shape) or old.dtype != dtype or old.device != eng.device:
+                    raise ValueError('OutputRing(like=...): the other ring has no %s array of shape %s' % (dtype, (shape,)))
+                return old
+            return torch.empty(*shape, dtype=dtype, device=eng.device)
+        def skip():   # an array this ring does not have: step over the other ring's
+            next(taken, None)
+            return None
         with torch.cuda.device(eng.device):
-            mk = lambda *shape, dtype=torch.float32: torch.empty(*shape, dtype=dtype, device=eng.device)  # noqa: E731
             self.obs = mk(T, n, N, D)
             self.reward = mk(T, n, N)
             self.done = mk(T, n, N, dtype=torch.uint8)
-            self.node_obs = mk(T, n, N, E, F) if eng.emit_graph else None
-            self.adj_env = mk(T, n, E, E) if eng.emit_graph else None
-            self.info_planes = mk(T, _lib.INFO_WIDTH, n, N) if eng.emit_info else None
-            self.edge_nnz = mk(T, n, dtype=torch.int32) if eng.count_edges else None
-            self.graph_record = mk(T, n, N, eng.step_record_words, dtype=torch.int32) if eng.emit_graph_record else None
+            self.node_obs = mk(T, n, N, E, F) if eng.emit_graph else skip()
+            self.adj_env = mk(T, n, E, E) if eng.emit_graph else skip()
+            self.info_planes = mk(T, _lib.INFO_WIDTH, n, N) if eng.emit_info else skip()
+            self.edge_nnz = mk(T, n, dtype=torch.int32) if eng.count_edges else skip()
+            self.graph_record = mk(T, n, N, eng.step_record_words, dtype=torch.int32) if eng.emit_graph_record else skip()
         pick = lambda a, t: a[t] if a is not None else None  # noqa: E731
         self.sets = [eng.new_output_set(obs=self.obs[t], reward=self.reward[t], done=self.done[t], node_obs=pick(self.node_obs, t),
                                         adj_env=pick(self.adj_env, t), info_planes=pick(self.info_planes, t),
