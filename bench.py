@@ -704,7 +704,7 @@ def main():
     else:
         eng.reset()
     # the box's write ceiling, first reading: before the warm-up, on the buffer the run writes (second reading after the timed region)
-    ceil_dst = None if pipe is not None else (ring.node_obs if ring is not None and ring.node_obs is not None else eng.node_obs)
+    ceil_dst = ring.node_obs if (pipe is None and ring is not None) else None   # (read where the run writes time slots: secondary_line)
     ceil0 = (store_ceiling(device, algorithmic_bytes(cfg) * n_envs * cfg.N, min(span_steps, ep - 1) if launch == 'span' else 1, dst=ceil_dst)
              if rank == 0 and ceil_dst is not None else None)
     if gather and episodes and pipe is None:   # the first episode's record
