@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "fmarl_dev.h"
 #include "fmarl_kernels.h"
@@ -860,6 +861,80 @@ int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, i
     else if (shape == 3) hipLaunchKernelGGL(fmarl::store_stream_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
     else hipLaunchKernelGGL(fmarl::store_stream_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
     HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+// ---- time-slot arrays with interleaved physical memory (include/fmarl.h fmarl_ring_alloc)
+namespace {
+struct RingAlloc {
+    void *ptr = nullptr;
+    size_t total = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    bool mapped = false;
+};
+void ring_release(RingAlloc *r) {
+    if (!r) return;
+    if (r->ptr && r->mapped) (void)hipMemUnmap(r->ptr, r->total);
+    for (auto h : r->handles) (void)hipMemRelease(h);
+    if (r->ptr) (void)hipMemAddressFree(r->ptr, r->total);
+    delete r;
+}
+}  // namespace
+
+int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **base, void **cookie) {
+    if (!base || !cookie || slots < 1 || slot_bytes == 0) return fail(FMARL_EINVAL, "fmarl_ring_alloc: bad argument");
+    *base = *cookie = nullptr;
+    int dev = 0, vmm = 0;
+    HIP_OK(hipGetDevice(&dev));
+    HIP_OK(hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev));
+    if (!vmm) return fail(FMARL_EHIP, "fmarl_ring_alloc: the device has no virtual memory management");
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0;
+    HIP_OK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran < 4096) gran = 4096;
+    if (piece_bytes == 0) {   // the largest power of two <= 16 MiB that divides a slot; larger while the handles would exceed 32 768
+        piece_bytes = (size_t)16 << 20;
+        while (piece_bytes > gran && slot_bytes % piece_bytes) piece_bytes >>= 1;
+        while (slot_bytes % (piece_bytes * 2) == 0 && (slot_bytes / piece_bytes) * (size_t)slots > 32768) piece_bytes *= 2;
+    }
+    if (piece_bytes < gran || piece_bytes % gran || slot_bytes % piece_bytes)
+        return fail(FMARL_EINVAL, "fmarl_ring_alloc: a slot must be a whole number of pieces, a piece a multiple of the allocation granularity");
+    const size_t per_slot = slot_bytes / piece_bytes, count = per_slot * (size_t)slots;
+    RingAlloc *r = new (std::nothrow) RingAlloc();
+    if (!r) return fail(FMARL_EINVAL, "fmarl_ring_alloc: out of host memory");
+    r->total = slot_bytes * (size_t)slots;
+    hipError_t e = hipMemAddressReserve(&r->ptr, r->total, piece_bytes, nullptr, 0);
+    if (e != hipSuccess) { r->ptr = nullptr; ring_release(r); return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e)); }
+    r->handles.reserve(count);
+    for (size_t k = 0; k < count && e == hipSuccess; ++k) {   // physical pieces, in creation order
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, piece_bytes, &prop, 0);
+        if (e == hipSuccess) r->handles.push_back(h);
+    }
+    // virtual piece j of slot t <- physical piece j * slots + t: a slot's pieces are spread evenly over the whole allocation
+    for (size_t t = 0; t < (size_t)slots && e == hipSuccess; ++t)
+        for (size_t j = 0; j < per_slot && e == hipSuccess; ++j)
+            e = hipMemMap((char *)r->ptr + (t * per_slot + j) * piece_bytes, piece_bytes, 0, r->handles[j * (size_t)slots + t], 0);
+    if (e == hipSuccess) {
+        r->mapped = true;
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(r->ptr, r->total, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (!r->mapped && r->ptr) { (void)hipMemUnmap(r->ptr, r->total); }
+        ring_release(r);
+        return fail(FMARL_EHIP, "fmarl_ring_alloc: %s", hipGetErrorString(e));
+    }
+    *base = r->ptr; *cookie = r;
+    return FMARL_OK;
+}
+
+int fmarl_ring_free(void *cookie) {
+    if (!cookie) return fail(FMARL_EINVAL, "fmarl_ring_free: null cookie");
+    ring_release((RingAlloc *)cookie);
     return FMARL_OK;
 }
 

@@ -8,6 +8,7 @@ agent as a stride-0 ``expand`` (the reference returns N identical copies,
 multiagent/custom_scenarios/navigation_graph.py:1033).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -712,6 +713,49 @@ class RolloutEngine:
             pass
 
 
+class _SpreadBlock(object):
+    """Device memory of ``fmarl_ring_alloc`` -- time slots whose physical memory is interleaved piece by piece -- presented through
+    ``__cuda_array_interface__``; tensors made from it (``torch.as_tensor``) keep it alive, the memory is unmapped with the last one."""
+
+    def __init__(self, lib, device, shape, slot_bytes, slots):
+        base, cookie = C.c_void_p(), C.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.fmarl_ring_alloc(int(slot_bytes), int(slots), 0, C.byref(base), C.byref(cookie))
+        if rc:
+            raise MemoryError(lib.fmarl_last_error().decode())
+        self._lib, self._cookie, self._device = lib, cookie, device
+        self.__cuda_array_interface__ = dict(shape=tuple(int(v) for v in shape), typestr='<f4', data=(int(base.value), False), version=2)
+
+    def __del__(self):
+        try:
+            if self._cookie is not None and self._cookie.value:
+                torch.cuda.synchronize(self._device)   # no launch may still write here
+                self._lib.fmarl_ring_free(self._cookie)
+                self._cookie = None
+        except Exception:
+            pass
+
+
+def alloc_time_slots(lib, device, shape, spread=None, zero=False):
+    """A float32 device tensor of ``shape`` = (T, ...) for T time slots: virtually contiguous, and -- ``spread`` True, or None and a slot
+    is 64 MiB or more -- with its physical memory interleaved piece by piece over the whole array (``fmarl_ring_alloc``; see
+    ``OutputRing``).  Falls back to a plain allocation where the slot size has no suitable divisor or the device has no virtual
+    memory management (``spread=True`` raises instead).  -> (tensor, interleaved?)"""
+    T, slot_bytes = int(shape[0]), 4 * int(np.prod(shape[1:]))
+    if spread is None and os.environ.get('FMARL_RING_SPREAD') == '0':   # (measurement aid: plain allocations)
+        spread = False
+    if T >= 2 and (spread or (spread is None and slot_bytes >= (64 << 20))):
+        try:
+            t = torch.as_tensor(_SpreadBlock(lib, device, shape, slot_bytes, T), device=device)
+            if zero:
+                t.zero_()
+            return t, True
+        except MemoryError:
+            if spread:
+                raise
+    return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device), False
+
+
 class OutputRing(object):
     """``slots`` time slots of step outputs, laid out (slots, n, ...) like the reference's rollout storage
     (onpolicy/utils/graph_buffer.py:84-110): slot t is an output set of the engine (``sets[t]``), and ``strides`` are the
@@ -724,9 +768,14 @@ class OutputRing(object):
     ``like``: another ring of the same shape (same n_envs, config, slots) whose ARRAYS are taken over instead of allocating new
     ones -- a second engine over the same memory.  Worth it for large rings: the first large allocation of a process comes out
     of pristine device memory; one made after it has been freed is, on some boxes, 15 % slower to stream into
-    (profiles/r4_notes.md), so allocate the big buffers first and keep them."""
+    (profiles/r4_notes.md), so allocate the big buffers first and keep them.
 
-    def __init__(self, engine, slots, like=None):
+    ``spread`` (default: on for node_obs / adj arrays whose slots are 64 MiB and more): the slots stay virtually contiguous --
+    ``node_obs[t]`` is an ordinary contiguous tensor -- but their physical memory is interleaved in pieces over the whole array
+    (``fmarl_ring_alloc``): MI355X writes ONE 8 GB region at 5.7-6.0 TB/s and the same bytes spread over 160 GB at 6.8-7.1, so a
+    launch that fills a single slot (``step``: a policy in the loop) runs at the rate a whole rollout gets."""
+
+    def __init__(self, engine, slots, like=None, spread=None):
         eng, cfg = engine, engine.cfg
         n, N, E, D, F = eng.n_envs, cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat
         self.engine, self.slots = eng, int(slots)
@@ -735,12 +784,21 @@ class OutputRing(object):
         if like is not None:
             taken = iter([like.obs, like.reward, like.done, like.node_obs, like.adj_env, like.info_planes, like.edge_nnz, like.graph_record])
 
-        def mk(*shape, dtype=torch.float32):
+        self.spread = []   # names of the arrays whose physical memory is interleaved
+
+        def mk(*shape, dtype=torch.float32, name=None):
             old = next(taken, None)
             if like is not None:
                 if old is None or tuple(old.shape) != tuple(shape) or old.dtype != dtype or old.device != eng.device:
                     raise ValueError('OutputRing(like=...): the other ring has no %s array of shape %s' % (dtype, (shape,)))
+                if name in getattr(like, 'spread', ()):
+                    self.spread.append(name)
                 return old
+            if name and dtype == torch.float32:
+                t, interleaved = alloc_time_slots(eng.lib, eng.device, shape, spread)
+                if interleaved:
+                    self.spread.append(name)
+                return t
             return torch.empty(*shape, dtype=dtype, device=eng.device)
         def skip():   # an array this ring does not have: step over the other ring's
             next(taken, None)
@@ -749,8 +807,8 @@ class OutputRing(object):
             self.obs = mk(T, n, N, D)
             self.reward = mk(T, n, N)
             self.done = mk(T, n, N, dtype=torch.uint8)
-            self.node_obs = mk(T, n, N, E, F) if eng.emit_graph else skip()
-            self.adj_env = mk(T, n, E, E) if eng.emit_graph else skip()
+            self.node_obs = mk(T, n, N, E, F, name='node_obs') if eng.emit_graph else skip()
+            self.adj_env = mk(T, n, E, E, name='adj') if eng.emit_graph else skip()
             self.info_planes = mk(T, _lib.INFO_WIDTH, n, N) if eng.emit_info else skip()
             self.edge_nnz = mk(T, n, dtype=torch.int32) if eng.count_edges else skip()
             self.graph_record = mk(T, n, N, eng.step_record_words, dtype=torch.int32) if eng.emit_graph_record else skip()

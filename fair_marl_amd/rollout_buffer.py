@@ -39,8 +39,11 @@ class DeviceRolloutBuffer(object):
         dev = eng.device
         z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         self.obs = z(T + 1, n, N, D)
-        self.node_obs = z(T + 1, n, N, E, F)
-        self.adj_env = z(T + 1, n, E, E)
+        # (the two large arrays: slots virtually contiguous, physical memory interleaved over the whole array -- a step that fills ONE
+        # slot then writes at the rate of the whole buffer: engine.alloc_time_slots / fmarl_ring_alloc)
+        from .engine import alloc_time_slots
+        self.node_obs, _ = alloc_time_slots(eng.lib, dev, (T + 1, n, N, E, F), zero=True)
+        self.adj_env, _ = alloc_time_slots(eng.lib, dev, (T + 1, n, E, E), zero=True)
         self.rewards = z(T, n, N, 1)
         self.dones = z(T, n, N, dtype=torch.uint8)
         self.masks = torch.ones(T + 1, n, N, 1, dtype=torch.float32, device=dev)

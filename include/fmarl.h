@@ -303,6 +303,19 @@ int fmarl_poison_lds(void *handle, void *stream);
  * (which has no device path); takes no handle. */
 int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, int order, int persist, void *stream);
 
+/* Memory for time slots (fair_marl_amd.OutputRing; the layout of the reference's rollout storage, onpolicy/utils/graph_buffer.py:84-110:
+ * a (slots, n, ...) array, slot t = the bytes [t * slot_bytes, (t + 1) * slot_bytes) behind *base).  The slots are virtually
+ * contiguous, but their PHYSICAL memory is interleaved: the array is backed by slots * slot_bytes / piece_bytes physical pieces
+ * (hipMemCreate), and virtual piece j of slot t is mapped to physical piece j * slots + t -- every slot is spread evenly over the
+ * whole allocation.  Why: MI355X takes a store stream at 5.7-6.0 TB/s when its target is one contiguous 8 GB region and at 6.8-7.1
+ * TB/s when the same bytes are spread over 160 GB, even in pieces of 32 MiB (tools/spread_probe.hip, profiles/r4_notes.md) -- a
+ * launch that writes ONE time slot (a policy in the loop: fmarl_step) gets the rate of the whole ring.  piece_bytes = 0: the
+ * library's choice (<= 16 MiB, a divisor of slot_bytes); otherwise a multiple of the allocation granularity that divides
+ * slot_bytes.  FMARL_EINVAL when the slot size has no such divisor, FMARL_EHIP when the device has no virtual memory management:
+ * allocate plainly then.  The memory belongs to the caller until fmarl_ring_free(cookie) (no launch may still use it). */
+int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **base, void **cookie);
+int fmarl_ring_free(void *cookie);
+
 /* --- pieces exported on their own -------------------------------------------------------- */
 
 /* cdist(agent_pos, goal_pos) of navigation_graph.py:555: f64 (n, N, 2) x (n, L, 2) -> (n, N, L). */

@@ -1719,3 +1719,48 @@ def test_fairnav_full_size():
     assert torch.isfinite(eng.node_obs).all()
     gm = torch.as_tensor(eng.get_state()['goal_match'])
     assert bool((gm.sort(dim=1).values == torch.arange(N)).all())
+
+
+def test_time_slots_with_interleaved_physical_memory():
+    """fmarl_ring_alloc: (T, ...) arrays whose slots are virtually contiguous while their physical pieces are interleaved over the
+    whole array.  The mapping is invisible to a reader -- every byte written through one view is read back through another -- a slot
+    size without a suitable divisor is refused (the Python side then allocates plainly), the memory goes back when the last tensor
+    does, and an OutputRing on such arrays holds the same rollout as one on plain allocations."""
+    import ctypes as C
+    import gc
+    from fair_marl_amd import _lib
+    from fair_marl_amd.engine import alloc_time_slots
+    lib = _lib.load()
+    free0 = torch.cuda.mem_get_info()[0]
+    t, inter = alloc_time_slots(lib, torch.device(DEV), (5, 3, 1 << 20), spread=True)      # 12 MiB slots
+    assert inter and t.shape == (5, 3, 1 << 20) and t.is_contiguous() and t.dtype == torch.float32
+    assert free0 - torch.cuda.mem_get_info()[0] >= 5 * 12 * (1 << 20)
+    ref = torch.arange(t.numel(), device=DEV, dtype=torch.float32).view(t.shape)
+    t.copy_(ref)
+    for k in range(5):
+        assert torch.equal(t[k], ref[k])
+    assert torch.equal(t.view(-1)[1234567:7654321], ref.view(-1)[1234567:7654321])       # across piece and slot boundaries
+    del t, ref
+    gc.collect()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 16 * (1 << 20)
+    base, cookie = C.c_void_p(), C.c_void_p()
+    assert lib.fmarl_ring_alloc(4096 * 3 + 4, 4, 0, C.byref(base), C.byref(cookie)) == 1    # no divisor that is a multiple of the granularity
+    t2, inter2 = alloc_time_slots(lib, torch.device(DEV), (4, 1000, 3), spread=None)       # small slots: plain
+    assert not inter2
+    # the same rollout into interleaved and into plain time slots
+    cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=2)
+    n = 256
+    tape = torch.randint(0, 5, (25, n, 4), device=DEV, dtype=torch.int32, generator=torch.Generator(device=DEV).manual_seed(3))
+    rings = []
+    for spread in (True, False):
+        eng = fm.RolloutEngine(cfg, n, device=DEV, seed=9)
+        ring = fm.OutputRing(eng, 25, spread=spread)
+        assert (ring.spread == ['node_obs', 'adj']) == spread
+        eng.reset()
+        eng.rollout(tape, mode='span', ring=ring)
+        eng.rollout(tape, mode='eager', ring=ring)
+        rings.append(ring)
+    torch.cuda.synchronize()
+    for k in ('obs', 'reward', 'done', 'node_obs', 'adj_env', 'info_planes'):
+        assert torch.equal(getattr(rings[0], k), getattr(rings[1], k)), k
