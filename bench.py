@@ -326,6 +326,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
                algorithmic_bytes_per_step=per_step, store_ceiling_ms=ceil['ms_per_step'] if ceil else None,
                store_ceiling_shape=ceil['shape'] if ceil else None,
                frac_of_box_ceiling=(ceil['ms_per_step'] / k_step if ceil else None))
+    if n * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS:
+        out['bound'] = ('launch / latency: the batch cannot fill the chip (%d waves on 256 CUs), a step is one wave\'s dependent float64 chain; '
+                        'an HBM roofline does not apply -- `frac` is reported for completeness' % ((n * cfg.N + 63) // 64))
     if mode == 'steady':
         out['regime'] = 'min_dist_thresh %.2f, %d untimed steps first: episodes end env by env at all phases' % (STEADY['min_dist_thresh'], pre_steps)
     return out
