@@ -891,12 +891,15 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
     size_t gran = 0;
-    HIP_OK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    HIP_OK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
     if (gran < 4096) gran = 4096;
-    if (piece_bytes == 0) {   // the largest power of two <= 16 MiB that divides a slot; larger while the handles would exceed 32 768
-        piece_bytes = (size_t)16 << 20;
-        while (piece_bytes > gran && slot_bytes % piece_bytes) piece_bytes >>= 1;
-        while (slot_bytes % (piece_bytes * 2) == 0 && (slot_bytes / piece_bytes) * (size_t)slots > 32768) piece_bytes *= 2;
+    if (piece_bytes == 0) {
+        // the largest divisor of a slot that is a multiple of the granularity and at most 16 MiB (a slot = k pieces, k as small as
+        // possible: every piece is a hipMemCreate call, and those get slow in the tens of thousands); 0 pieces found = no divisor
+        const size_t cap = (size_t)16 << 20;
+        for (size_t k = (slot_bytes + cap - 1) / cap; k <= slot_bytes / gran && k <= 65536; ++k)
+            if (slot_bytes % k == 0 && (slot_bytes / k) % gran == 0) { piece_bytes = slot_bytes / k; break; }
+        if (piece_bytes == 0) return fail(FMARL_EINVAL, "fmarl_ring_alloc: the slot size has no divisor that is a multiple of the allocation granularity");
     }
     if (piece_bytes < gran || piece_bytes % gran || slot_bytes % piece_bytes)
         return fail(FMARL_EINVAL, "fmarl_ring_alloc: a slot must be a whole number of pieces, a piece a multiple of the allocation granularity");
@@ -904,8 +907,12 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     RingAlloc *r = new (std::nothrow) RingAlloc();
     if (!r) return fail(FMARL_EINVAL, "fmarl_ring_alloc: out of host memory");
     r->total = slot_bytes * (size_t)slots;
-    hipError_t e = hipMemAddressReserve(&r->ptr, r->total, piece_bytes, nullptr, 0);
-    if (e != hipSuccess) { r->ptr = nullptr; ring_release(r); return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e)); }
+    hipError_t e = hipMemAddressReserve(&r->ptr, r->total, (size_t)2 << 20, nullptr, 0);   // (the alignment must be a power of two; pieces need not be)
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
+        r->ptr = nullptr; ring_release(r);
+        return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e));
+    }
     r->handles.reserve(count);
     for (size_t k = 0; k < count && e == hipSuccess; ++k) {   // physical pieces, in creation order
         hipMemGenericAllocationHandle_t h;

@@ -1731,6 +1731,7 @@ def test_time_slots_with_interleaved_physical_memory():
     from fair_marl_amd import _lib
     from fair_marl_amd.engine import alloc_time_slots
     lib = _lib.load()
+    torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     t, inter = alloc_time_slots(lib, torch.device(DEV), (5, 3, 1 << 20), spread=True)      # 12 MiB slots
     assert inter and t.shape == (5, 3, 1 << 20) and t.is_contiguous() and t.dtype == torch.float32
@@ -1743,6 +1744,7 @@ def test_time_slots_with_interleaved_physical_memory():
     del t, ref
     gc.collect()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()   # (the comparison tensor goes back to the driver as well)
     assert free0 - torch.cuda.mem_get_info()[0] < 16 * (1 << 20)
     base, cookie = C.c_void_p(), C.c_void_p()
     assert lib.fmarl_ring_alloc(4096 * 3 + 4, 4, 0, C.byref(base), C.byref(cookie)) == 1    # no divisor that is a multiple of the granularity
