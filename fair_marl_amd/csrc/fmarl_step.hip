@@ -828,7 +828,10 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
 // the static entities in the LDS tables (StepCarry): only the first step loads the state, only the last one stores it, and
 // the step body's own barriers are all the ordering the steps need (a step's first LDS writes come two barriers after its
 // start, by when every wave has left the previous step's emission).
-__global__ __launch_bounds__(kThreads, 3) void step_span_kernel(
+#ifndef FMARL_SPAN_BLOCKS
+#define FMARL_SPAN_BLOCKS 3
+#endif
+__global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_kernel(
     Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, const float *action_vec, int T) {
     StepCarry c = {};
     for (int t = 0; t < T; ++t) {
