@@ -1766,3 +1766,16 @@ def test_time_slots_with_interleaved_physical_memory():
     torch.cuda.synchronize()
     for k in ('obs', 'reward', 'done', 'node_obs', 'adj_env', 'info_planes'):
         assert torch.equal(getattr(rings[0], k), getattr(rings[1], k)), k
+    # a second engine over the same arrays (OutputRing(like=...): what bench.py does for the headline config's secondary entries)
+    eng2 = fm.RolloutEngine(cfg, n, device=DEV, seed=9)
+    ring2 = fm.OutputRing(eng2, 25, like=rings[0])
+    assert ring2.node_obs.data_ptr() == rings[0].node_obs.data_ptr() and ring2.spread == rings[0].spread
+    before = rings[1].node_obs.clone()
+    rings[0].node_obs.zero_()
+    eng2.reset()
+    eng2.rollout(tape, mode='span', ring=ring2)
+    eng2.rollout(tape, mode='eager', ring=ring2)
+    torch.cuda.synchronize()
+    assert torch.equal(rings[0].node_obs, before)        # the same rollout, written through the second engine into the first ring's memory
+    with pytest.raises(ValueError):
+        fm.OutputRing(fm.RolloutEngine(cfg, n // 2, device=DEV, seed=9), 25, like=rings[0])
