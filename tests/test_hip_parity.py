@@ -1731,21 +1731,23 @@ def test_time_slots_with_interleaved_physical_memory():
     from fair_marl_amd import _lib
     from fair_marl_amd.engine import alloc_time_slots
     lib = _lib.load()
-    torch.cuda.empty_cache()
-    free0 = torch.cuda.mem_get_info()[0]
-    t, inter = alloc_time_slots(lib, torch.device(DEV), (5, 3, 1 << 20), spread=True)      # 12 MiB slots
-    assert inter and t.shape == (5, 3, 1 << 20) and t.is_contiguous() and t.dtype == torch.float32
-    assert free0 - torch.cuda.mem_get_info()[0] >= 5 * 12 * (1 << 20)
-    ref = torch.arange(t.numel(), device=DEV, dtype=torch.float32).view(t.shape)
-    t.copy_(ref)
-    for k in range(5):
-        assert torch.equal(t[k], ref[k])
-    assert torch.equal(t.view(-1)[1234567:7654321], ref.view(-1)[1234567:7654321])       # across piece and slot boundaries
-    del t, ref
-    gc.collect()
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()   # (the comparison tensor goes back to the driver as well)
-    assert free0 - torch.cuda.mem_get_info()[0] < 16 * (1 << 20)
+    for cycle in range(2):   # (the first cycle also loads torch's kernels into device memory: the accounting is checked on the second)
+        torch.cuda.empty_cache()
+        free0 = torch.cuda.mem_get_info()[0]
+        t, inter = alloc_time_slots(lib, torch.device(DEV), (5, 3, 1 << 20), spread=True)      # 12 MiB slots
+        assert inter and t.shape == (5, 3, 1 << 20) and t.is_contiguous() and t.dtype == torch.float32
+        assert free0 - torch.cuda.mem_get_info()[0] >= 5 * 12 * (1 << 20)
+        ref = torch.arange(t.numel(), device=DEV, dtype=torch.float32).view(t.shape)
+        t.copy_(ref)
+        for k in range(5):
+            assert torch.equal(t[k], ref[k])
+        assert torch.equal(t.view(-1)[1234567:7654321], ref.view(-1)[1234567:7654321])       # across piece and slot boundaries
+        del t, ref
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()   # (the comparison tensor goes back to the driver as well)
+        if cycle:
+            assert free0 - torch.cuda.mem_get_info()[0] < 16 * (1 << 20)
     base, cookie = C.c_void_p(), C.c_void_p()
     assert lib.fmarl_ring_alloc(4096 * 3 + 4, 4, 0, C.byref(base), C.byref(cookie)) == 1    # no divisor that is a multiple of the granularity
     t2, inter2 = alloc_time_slots(lib, torch.device(DEV), (4, 1000, 3), spread=None)       # small slots: plain
