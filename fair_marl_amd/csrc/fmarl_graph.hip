@@ -263,6 +263,23 @@ __global__ __launch_bounds__(256) void info_mean_kernel(const float *info, doubl
 // workgroups that live for the whole launch, as a span's do -- chunk ((b + k grid) * order) mod n_chunks for k = 1, 2, ...: order 1
 // is dispatch order (the resident workgroups write one compact window), a large odd order scatters them over the buffer.
 // The value depends on the address, so no two stores are equal.
+// masks / active_masks of the runner's insert (onpolicy/runner/shared/graph_mpe_runner.py:444-465) for `rows` env-steps of N agents:
+// masks = 0 where the agent is done; active_masks = 0 where the agent is done but its env is not (an env whose agents are all
+// done keeps active_masks 1).  One lane per env-step: N bytes in, 2 N floats out (a rollout buffer's per-step bookkeeping as one
+// launch instead of eight elementwise ones -- at 3 agents x 4 096 envs those cost three times the step kernel).
+__global__ __launch_bounds__(256) void insert_masks_kernel(const uint8_t *done, float *masks, float *active, size_t rows, int N) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint8_t *d = done + r * N;
+    bool all = true;
+    for (int i = 0; i < N; ++i) all &= d[i] != 0;
+    for (int i = 0; i < N; ++i) {
+        const bool di = d[i] != 0;
+        masks[r * N + i] = di ? 0.f : 1.f;
+        active[r * N + i] = (di && !all) ? 0.f : 1.f;
+    }
+}
+
 typedef float fmarl_f4 __attribute__((ext_vector_type(4)));
 template <int SHAPE>   // shapes 3 / 4: 1 / 2 with non-temporal stores (experiments: no faster than plain stores on MI355X)
 __global__ __launch_bounds__(256) void store_stream_kernel(float4 *dst, size_t n16, uint32_t chunk16, uint32_t n_chunks, uint32_t order) {

@@ -945,6 +945,15 @@ int fmarl_ring_free(void *cookie) {
     return FMARL_OK;
 }
 
+int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, int64_t rows, int num_agents, void *stream) {
+    if (!done || !masks || !active_masks || rows < 0 || num_agents < 1) return fail(FMARL_EINVAL, "fmarl_insert_masks: bad argument");
+    if (!rows) return FMARL_OK;
+    hipLaunchKernelGGL(fmarl::insert_masks_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, done, masks,
+                       active_masks, (size_t)rows, num_agents);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
 int fmarl_get_phase(void *handle) {
     Handle *h = (Handle *)handle;
     return h && h->lockstep ? h->host_step : -1;

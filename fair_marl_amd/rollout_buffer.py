@@ -91,12 +91,17 @@ class DeviceRolloutBuffer(object):
             raise RuntimeError('buffer full: call after_update() first')
         self.engine.use_outputs(self._sets[t + 1])
         self.engine.step(actions, auto_reset=True)
-        done = self.dones[t].to(torch.bool)                          # (n, N)
-        done_env = done.all(dim=1, keepdim=True)                     # graph_mpe_runner.py:444
-        self.masks[t + 1] = (~done).to(torch.float32).unsqueeze(-1)  # :452-458
-        self.active_masks[t + 1] = (~(done & ~done_env)).to(torch.float32).unsqueeze(-1)  # :459-465
+        self._insert_masks(t, 1)   # graph_mpe_runner.py:444-465
         self.step = t + 1
         return self._sets[t + 1]
+
+    def _insert_masks(self, t0, T):
+        """masks / active_masks of the slots t0 + 1 ... t0 + T from the dones of the steps t0 ... t0 + T - 1 (one launch)."""
+        eng = self.engine
+        n, N = eng.n_envs, eng.cfg.N
+        with torch.cuda.device(eng.device):
+            _lib.check(eng.lib.fmarl_insert_masks(self.dones[t0].data_ptr(), self.masks[t0 + 1].data_ptr(), self.active_masks[t0 + 1].data_ptr(),
+                                                  T * n, N, eng._stream()), 'fmarl_insert_masks')
 
     def insert_span(self, action_tape):
         """``insert_step(action_tape[t])`` for every t through ONE ``fmarl_step_span`` call: the time slots are contiguous
@@ -113,10 +118,7 @@ class DeviceRolloutBuffer(object):
         eng.use_outputs(first)
         eng.step_span(tape, strides=dict(obs=self.obs[0].numel(), node_obs=self.node_obs[0].numel(), adj=self.adj_env[0].numel(),
                                          reward=n * N, done=n * N, info=self.info_planes[0].numel() if self.info_planes is not None else 0))
-        done = self.dones[t0:t0 + T].to(torch.bool)                         # (T, n, N)
-        done_env = done.all(dim=2, keepdim=True)
-        self.masks[t0 + 1:t0 + T + 1] = (~done).to(torch.float32).unsqueeze(-1)
-        self.active_masks[t0 + 1:t0 + T + 1] = (~(done & ~done_env)).to(torch.float32).unsqueeze(-1)
+        self._insert_masks(t0, T)
         self.step = t0 + T
         last = self._sets[self.step]
         eng.use_outputs(last)

@@ -303,6 +303,11 @@ int fmarl_poison_lds(void *handle, void *stream);
  * (which has no device path); takes no handle. */
 int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, int order, int persist, void *stream);
 
+/* The masks of the runner's insert (onpolicy/runner/shared/graph_mpe_runner.py:444-465) for `rows` env-steps of num_agents agents each:
+ * done u8 (rows, N) -> masks f32 (rows, N): 0 where the agent is done; active_masks f32 (rows, N): 0 where the agent is done but
+ * its env is not.  One launch (DeviceRolloutBuffer.insert_step / insert_span). */
+int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, int64_t rows, int num_agents, void *stream);
+
 /* Memory for time slots (fair_marl_amd.OutputRing; the layout of the reference's rollout storage, onpolicy/utils/graph_buffer.py:84-110:
  * a (slots, n, ...) array, slot t = the bytes [t * slot_bytes, (t + 1) * slot_bytes) behind *base).  The slots are virtually
  * contiguous, but their PHYSICAL memory is interleaved: the array is backed by slots * slot_bytes / piece_bytes physical pieces
