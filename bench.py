@@ -210,7 +210,7 @@ SAME_SLOT_EPB = {'cfg3': 4}
 EAGER_EPB = {}   # one launch per step: the library's choice everywhere (tools/ring_epb.py <config> <list> eager)
 # steps per span launch when the records of a run travel to a learner rank (N > 1): a run's records can only leave when its launch
 # has ended, so the LAST run's gather of a timed region is exposed in full -- short runs keep it short, long runs save launches
-GATHER_SPAN_STEPS = 5
+GATHER_SPAN_STEPS = 5   # (and the last runs of a region halve down to single steps: run_spans)
 
 
 def _use_ring(cfg, n_envs, slots, device):
@@ -659,6 +659,10 @@ def main():
         while t < end:
             off = t % ep
             k = min(ep - off, end - t, span_steps)
+            if gather and end - t <= span_steps:
+                # the last stretch of a region: the runs halve down to single steps, so that the gather nobody can hide -- the last
+                # one, behind which the region's closing synchronisation waits -- carries one step's records instead of a whole run's
+                k = min(k, max(1, (end - t + 1) // 2))
             c = chunk[0]
             strides = None
             if gather:
