@@ -571,7 +571,7 @@ def main():
                                tune_placement=(None if args.tune_placement and slots == 'same' else 0), emit_graph_record=gather,
                                envs_per_workgroup=epb_hint)
     ring = fm.OutputRing(eng, ep) if slots == 'ring' else None   # step t writes slot t mod episode_length
-    depth = 2
+    depth = 3   # record buffers in rotation: a gather has two runs' (steps') time before its buffer is written again
     # the learner rebuilds node_obs / adj from obs + a record gathered once per episode (navigation_graph) plus, for the two
     # formation scenarios, a per-step record of the step's scenario state (RolloutEngine.step_record_words)
     episodes = True
