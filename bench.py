@@ -568,7 +568,7 @@ def main():
         eng = pipe.engines[0]
     else:
         eng = fm.RolloutEngine(cfg, n_envs, device=device, seed=1, env_offset=rank * n_envs, async_reset=not args.sync_reset,
-                               tune_placement=(None if args.tune_placement and slots == 'same' else 0), emit_graph_record=gather,
+                               tune_placement=(6 if args.tune_placement and slots == 'same' else 0), emit_graph_record=gather,
                                envs_per_workgroup=epb_hint)
     ring = fm.OutputRing(eng, ep) if slots == 'ring' else None   # step t writes slot t mod episode_length
     depth = 3   # record buffers in rotation: a gather has two runs' (steps') time before its buffer is written again

@@ -64,8 +64,12 @@ class RolloutEngine:
         self.step_record_words = int(self.lib.fmarl_step_record_words(C.byref(self.c)))
         self.emit_graph_record = bool(emit_graph_record and self.step_record_words)
         self.placement_ms = None
-        if tune_placement is None:   # worth it once the graph outputs are half a GB (the step is then bound by their store stream)
-            tune_placement = 6 if emit_graph and cfg.scenario_name == 'navigation_graph' and n * N * E * F * 4 >= (1 << 29) else 0
+        # tune_placement = k > 1: time k candidate allocations of node_obs / adj and keep the fastest pair (rounds 2-3: for ONE output
+        # set that every step rewrites, some boxes run 10 % apart between allocation pairs).  Off by default since round 4: a
+        # rollout that keeps its steps writes time slots (OutputRing / DeviceRolloutBuffer), whose interleaved memory does not depend
+        # on the luck of one allocation
+        if tune_placement is None:
+            tune_placement = 0
         if tune_placement and tune_placement > 1:
             self._tune_output_placement(int(tune_placement))
         self._default_graph = (self.node_obs, self.adj_env)
