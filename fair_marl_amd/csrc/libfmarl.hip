@@ -868,13 +868,12 @@ int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, i
 namespace {
 struct RingAlloc {
     void *ptr = nullptr;
-    size_t total = 0;
+    size_t total = 0, piece = 0, mapped = 0;   // `mapped` virtual pieces from the start of the range are mapped
     std::vector<hipMemGenericAllocationHandle_t> handles;
-    bool mapped = false;
 };
 void ring_release(RingAlloc *r) {
     if (!r) return;
-    if (r->ptr && r->mapped) (void)hipMemUnmap(r->ptr, r->total);
+    if (r->ptr && r->mapped) (void)hipMemUnmap(r->ptr, r->mapped * r->piece);
     for (auto h : r->handles) (void)hipMemRelease(h);
     if (r->ptr) (void)hipMemAddressFree(r->ptr, r->total);
     delete r;
@@ -907,6 +906,7 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     RingAlloc *r = new (std::nothrow) RingAlloc();
     if (!r) return fail(FMARL_EINVAL, "fmarl_ring_alloc: out of host memory");
     r->total = slot_bytes * (size_t)slots;
+    r->piece = piece_bytes;
     hipError_t e = hipMemAddressReserve(&r->ptr, r->total, (size_t)2 << 20, nullptr, 0);   // (the alignment must be a power of two; pieces need not be)
     if (e != hipSuccess) {
         (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
@@ -921,18 +921,18 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     }
     // virtual piece j of slot t <- physical piece j * slots + t: a slot's pieces are spread evenly over the whole allocation
     for (size_t t = 0; t < (size_t)slots && e == hipSuccess; ++t)
-        for (size_t j = 0; j < per_slot && e == hipSuccess; ++j)
+        for (size_t j = 0; j < per_slot && e == hipSuccess; ++j) {
             e = hipMemMap((char *)r->ptr + (t * per_slot + j) * piece_bytes, piece_bytes, 0, r->handles[j * (size_t)slots + t], 0);
+            if (e == hipSuccess) ++r->mapped;
+        }
     if (e == hipSuccess) {
-        r->mapped = true;
         hipMemAccessDesc acc = {};
         acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
         e = hipMemSetAccess(r->ptr, r->total, &acc, 1);
     }
     if (e != hipSuccess) {
-        (void)hipGetLastError();
-        if (!r->mapped && r->ptr) { (void)hipMemUnmap(r->ptr, r->total); }
-        ring_release(r);
+        (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
+        ring_release(r);           // unmaps what was mapped, releases every piece, frees the range
         return fail(FMARL_EHIP, "fmarl_ring_alloc: %s", hipGetErrorString(e));
     }
     *base = r->ptr; *cookie = r;

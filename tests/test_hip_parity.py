@@ -1751,6 +1751,13 @@ def test_time_slots_with_interleaved_physical_memory():
             assert free0 - torch.cuda.mem_get_info()[0] < 16 * (1 << 20)
     base, cookie = C.c_void_p(), C.c_void_p()
     assert lib.fmarl_ring_alloc(4096 * 3 + 4, 4, 0, C.byref(base), C.byref(cookie)) == 1    # no divisor that is a multiple of the granularity
+    # more than the device has: refused with a message, every piece handed back, no HIP error left behind
+    torch.cuda.empty_cache()
+    free1, total1 = torch.cuda.mem_get_info()
+    with pytest.raises(MemoryError):
+        alloc_time_slots(lib, torch.device(DEV), (2, (total1 // 4 // (1 << 20) * (1 << 20)) * 3 // 4), spread=True)   # 2 x 0.75 x the device
+    assert abs(torch.cuda.mem_get_info()[0] - free1) < 64 * (1 << 20)
+    assert float(torch.ones(4, device=DEV).sum()) == 4.0
     t2, inter2 = alloc_time_slots(lib, torch.device(DEV), (4, 1000, 3), spread=None)       # small slots: plain
     assert not inter2
     # the same rollout into interleaved and into plain time slots
