@@ -640,6 +640,21 @@ def test_masked_reset_and_float_actions():
     check_state(eng, orc.st, 'masked reset')
 
 
+def test_device_assignment_at_32_agents_equals_the_reference_procedure_on_highs():
+    """The goal_match the DEVICE stores after a reset of BASELINE config 3's shape (32 agents: placement + cdist + lexifair, all on the
+    device) against the reference's own procedure (marl_fair_assign.py:16-55: 32 rounds of the min-max MILP, fix the bottleneck row)
+    with HiGHS in Gurobi's place, on the cost matrix of the device's own positions -- the inputs config 3 really solves.  (The
+    solver stays "parity unpinned": no Gurobi output exists.  This closes the chain device == definition == procedure at N = 32.)"""
+    from oracle.lexifair_milp import lexifair_milp
+    cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
+    eng = fm.RolloutEngine(cfg, 4, device=DEV, seed=17)
+    eng.reset()
+    st = eng.get_state()
+    for e in (0, 3):
+        c = no.cost_matrix(st['agent_pos'][e], st['landmark_pos'][e])
+        assert np.array_equal(st['goal_match'][e], lexifair_milp(c)), e
+
+
 def test_lexifair_cost_matrix_update_graph():
     from oracle.lexifair import lexifair
     eng = fm.RolloutEngine(fm.EnvConfig(num_agents=3, num_landmarks=3), 4, device=DEV)
