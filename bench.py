@@ -60,7 +60,7 @@ KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassig
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
 SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg3', 'span5'), ('cfg3', 'span-same'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'),
-             ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'pipeline2'), ('fnav', 'steady'),
+             ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'span'), ('fnav', 'pipeline2'), ('fnav', 'steady'), ('fnav', 'steady-span'),
              ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
 # nav_fairassign_fairrew_formation_graph where a training run is: a threshold at which goals are reached, so that episodes end
 # env by env, and enough untimed steps for the envs' episode phases to be uniform (mode 'steady'; tools/fnav_steady.py)
@@ -232,7 +232,8 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
       'span<S>' = the same in runs of at most S steps (the launch pattern of an N > 1 run, whose records leave run by run);
       'span-same' = spans that rewrite ONE output set every step (stride 0: round 3's headline mode, kept for comparison);
       'graph' = one hipGraph replay per episode (launch-bound batches; one output set);
-      'steady' (nav_fairassign_fairrew_formation_graph) = one launch per step with episodes ending at all phases (STEADY);
+      'steady' (nav_fairassign_fairrew_formation_graph) = one launch per step with episodes ending at all phases (STEADY),
+      'steady-span' = the same regime as spans (that scenario's span: the whole tape one launch, episode ends inside);
       'pipeline<k>' = k sub-batches on k streams.
     Every step writes its own time slot of an episode-long ring (`slots`: 'ring') except where the mode says otherwise; `arena` = a
     ring of the same shape whose arrays are taken over (the headline's: a large allocation made after another one was freed is, on
@@ -241,7 +242,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     spec = CONFIGS[name]
     env_kw = dict(spec['env'])
     pre_steps = 0
-    if mode == 'steady':
+    if mode.startswith('steady'):
         env_kw['min_dist_thresh'] = STEADY['min_dist_thresh']
         pre_steps = STEADY['pre_steps']
     cfg = fm.EnvConfig(**env_kw)
@@ -253,7 +254,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
         return secondary_pipeline(name, int(mode[len('pipeline'):].replace('span', '')), device, steps, warmup, spans, slots)
     same = mode == 'span-same'
     run_len = int(mode[4:]) if mode.startswith('span') and mode[4:].isdigit() else 0
-    rmode = 'span' if mode.startswith('span') else ('eager' if mode == 'steady' else mode)
+    rmode = 'span' if mode.startswith('span') or mode == 'steady-span' else ('eager' if mode == 'steady' else mode)
     epb = (SAME_SLOT_EPB if same else SPAN_EPB).get(name, 0) if rmode == 'span' else EAGER_EPB.get(name, 0)
     eng = fm.RolloutEngine(cfg, n, device=device, seed=1, envs_per_workgroup=epb, tune_placement=0)
     ring = None
@@ -304,9 +305,13 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     folded = c1[1] - c0[1] > 0
     kern = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
     if rmode == 'span':
-        kern = {'fair_graph_formation': 'formation_span_kernel + formation_kernel<true>'}.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel')
+        kern = {'fair_graph_formation': 'formation_span_kernel + formation_kernel<true>',
+                'nav_fairassign_fairrew_formation_graph': 'fairnav_span_kernel'}.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel')
     span_text = 'fmarl_step_span: one launch per run of steps between episode ends%s (%d envs per workgroup), the episode-ending step a launch of its own' \
                 % (' and at most %d steps' % run_len if run_len else '', eng.envs_per_workgroup)
+    if cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph':
+        span_text = ('fmarl_step_span: the %d steps of the tape as ONE launch (%d envs per workgroup); episodes end env by env and the step '
+                     'resets them itself, the state goes through L2 between the steps' % (ep, eng.envs_per_workgroup))
     steps_per_launch = (c1[0] - c0[0]) / max(1, len(kernel_ms))
     epw = eng.envs_per_workgroup
     ring_bytes = ring.nbytes if ring is not None else 0
@@ -329,7 +334,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     if n * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS:
         out['bound'] = ('launch / latency: the batch cannot fill the chip (%d waves on 256 CUs), a step is one wave\'s dependent float64 chain; '
                         'an HBM roofline does not apply -- `frac` is reported for completeness' % ((n * cfg.N + 63) // 64))
-    if mode == 'steady':
+    if mode.startswith('steady'):
         out['regime'] = 'min_dist_thresh %.2f, %d untimed steps first: episodes end env by env at all phases' % (STEADY['min_dist_thresh'], pre_steps)
     return out
 
@@ -432,8 +437,10 @@ def cpu_baseline(env_kw, n_envs, episodes, workers):
 
 
 def launch_plan(launch, pipeline, scenario_name, gather, span_steps, episode_length):
-    """(launch mode, most steps per span launch) of a run.  The launch mode never depends on the number of GPUs: spans wherever the
-    scenario has a span kernel (nav_fairassign_fairrew_formation_graph steps: its span is a loop of steps anyway).  What the exchange
+    """(launch mode, most steps per span launch) of a run.  The launch mode never depends on the number of GPUs: spans, except for
+    nav_fairassign_fairrew_formation_graph, which steps -- its envs end their episodes INSIDE a span, and the record of an episode's
+    static entities, which the learner rank needs for every step, can only be packed between launches (its span figure at N = 1 is
+    the `secondary` entry (fnav, span)).  What the exchange
     changes is the LENGTH of a run: a run's records can only leave when its launch has ended, so with a gather the runs are
     GATHER_SPAN_STEPS long -- the gather of one run crosses xGMI while the next one computes, and only the last run's gather of
     a timed region is exposed -- instead of reaching to the episode end."""
@@ -457,8 +464,8 @@ def main():
                          'every workgroup walks its own envs through time, the episode-ending step a launch of its own (actions '
                          'come from a tape: BASELINE\'s random-action rollout); step: one fmarl_step call per step (what a policy in '
                          'the loop gets); graph: one hipGraph replay per episode (N=1).  auto = span for every N (the same launch '
-                         'mode whatever the number of GPUs), except for nav_fairassign_fairrew_formation_graph (its span is a loop of '
-                         'steps anyway)')
+                         'mode whatever the number of GPUs), except for nav_fairassign_fairrew_formation_graph (episodes end inside its '
+                         'span; the per-episode record a learner rank needs is packed between launches: step)')
     ap.add_argument('--span-steps', type=int, default=0, help='most steps per span launch (0 = auto: up to the episode end for N = 1; '
                     '%d when the records of a run are gathered to a learner rank -- a run\'s records can only leave when its launch has '
                     'ended, and the last run\'s gather of the timed region is exposed)' % GATHER_SPAN_STEPS)
@@ -546,6 +553,9 @@ def main():
     gather = (world > 1 or args.record_path) and not args.no_gather
     launch, span_steps = launch_plan('graph' if args.graph else ('step' if args.eager else args.launch), args.pipeline, cfg.scenario_name,
                                      gather, args.span_steps, ep)
+    if fnav_sc and gather and launch == 'span':
+        raise SystemExit('bench.py: nav_fairassign_fairrew_formation_graph ends episodes inside a span; with the trajectory gather its '
+                         'per-episode records must be packed between launches: use --launch step (the default)')
     if launch == 'graph':
         if world > 1:
             raise SystemExit('bench.py: --launch graph is a single-GPU mode')

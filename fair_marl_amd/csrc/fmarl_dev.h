@@ -157,11 +157,12 @@ __device__ __forceinline__ Params span_params(const Params &p) {
 // cannot see through -- the fields are then loaded (scalar loads from the constant segment) where a step uses them instead
 // of all being loaded before the time loop and kept in scalar registers across it (span_params keeps ~55 of them live: the
 // kernel spilled 194 scalar registers into vector lanes, each access a VALU instruction).  `Params` must be the first argument.
-__device__ __forceinline__ const Params &span_params_reloaded() {
-    typedef const Params __attribute__((address_space(4))) *ConstParams;
+template <typename Args = Params>   // (Args: a kernel's ONLY argument, or the type of its first one)
+__device__ __forceinline__ const Args &span_params_reloaded() {
+    typedef const Args __attribute__((address_space(4))) *ConstArgs;
     uint64_t a = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
     a = pin_sgpr(a);
-    return *(const Params *)(ConstParams)a;
+    return *(const Args *)(ConstArgs)a;
 }
 // between two steps of a span: a workgroup re-reads from global memory what it wrote itself
 __device__ __forceinline__ void span_step_done() {

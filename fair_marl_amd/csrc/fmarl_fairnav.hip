@@ -567,6 +567,26 @@ __global__ __launch_bounds__(kThreads, 4) void fairnav_kernel(Params p, FmarlOut
     fairnav_body<STEP>(p, o, action_idx, action_vec, auto_reset);
 }
 
+// fmarl_step_span for nav_fairassign_fairrew_formation_graph: T steps of the workgroup's own envs in one launch, episode ends
+// included (the step resets its ended envs itself).  The state goes through global memory between the steps -- a workgroup
+// re-reads what it wrote itself: L2 hits -- and nothing is carried in registers: with a register carry the kernel needed 181
+// VGPRs (or spilled at 128) and ran SLOWER than a launch per step (round 3, profiles/r3_notes.md).  What the span saves is what
+// lies outside the waves' lifetimes: a wave of the step launch lives 36-44 us of the launch's 60 (dispatch, the write-back of
+// the L2 at the kernel's end) and the next launch starts 6 us later (profiles/r4_ticks_fnav.txt).
+// All arguments are one struct, re-read from the argument block inside the time loop (span_params_reloaded): held in scalar
+// registers across a whole step -- shapes, eight output pointers, nine strides -- they spill twice as many registers.
+struct FairnavSpanArgs { Params p; FmarlOutputs o; SpanStrides s; const int32_t *action_idx; const float *action_vec; int T, auto_reset; };
+__global__ __launch_bounds__(kThreads, 4) void fairnav_span_kernel(FairnavSpanArgs) {
+    for (int t = 0;; ++t) {
+        const FairnavSpanArgs &a = span_params_reloaded<FairnavSpanArgs>();
+        if (t >= a.T) break;
+        const FmarlOutputs ot = span_outputs(a.o, a.s, t);
+        fairnav_body<true>(a.p, ot, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
+                           a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset);
+        span_step_done();   // the next step reads this step's state stores, and overwrites the LDS tables the emission read
+    }
+}
+
 // Learner-side reconstruction of node_obs / adj of nav_fairassign_fairrew_formation_graph envs from the gathered records:
 // per agent and step [x, y, vx, vy, newly-stopped | (goal code, occupancy, history) x N] written by fairnav_kernel
 // (FmarlOutputs.graph_record) + the once-per-episode record of the static entities (fmarl_rebuild.hip layout).  Same LDS

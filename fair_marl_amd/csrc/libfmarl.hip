@@ -760,11 +760,11 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
     int t = 0;
     while (t < n_steps) {
         // steps that certainly end no episode go out as one span launch; the step that ends an episode and envs out of
-        // lockstep go through fmarl_step.  The third scenario's
-        // episodes end env by env and its step is one workgroup's dependent chain, not a store stream: a span kernel of it
-        // measured SLOWER than a launch per step (0.086 vs 0.075 ms per step, profiles/r3_notes.md), so it always steps.
+        // lockstep go through fmarl_step.  The third scenario's episodes end env by env and its step resets them itself: all
+        // its steps are one launch (fairnav_span_kernel: the state through global memory between the steps).
         int k = 0;
-        if (sc != FMARL_SCENARIO_FAIRNAV && h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;
+        if (sc == FMARL_SCENARIO_FAIRNAV) k = n_steps - t;
+        else if (h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;
         if (k > n_steps - t) k = n_steps - t;
         FmarlOutputs o = *outs;
         if (o.obs) o.obs += (size_t)t * span->obs;
@@ -789,14 +789,16 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
             if (!outputs_aligned(p, &o)) return fail(FMARL_EINVAL, "fmarl_step_span: node_obs / adj must be 16-byte aligned for this shape");
             const bool prof = h->ev && h->ev_n < h->ev_cap;
             if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
-            if (sc == FMARL_SCENARIO_FORMATION)
+            if (sc == FMARL_SCENARIO_FAIRNAV)
+                hipLaunchKernelGGL(fairnav_span_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, FairnavSpanArgs{p, o, s, a, av, k, 1});
+            else if (sc == FMARL_SCENARIO_FORMATION)
                 hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             else
                 hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = k; ++h->ev_n; }
             HIP_OK(hipGetLastError());
             if (h->lockstep) h->host_step += k;
-            h->episode_started = false;
+            h->episode_started = sc == FMARL_SCENARIO_FAIRNAV;   // (as fmarl_step: that scenario's envs start their episodes inside the step)
             h->counts[0] += k;
             t += k;
         } else {

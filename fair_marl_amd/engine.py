@@ -598,7 +598,8 @@ class RolloutEngine:
         action vectors (the reference's one-hot / continuous form, as for ``step``) -- through ``fmarl_step_span``: the steps
         between episode ends go out as ONE launch in which every workgroup walks its own envs through time (envs never
         interact; no per-step launch, no per-step head and tail of the grid), the step that ends an episode as a launch of
-        its own.  Same results as T ``step`` calls, bit for bit.  By default every step writes the engine's current output
+        its own (nav_fairassign_fairrew_formation_graph resets its ended envs inside the step: the whole tape is one
+        launch).  Same results as T ``step`` calls, bit for bit.  By default every step writes the engine's current output
         set (what is left in it are the last step's outputs); ``strides`` = dict of per-step element strides for 'obs',
         'node_obs', 'adj', 'reward', 'done', 'info', 'edge_nnz', 'graph_record' makes step t write the set's buffers shifted
         by t strides -- the time slots of a rollout buffer laid out (T, n, ...) (``DeviceRolloutBuffer.insert_span``)."""
@@ -624,12 +625,13 @@ class RolloutEngine:
         rollout of the reference's throughput runs, or a scripted tape.  Outputs of the last step are in the engine's current
         output set.  ``mode``:
 
-        * ``'span'`` (default for navigation_graph and fair_graph_formation): ``step_span`` -- one launch per run of steps
-          between episode ends (10 agents x 65 536 envs: 0.250 -> 0.199 ms per step; 3 agents x 4 096 envs: 14.5 -> 11.5 us);
+        * ``'span'`` (default): ``step_span`` -- one launch per run of steps between episode ends (10 agents x 65 536 envs:
+          0.250 -> 0.199 ms per step; 3 agents x 4 096 envs: 14.5 -> 11.5 us); nav_fairassign_fairrew_formation_graph, whose
+          episodes end env by env inside the step: the whole tape as ONE launch (65 536 x 3: 0.059 -> 0.050 ms per step);
         * ``'graph'``: one hipGraph replay per call, captured on first use and cached per (tape tensor, length, output set,
           episode phase) -- valid while the caller refills the same tensor in place; needs envs in lockstep and a phase / length
           the lean capture covers, otherwise the call falls through to ``'eager'`` (always so for
-          nav_fairassign_fairrew_formation_graph, whose episodes end env by env: its default is ``'eager'``);
+          nav_fairassign_fairrew_formation_graph, whose envs are never in lockstep);
         * ``'eager'``: one ``step`` call per step.
 
         ``use_graph`` (older spelling): True = 'graph' where valid, False = 'eager'.
@@ -643,7 +645,7 @@ class RolloutEngine:
         if mode is None and use_graph is not None:
             mode = 'graph' if use_graph else 'eager'
         if mode is None:
-            mode = 'span' if self.cfg.scenario_name != 'nav_fairassign_fairrew_formation_graph' else 'eager'
+            mode = 'span'
         if mode == 'span':
             if ring is not None:
                 self.use_outputs(ring.sets[0])

@@ -239,9 +239,10 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
  * same buffer, e.g. a rollout that only needs the last observation; the slots of a rollout buffer laid out (T, n, ...) have
  * stride n * ...).  Envs never interact, so inside a span every workgroup walks its own envs through the steps without waiting
  * for the rest of the batch: no per-step launch, no per-step head and tail of the grid.  The step that ends an episode is a
- * launch of its own (it commits / resets and, with the staged reset, waits for the staging that ran beside the span); so are
- * every step while the envs are not in lockstep and every step of
- * nav_fairassign_fairrew_formation_graph (whose step is a dependent chain, not a store stream: a span of it is slower).
+ * launch of its own (it commits / resets and, with the staged reset, waits for the staging that ran beside the span); so is
+ * every step while the envs are not in lockstep.  nav_fairassign_fairrew_formation_graph, whose envs end their episodes one
+ * by one and are reset inside the step, runs ALL n_steps as one launch (fairnav_span_kernel: the state goes through L2
+ * between the steps; 65 536 x 3: 0.059 -> 0.050 ms per step, profiles/r4_notes.md).
  * The scripted / random-action rollout of the reference's throughput runs; a policy in the loop needs fmarl_step.  Not
  * capturable into a hipGraph (it decides on the host where episodes end; it needs no graph: an episode is three launches).
  * Measured (profiles/r3_notes.md): 10 agents x 65 536 envs 0.250 -> 0.199 ms per step, 3 agents x 4 096 envs 14.5 -> 11.5 us. */

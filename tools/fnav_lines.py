@@ -1,0 +1,8 @@
+import sys, os, json
+sys.path.insert(0, os.getcwd())
+import torch, bench
+dev = torch.device('cuda:0'); torch.cuda.set_device(dev)
+for rep in range(2):
+    for mode in ('eager', 'span', 'steady', 'steady-span'):
+        d = bench.secondary_line('fnav', mode, dev)
+        print(mode, 'ms_per_step %.4f kernel %.4f frac %.3f launches %d kernel=%s' % (d['ms_per_step'], d['kernel_avg_ms'], d['frac'], d['kernel_launches'], d['kernel']), flush=True)
