@@ -286,9 +286,11 @@ struct PlacedEnvLds {
 //                 workgroup of a training run, where episodes end at all phases -- 0.052 ms per launch when no env ends,
 //                 0.086 when two or three per workgroup do.)
 //   STEP = false: the observation part of an explicit reset (fmarl_reset: placement and assignment by their own kernels).
+//   `resident` (a later step of a span): the static entities of the workgroup's envs are still in their LDS tables -- the previous
+//                 step left them there, and re-read them for the envs it reset.
 template <bool STEP>
 __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
-                                             const float *action_vec, int auto_reset) {
+                                             const float *action_vec, int auto_reset, bool resident = false) {
     FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int env0 = env_block(p) * p.epb;
@@ -315,7 +317,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
     if (!STEP && !__syncthreads_or(flagged)) return;
     if (in_range && i == 0) *t.flag() = (STEP || flagged) ? 0 : 1;   // (a step emits every env: the ended ones after their reset)
-    load_statics(p, lds, env0, nenv);
+    if (!resident) load_statics(p, lds, env0, nenv);
     __syncthreads();
     FMARL_TICK(0);   // state loads, entity tables, barrier
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
@@ -556,9 +558,9 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
 
 template <bool STEP>
 __device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
-                                             const float *action_vec, int auto_reset) {
+                                             const float *action_vec, int auto_reset, bool resident = false) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset);
+    fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset, resident);
 }
 
 template <bool STEP>
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kThreads, 4) void fairnav_span_kernel(FairnavSpanAr
         if (t >= a.T) break;
         const FmarlOutputs ot = span_outputs(a.o, a.s, t);
         fairnav_body<true>(a.p, ot, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
-                           a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset);
+                           a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset, t > 0);
         span_step_done();   // the next step reads this step's state stores, and overwrites the LDS tables the emission read
     }
 }
