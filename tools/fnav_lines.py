@@ -1,3 +1,5 @@
+"""measurement aid (GPU box): bench.py's four `secondary` entries of nav_fairassign_fairrew_formation_graph (one launch per step / span,
+lockstep start / episodes ending at all phases), twice; FMARL_LIB selects a library variant.  usage: python tools/fnav_lines.py"""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import torch, bench
