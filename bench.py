@@ -283,7 +283,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     for _ in range(max(1, warmup // ep) + pre_steps // ep):
         episode(timed)
     torch.cuda.synchronize(device)
-    eng.profile_enable(steps)
+    # one launch per step: an event pair around every launch sits BETWEEN the launches (6-7 us per step at 65 536 x 3: a tenth of the
+    # step) -- the wall time comes from a pass without them, the kernel times from a second pass of the same steps
+    eng.profile_enable(steps if rmode != 'eager' else 0)
     c0 = eng.launch_counts()
     if rmode == 'graph':
         for _ in range(2):
@@ -298,6 +300,12 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
         episode(rmode)
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    if rmode == 'eager':
+        eng.profile_enable(steps)
+        c0 = eng.launch_counts()
+        for _ in range(steps // ep):
+            episode(rmode)
+        torch.cuda.synchronize(device)
     if rmode != 'graph':
         kernel_ms, c1 = eng.profile_read(), eng.launch_counts()
     k_step = float(np.sum(kernel_ms)) / (c1[0] - c0[0])       # step-kernel time per step (a span launch covers many)
@@ -334,6 +342,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     if n * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS:
         out['bound'] = ('launch / latency: the batch cannot fill the chip (%d waves on 256 CUs), a step is one wave\'s dependent float64 chain; '
                         'an HBM roofline does not apply -- `frac` is reported for completeness' % ((n * cfg.N + 63) // 64))
+    if rmode == 'eager':
+        out['timing'] = ('ms_per_step: a pass without per-launch events; kernel_avg_ms: a second pass of the same steps with a hipEvent pair '
+                         'around every launch (the pairs sit between the launches and delay their dispatch: kernel_avg_ms can exceed ms_per_step)')
     if mode.startswith('steady'):
         out['regime'] = 'min_dist_thresh %.2f, %d untimed steps first: episodes end env by env at all phases' % (STEADY['min_dist_thresh'], pre_steps)
     return out
