@@ -191,6 +191,8 @@ def moved_bytes(cfg, agents, steps):
     per_step = algorithmic_bytes(cfg)
     C = 2 * (cfg.num_landmarks + cfg.num_obstacles) + 6 * cfg.num_walls
     once = 4.0 * (2 * 12 + C / cfg.N)
+    if cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph':
+        once = 4.0 * C / cfg.N   # (its span keeps the static entities in LDS; the state goes through global memory every step)
     return agents * ((per_step - once) * steps + once)
 
 
@@ -872,7 +874,8 @@ def main():
             steps_per_launch = float(kernel_steps[span_launches].mean())
             bytes_per_launch = agents * algorithmic_bytes(cfg) * steps_per_launch
             bytes_moved = moved_bytes(cfg, agents, steps_per_launch)
-            kernel_name = 'formation_span_kernel' if cfg.scenario_name == 'fair_graph_formation' else 'step_span_kernel'
+            kernel_name = {'fair_graph_formation': 'formation_span_kernel',
+                           'nav_fairassign_fairrew_formation_graph': 'fairnav_span_kernel'}.get(cfg.scenario_name, 'step_span_kernel')
         else:
             k_avg_ms = float(kernel_ms.mean()) if kernel_ms.size else float('nan')
             steps_per_launch = 1.0
@@ -891,9 +894,10 @@ def main():
         emis_ms = emission_only_ms(eng) if pipe is None else None
         launch_text = {
             'span': 'fmarl_step_span: runs of steps (up to the episode end%s) as ONE launch each in which every workgroup walks its own envs through '
-                    'time (%d envs per workgroup; state in registers, static entities in LDS between the steps), the step that ends an episode '
-                    'as a launch of its own: %d launches for the %d timed steps'
-                    % ('' if span_steps >= ep else ', at most %d steps' % span_steps, eng.envs_per_workgroup, len(kernel_ms), K),
+                    'time (%d envs per workgroup; %s), the step that ends an episode %s: %d launches for the %d timed steps'
+                    % ('' if span_steps >= ep else ', at most %d steps' % span_steps, eng.envs_per_workgroup,
+                       'state through L2, static entities in LDS between the steps' if fnav_sc else 'state in registers, static entities in LDS between the steps',
+                       'inside the span (this scenario resets its ended envs in the step)' if fnav_sc else 'as a launch of its own', len(kernel_ms), K),
             'step': ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
                      % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step'),
             'graph': 'one hipGraph replay per episode of %d steps (kernel_avg_ms from an eager pass before the timed region)' % ep}[launch]

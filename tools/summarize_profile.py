@@ -39,7 +39,7 @@ stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % stem))
 mode = bench['config'].get('launch_mode', 'step')
 if mode == 'span':   # the dominant kernel is the span kernel (a launch = a run of steps)
-    kname = 'formation_span_kernel' if cfg == 'cfg4' else 'step_span_kernel'
+    kname = {'cfg4': 'formation_span_kernel', 'fnav': 'fairnav_span_kernel'}.get(cfg, 'step_span_kernel')
 else:
     kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
