@@ -875,9 +875,14 @@ struct RingAlloc {
 };
 void ring_release(RingAlloc *r) {
     if (!r) return;
-    if (r->ptr && r->mapped) (void)hipMemUnmap(r->ptr, r->mapped * r->piece);
+    for (size_t k = 0; r->ptr && k < r->mapped; ++k) (void)hipMemUnmap((char *)r->ptr + k * r->piece, r->piece);   // (piece by piece, as they were mapped)
     for (auto h : r->handles) (void)hipMemRelease(h);
-    if (r->ptr) (void)hipMemAddressFree(r->ptr, r->total);
+    // The virtual address range is NOT given back (hipMemAddressFree).  On this stack (ROCm 7.2, MI355X) an address range that is
+    // freed and handed out again by a later hipMemAddressReserve keeps stale translations in the GPU for a while: an array mapped
+    // there read back zeroes in up to 70 % of its bytes right after a fill, other bytes changed seconds later, two reads of the
+    // same element disagreed (tools/vmm_reuse_probe.py; tests/test_hip_parity.py test_time_slots_after_a_freed_array_keep_what_is_written).
+    // With the ranges kept out of circulation: none of it.  The physical memory is returned above; what leaks is address space -- 47 bits of it,
+    // against at most a few hundred GB per array.
     delete r;
 }
 }  // namespace

@@ -1804,3 +1804,31 @@ def test_time_slots_with_interleaved_physical_memory():
     assert torch.equal(rings[0].node_obs, before)        # the same rollout, written through the second engine into the first ring's memory
     with pytest.raises(ValueError):
         fm.OutputRing(fm.RolloutEngine(cfg, n // 2, device=DEV, seed=9), 25, like=rings[0])
+
+
+def test_time_slots_after_a_freed_array_keep_what_is_written():
+    """fmarl_ring_alloc after fmarl_ring_free in one process: the new array must hold what a kernel writes into it right away, and keep
+    it.  (It did not while freed virtual address ranges were handed back to the runtime: a later reservation got the same addresses
+    and the GPU used stale translations for them -- tools/vmm_reuse_probe.py; the allocator keeps freed ranges out of circulation.)"""
+    import gc
+    import time
+    from fair_marl_amd import _lib
+    from fair_marl_amd.engine import alloc_time_slots
+    lib = _lib.load()
+    shapes = [(2, 32768, 10, 16, 12), (2, 32768, 3, 9, 13), (2, 32768, 10, 16, 12), (2, 32768, 3, 9, 13), (2, 32768, 6, 16, 11),
+              (2, 32768, 10, 16, 12), (2, 32768, 6, 16, 11)]
+    for k, shape in enumerate(shapes):
+        t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
+        assert interleaved
+        t.fill_(float(k + 1))
+        torch.cuda.synchronize()
+        flat = t.view(-1)
+        assert int((flat != float(k + 1)).sum()) == 0, 'array %d right after its fill' % k
+        time.sleep(0.3)
+        assert int((flat != float(k + 1)).sum()) == 0, 'array %d 0.3 s later' % k
+        assert int((flat.cpu() != float(k + 1)).sum()) == 0, 'array %d copied to the host' % k
+        assert int((flat != float(k + 1)).sum()) == 0, 'array %d after the copy' % k
+        del t, flat
+        gc.collect()
+        torch.cuda.synchronize()
+
