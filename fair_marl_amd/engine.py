@@ -53,8 +53,10 @@ class RolloutEngine:
             self._state_ptr = self.state.data_ptr()
             # emit_graph=False (the reference's non-graph MPEEnv, MPE_env.py:21-53): node_obs / adj are never
             # computed -- the kernels skip the whole emission when handed NULL pointers
-            self.node_obs = torch.zeros(n, N, E, F, dtype=torch.float32, device=self.device) if emit_graph else None
-            self.adj_env = torch.zeros(n, E, E, dtype=torch.float32, device=self.device) if emit_graph else None
+            # (arrays of 64 MiB and more are made of hipMemCreate pieces -- alloc_time_slots: at 10 agents x 65 536 envs a launch streams
+            # into those 13 % faster than into one plain allocation, profiles/r4_notes.md)
+            self.node_obs = alloc_time_slots(self.lib, self.device, (1, n, N, E, F), zero=True, single=True)[0][0] if emit_graph else None
+            self.adj_env = alloc_time_slots(self.lib, self.device, (1, n, E, E), zero=True, single=True)[0][0] if emit_graph else None
             self.agent_id = torch.arange(N, device=self.device).view(1, N, 1).expand(n, N, 1)
         self.emit_info, self.emit_graph = emit_info, emit_graph
         # count_edges: the adj emission also counts every env's policy edges (process_adj then never reads adj back)
@@ -742,15 +744,16 @@ class _SpreadBlock(object):
             pass
 
 
-def alloc_time_slots(lib, device, shape, spread=None, zero=False):
+def alloc_time_slots(lib, device, shape, spread=None, zero=False, single=False):
     """A float32 device tensor of ``shape`` = (T, ...) for T time slots: virtually contiguous, and -- ``spread`` True, or None and a slot
     is 64 MiB or more -- with its physical memory interleaved piece by piece over the whole array (``fmarl_ring_alloc``; see
     ``OutputRing``).  Falls back to a plain allocation where the slot size has no suitable divisor or the device has no virtual
-    memory management (``spread=True`` raises instead).  -> (tensor, interleaved?)"""
+    memory management (``spread=True`` raises instead).  ``single``: also for T = 1 (one array: nothing to interleave, but an array made
+    of ``hipMemCreate`` pieces takes a store stream faster than one plain allocation of the same size).  -> (tensor, interleaved?)"""
     T, slot_bytes = int(shape[0]), 4 * int(np.prod(shape[1:]))
     if spread is None and os.environ.get('FMARL_RING_SPREAD') == '0':   # (measurement aid: plain allocations)
         spread = False
-    if T >= 2 and (spread or (spread is None and slot_bytes >= (64 << 20))):
+    if (T >= 2 or single) and (spread or (spread is None and slot_bytes >= (64 << 20))):
         try:
             t = torch.as_tensor(_SpreadBlock(lib, device, shape, slot_bytes, T), device=device)
             if zero:

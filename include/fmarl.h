@@ -318,7 +318,9 @@ int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, i
  * launch that writes ONE time slot (a policy in the loop: fmarl_step) gets the rate of the whole ring.  piece_bytes = 0: the
  * library's choice (<= 16 MiB, a divisor of slot_bytes); otherwise a multiple of the allocation granularity that divides
  * slot_bytes.  FMARL_EINVAL when the slot size has no such divisor, FMARL_EHIP when the device has no virtual memory management:
- * allocate plainly then.  The memory belongs to the caller until fmarl_ring_free(cookie) (no launch may still use it). */
+ * allocate plainly then.  The memory belongs to the caller until fmarl_ring_free(cookie) (no launch may still use it).
+ * fmarl_ring_free returns the physical memory; the array's virtual address range stays reserved for the life of the process (a range
+ * that is freed and reserved again reads back stale data on this stack: tools/vmm_reuse_probe.py -- address space is not scarce). */
 int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **base, void **cookie);
 int fmarl_ring_free(void *cookie);
 
