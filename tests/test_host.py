@@ -364,6 +364,9 @@ def test_hot_kernels_keep_their_register_and_scratch_budget():
                                                  # the span kernels (the bench's default launch mode) and the learner-side gather: the latter once
                                                  # compiled to 179 VGPRs = two waves per SIMD for a copy kernel (profiles/r3_notes.md)
                                                  ('16step_span_kernel', 160, 0, 3), ('21formation_span_kernel', 128, 0, 4),
-                                                 ('23minibatch_gather_kernel', 112, 0, 4)):
+                                                 ('23minibatch_gather_kernel', 112, 0, 4),
+                                                 # (its 112 bytes of scratch are thread-index arithmetic hoisted out of the time loop and
+                                                 # reloaded at loop depth 1, none of it inside the emission loops: profiles/r4_notes.md section 12)
+                                                 ('19fairnav_span_kernel', 128, 128, 4)):
         vgpr, scratch, occ = find(part)
         assert vgpr <= max_vgpr and scratch <= max_scratch and occ >= min_occ, (part, vgpr, scratch, occ)
