@@ -445,10 +445,12 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                     place_env(p, pl, kResetAuto, env, false);
                 }
             }
-            __threadfence_block();   // the static entities of the placed envs are re-read from the state below
+            __threadfence_block();   // (walls: the static entities of the placed envs are re-read from the state below)
             __syncthreads();
             if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
-                load_statics_range(p, lds, env0, el, el + 1, i, N);   // f32 copies of the new landmarks / obstacles, wall tables
+                if (p.W == 0) {   // the placement left the new landmarks / obstacles in the env's float64 table: their f32 copies from there
+                    for (int k = i; k < L + p.O; k += N) { const double2 e = t.pos()[N + k]; t.posf()[N + k] = make_float2((float)e.x, (float)e.y); }
+                } else load_statics_range(p, lds, env0, el, el + 1, i, N);   // (+ the wall tables: a round trip through global memory)
                 const double2 nx = t.pos()[i];   // (the placement wrote the env's float64 table)
                 t.occ()[i] = 0.0; t.hist()[i] = -1;
                 t.agentf()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
