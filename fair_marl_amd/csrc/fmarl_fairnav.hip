@@ -445,6 +445,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                     place_env(p, pl, kResetAuto, env, false);
                 }
             }
+            FMARL_TICK(11);   // (measure builds) the placement itself, by the first lane of every ended env
             __threadfence_block();   // (walls: the static entities of the placed envs are re-read from the state below)
             __syncthreads();
             if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
