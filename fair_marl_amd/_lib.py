@@ -97,6 +97,7 @@ _SIGS = {
     'fmarl_insert_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     'fmarl_ring_alloc': (C.c_int, [C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'fmarl_ring_free': (C.c_int, [C.c_void_p]),
+    'fmarl_ring_stats': (C.c_int, [C.POINTER(C.c_uint64)]),
     'fmarl_store_stream': (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     'fmarl_profile_read': (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     'fmarl_cost_matrix': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -32,42 +32,49 @@ __device__ __forceinline__ double bperm_f64(int addr, double v) {
 
 // Min-sum assignment (Kuhn-Munkres with potentials, shortest augmenting paths) of ONE env by the env's own N agent lanes: lane
 // `li` of the segment [base, base + N) of the wave owns column li (v, minv, way, matched row) and row li (u, in-tree flag).
-// Every env of the wave runs its matching at the same time (64 / N envs: 60 of 64 lanes at ten agents), where rounds 2-3 dealt
-// (env, which) tasks to four 16-lane groups -- 40 of 64 lanes, three rounds per step at cfg 4 instead of two.  The cross-lane
-// traffic: the argmin as a rotation all-reduce (partners li + 1, 2, 4, ... mod N: ceil(log2 N) steps, every lane ends with the
-// minimum of a cyclic window >= N), a few single-lane reads (ds_bpermute).  Costs are |x_row - P_col| computed on the fly
-// (x: agent positions in LDS, Pc: the lane's own slot).  The optimum is unique for generic real costs, so it equals SciPy's
+// Every env of the wave runs its matchings at the same time (64 / N envs: 60 of 64 lanes at ten agents).  The cross-lane
+// traffic: the argmin as a rotation all-reduce, a few single-lane reads (ds_bpermute).  Costs are |x_row - P_col| computed on the
+// fly (x: agent positions in LDS, Pc: the lane's own slot).  The optimum is unique for generic real costs, so it equals SciPy's
 // linear_sum_assignment (ff:615-618) whatever the start.
 // Warm start: `v` = column potential left by an earlier matching on nearly the same costs (any values are feasible once u = the
 // row minima of c - v: `u` / `mine` = reduced row minimum and its column, from the kernel's agent x slot distance pass);
-// every row claims the column of its minimum, the lowest row wins a contested one (`claim`: an LDS table of N ints of the
-// env), only the rows left without a column go through the augmenting search.  ans[row] = col; returns the final column
-// potential shifted so that the maximum over the columns is 0.
+// every row claims the column of its minimum, the lowest row wins a contested one (`claim`: an LDS table of N ints per
+// matching), only the rows left without a column go through the augmenting search.
 struct SegLanes {
-    int N, li, base, self4, rot[5], steps;
+    int N, li, base, self4, rot[7];
     uint32_t full;
     __device__ __forceinline__ SegLanes(int N_, int li_, int base_) : N(N_), li(li_), base(base_) {
         self4 = (base + li) << 2;
-        steps = 0;
+        // partners of the rotation all-reduce, radix 4: round r reads the lanes li + k 4^r (mod N), k = 1, 2, 3 -- three
+        // independent ds_bpermute round trips in flight at once, then the window every lane has seen is four times as wide.
+        // (Round 4 doubled the window per round: four DEPENDENT round trips at ten agents where this takes two.)
+        constexpr int off[7] = {1, 2, 3, 4, 8, 12, 16};
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {   // (N <= 32; fixed trip count: rot[] stays in registers)
-            int q = li + (1 << s);
+        for (int s = 0; s < 7; ++s) {   // (N <= 32; fixed trip count: rot[] stays in registers)
+            int q = li + off[s];
             q = q >= N ? q - N : q;
-            rot[s] = (base + ((1 << s) < N ? q : li)) << 2;
-            steps += (1 << s) < N ? 1 : 0;
+            rot[s] = (base + (off[s] < N ? q : li)) << 2;
         }
         full = N >= 32 ? ~0u : ((1u << N) - 1);
     }
     __device__ __forceinline__ int at(int k) const { return (base + k) << 2; }   // bpermute address of segment lane k
+    template <bool MAX> static __device__ __forceinline__ double pick(double a, double b) {
+        // one v_min_f64 / v_max_f64 (asm: the builtin form canonicalises both operands first; no NaNs here)
+        if (MAX) asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+        else asm("v_min_f64 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+        return a;
+    }
+    // min / max over the segment, in every lane of it (every lane ends with the extreme of a cyclic window >= N)
     template <bool MAX> __device__ __forceinline__ double extreme(double v) const {
-#pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            if (s < steps) {   // (uniform)
-                const double o = bperm_f64(rot[s], v);
-                if (MAX) asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
-                else asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
-            }
+        if (N > 1) {   // (all conditions uniform)
+            const double o1 = bperm_f64(rot[0], v), o2 = N > 2 ? bperm_f64(rot[1], v) : v, o3 = N > 3 ? bperm_f64(rot[2], v) : v;
+            v = pick<MAX>(pick<MAX>(v, o1), pick<MAX>(o2, o3));
         }
+        if (N > 4) {
+            const double o1 = bperm_f64(rot[3], v), o2 = N > 8 ? bperm_f64(rot[4], v) : v, o3 = N > 12 ? bperm_f64(rot[5], v) : v;
+            v = pick<MAX>(pick<MAX>(v, o1), pick<MAX>(o2, o3));
+        }
+        if (N > 16) v = pick<MAX>(v, bperm_f64(rot[6], v));
         return v;
     }
     __device__ __forceinline__ uint32_t bits(bool pred) const {   // the segment's lanes whose predicate holds, bit k = lane k
@@ -75,65 +82,95 @@ struct SegLanes {
     }
 };
 
-__device__ __forceinline__ double hungarian_seg(const SegLanes &sl, const bool act, const double2 *x, const double2 Pc, double u, const int mine,
-                                                double v, int8_t *ans, int *claim, const int which) {
+// The matchings of one step, as ONE loop: against the current slots (A: slot PA, row start uA / mineA -> ansA[row] = col, returns
+// its final column potential shifted so that the maximum over the columns is 0: the next step's warm start) and, when `needB`,
+// against the previous slots (B -> ansB; its potentials are dropped).  Both start from the potentials `v0`.
+//
+// Round 4 ran them one after the other as nested loops -- over the rows left without a column, over the search iterations of
+// a row, over the columns of its augmenting path -- and a wave's envs walked those in lockstep: every loop ran as long as the
+// env of the wave that needed it longest (tools/matching_sim.py: 42.5 search trips + 23.5 path trips per wave and step at ten
+// agents, where one env needs 17.3 + 9.9).  Here every env advances its own state machine: a trip of the one loop is one
+// search iteration of whatever row / matching the env is at, so the wave runs as long as its busiest env's TOTAL (28.3 trips),
+// and the path is flipped in one parallel step instead of a walk: each column carries the bit mask of the columns on the path
+// from the root to itself (`pmask`: the mask of the column it was reached from, plus itself), so when the search ends at a
+// free column j1 the columns of pmask(j1) each take the row of their predecessor at once (one ds_bpermute).
+// The arithmetic of one env is the same sequence as before: results and potentials are bit-identical.
+__device__ __forceinline__ double hungarian_pair(const SegLanes &sl, const bool act, const double2 *x, const double2 PA, const double uA,
+                                                 const int mineA, const bool needB, const double2 PB, const double uB, const int mineB,
+                                                 const double v0, int8_t *ansA, int8_t *ansB, int *claim) {
     const int N = sl.N, li = sl.li;
     const double INF = 1e300;
-    // start: the lowest row that claims a column gets it (those edges are tight)
-    if (act) claim[li] = N;
+    // start: the lowest row that claims a column gets it (those edges are tight); claim[0..N) for A, [N..2N) for B
+    if (act) { claim[li] = N; claim[N + li] = N; }
     wave_sync();
-    if (act) atomicMin(&claim[mine], li);
+    if (act) { atomicMin(&claim[mineA], li); if (needB) atomicMin(&claim[N + mineB], li); }
     wave_sync();
-    int prow = -1;   // row matched to column li
-    bool unmatched = false;
+    int prow = -1, prowB = -1;   // row matched to column li
+    bool unA = false, unB = false;
     if (act) {
-        const int c = claim[li];
+        const int c = claim[li], cB = claim[N + li];
         prow = c < N ? c : -1;
-        unmatched = claim[mine] != li;
+        prowB = cB < N ? cB : -1;
+        unA = claim[mineA] != li;
+        unB = needB && claim[N + mineB] != li;
     }
-    uint32_t um = sl.bits(unmatched);
+    uint32_t um = sl.bits(unA), umB = sl.bits(unB);
 #ifdef FMARL_HSTAT
-    if (act && li == 0) { atomicAdd(&g_fmarl_hstat[which][0], 1ull); atomicAdd(&g_fmarl_hstat[which][2], (unsigned long long)__builtin_popcount(um)); }
+    if (act && li == 0) {
+        atomicAdd(&g_fmarl_hstat[0][0], 1ull); atomicAdd(&g_fmarl_hstat[0][2], (unsigned long long)__builtin_popcount(um));
+        if (needB) { atomicAdd(&g_fmarl_hstat[1][0], 1ull); atomicAdd(&g_fmarl_hstat[1][2], (unsigned long long)__builtin_popcount(umB)); }
+    }
 #endif
-    while (um) {
-        const int i = __builtin_ctz(um);
-        um &= um - 1;
-        double minv = INF;
-        int way = -1, j0 = -1, i0 = i, j1 = -1;
-        bool usedc = false, in_tree = li == i;
-        for (int it = 0; it <= N; ++it) {   // at most N columns can join the tree
+    double2 Pc = PA;
+    double u = uA, v = v0, vfin = v0, minv = INF;
+    int pfin = prow, i = 0, i0 = 0, j0 = -1, way = -1, second = 0;
+    uint32_t pmask = 0, pm0 = 0;
+    bool usedc = false, in_tree = false, working = act;
+    // the next row without a column; when the matching has none left: on to matching B (its potentials start from v0 again), then out
+#define FMARL_NEXT_ROOT()                                                                                                    \
+    {                                                                                                                        \
+        if (um == 0 && second == 0) { vfin = v; pfin = prow; second = 1; Pc = PB; u = uB; v = v0; prow = prowB; um = umB; }  \
+        if (um == 0) working = false;                                                                                        \
+        else {                                                                                                               \
+            i = __builtin_ctz(um); um &= um - 1;                                                                             \
+            minv = INF; way = -1; usedc = false; in_tree = li == i; i0 = i; j0 = -1; pm0 = 0;                                \
+        }                                                                                                                    \
+    }
+    FMARL_NEXT_ROOT()
+    for (int trip = 0; working && trip < 2 * N * (N + 1); ++trip) {   // (a row's search adds at most N columns to its tree)
 #ifdef FMARL_HSTAT
-            if (li == 0) atomicAdd(&g_fmarl_hstat[which][3], 1ull);
+        if (li == 0) atomicAdd(&g_fmarl_hstat[second][3], 1ull);
 #endif
-            const double ui0 = bperm_f64(sl.at(i0), u);
-            const bool open = !usedc;
-            if (open) {
-                const double cur = dist2(x[i0], Pc) - ui0 - v;
-                if (cur < minv) { minv = cur; way = j0; }
-            }
-            const double delta = sl.extreme<false>(open ? minv : INF);
-            const uint32_t hit = sl.bits(open && minv == delta);   // ties to the lowest column
-            j1 = __builtin_ctz(hit);
-            if (in_tree) u += delta;
-            if (usedc) v -= delta; else minv -= delta;
-            if (li == j1) usedc = true;
-            j0 = j1;
-            const int r1 = bperm_i32(sl.at(j1), prow);
-            if (r1 < 0) break;
+        const double ui0 = bperm_f64(sl.at(i0), u);
+        const bool open = !usedc;
+        if (open) {
+            const double cur = dist2(x[i0], Pc) - ui0 - v;
+            if (cur < minv) { minv = cur; way = j0; pmask = pm0 | (1u << li); }
+        }
+        const double delta = sl.extreme<false>(open ? minv : INF);
+        const uint32_t hit = sl.bits(open && minv == delta);   // ties to the lowest column
+        const int j1 = __builtin_ctz(hit);
+        if (in_tree) u += delta;
+        if (usedc) v -= delta; else minv -= delta;
+        if (li == j1) usedc = true;
+        const int a1 = sl.at(j1);
+        const int r1 = bperm_i32(a1, prow);
+        const uint32_t pm1 = (uint32_t)bperm_i32(a1, (int)pmask);
+        if (r1 < 0) {   // a free column: flip the augmenting path back to the root (row i), all its columns at once
+            const int pw = bperm_i32(sl.at(way < 0 ? 0 : way), prow);
+            if ((pm1 >> li) & 1u) prow = way < 0 ? i : pw;
+            FMARL_NEXT_ROOT()
+        } else {
             if (li == r1) in_tree = true;
-            i0 = r1;
-        }
-        for (int j = j1; j >= 0;) {   // flip the augmenting path back to the root (row i)
-            const int jprev = bperm_i32(sl.at(j), way);
-            const int row = jprev < 0 ? i : bperm_i32(sl.at(jprev < 0 ? 0 : jprev), prow);
-            if (li == j) prow = row;
-            j = jprev;
+            i0 = r1; j0 = j1; pm0 = pm1;
         }
     }
+#undef FMARL_NEXT_ROOT
     double vout = 0.0;
     if (act) {
-        ans[prow] = (int8_t)li;
-        vout = v - sl.extreme<true>(v);
+        ansA[pfin] = (int8_t)li;
+        if (needB) ansB[prow] = (int8_t)li;
+        vout = vfin - sl.extreme<true>(vfin);
     }
     return vout;
 }
@@ -468,15 +505,12 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         // the previous ones -- that one only serves observation(agent 0) in its "free slot left" branch (ff:707-739): not when
         // agent 0 sits on a previous slot or every slot is taken (common once agents hold the ring)
         const SegLanes sl(N, i, elw * N);
-        int *claim = (int *)t.vdual();   // (the potentials' table: every lane has its own entry in `vd`, the distance pass is through)
-        vd_new = hungarian_seg(sl, active, t.pos(), P, rbest, rkb, vd, t.g_new(), claim, 0);
-        if (STEP) {
-            const bool need = active && !(*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0);
+        int *claim = (int *)t.vdual();   // (the potentials' table, N doubles = 2 N ints: every lane has its own entry in `vd`, the distance pass is through)
+        const bool need = STEP && active && !(*t.near_old0() >= 0 || ((~t.words()[0]) & full) == 0);
 #ifdef FMARL_HSTAT
-            if (active && !need && i == 0) atomicAdd(&g_fmarl_hstat[1][1], 1ull);
+        if (STEP && active && !need && i == 0) atomicAdd(&g_fmarl_hstat[1][1], 1ull);
 #endif
-            (void)hungarian_seg(sl, need, t.pos(), so, rbest_old, rkb_old, vd, t.g_old(), claim, 1);
-        }
+        vd_new = hungarian_pair(sl, active, t.pos(), P, rbest, rkb, need, so, rbest_old, rkb_old, vd, t.g_new(), t.g_old(), claim);
     }
     wave_sync();
     FMARL_TICK(5);   // matchings

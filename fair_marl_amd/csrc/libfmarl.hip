@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -868,22 +869,60 @@ int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, i
 
 // ---- time-slot arrays with interleaved physical memory (include/fmarl.h fmarl_ring_alloc)
 namespace {
+// A virtual address range this process reserved for an array of pieces.  Ranges are NEVER given back to the runtime
+// (hipMemAddressFree): on this stack (ROCm 7.2, MI355X) a range that is freed and handed out again by a later
+// hipMemAddressReserve keeps stale translations in the GPU for a while -- an array mapped there read back zeroes in up to 70 %
+// of its bytes right after a fill, other bytes changed seconds later, two reads of the same element disagreed
+// (tools/vmm_reuse_probe.py; tests/test_hip_parity.py test_time_slots_after_a_freed_array_keep_what_is_written).  With the
+// ranges kept out of the runtime's circulation: none of it.  What that costs is address space, and it is bounded here: a freed
+// array's range goes to a free list and the next request of the same (device, size) maps its fresh physical pieces into it --
+// the common case (a sweep, a test suite, an engine rebuilt with the same shape) reserves nothing new -- and a request that would
+// take the reservations past kRingReserveCap is refused with an error instead of growing without bound.
+struct RingRange { void *ptr; size_t total; int dev; bool in_use; };
 struct RingAlloc {
-    void *ptr = nullptr;
-    size_t total = 0, piece = 0, mapped = 0;   // `mapped` virtual pieces from the start of the range are mapped
+    size_t range = 0;                       // index into g_ranges
+    size_t piece = 0, mapped = 0;           // `mapped` virtual pieces from the start of the range are mapped
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
+std::mutex g_ring_mutex;
+std::vector<RingRange> g_ranges;
+uint64_t g_ring_reserved = 0, g_ring_reuses = 0, g_ring_check_fails = 0;
+constexpr uint64_t kRingReserveCap = (uint64_t)8 << 40;   // 8 TiB of the 47-bit address space
+
 void ring_release(RingAlloc *r) {
     if (!r) return;
-    for (size_t k = 0; r->ptr && k < r->mapped; ++k) (void)hipMemUnmap((char *)r->ptr + k * r->piece, r->piece);   // (piece by piece, as they were mapped)
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    RingRange &g = g_ranges[r->range];
+    for (size_t k = 0; k < r->mapped; ++k) (void)hipMemUnmap((char *)g.ptr + k * r->piece, r->piece);   // (piece by piece, as they were mapped)
     for (auto h : r->handles) (void)hipMemRelease(h);
-    // The virtual address range is NOT given back (hipMemAddressFree).  On this stack (ROCm 7.2, MI355X) an address range that is
-    // freed and handed out again by a later hipMemAddressReserve keeps stale translations in the GPU for a while: an array mapped
-    // there read back zeroes in up to 70 % of its bytes right after a fill, other bytes changed seconds later, two reads of the
-    // same element disagreed (tools/vmm_reuse_probe.py; tests/test_hip_parity.py test_time_slots_after_a_freed_array_keep_what_is_written).
-    // With the ranges kept out of circulation: none of it.  The physical memory is returned above; what leaks is address space -- 47 bits of it,
-    // against at most a few hundred GB per array.
+    g.in_use = false;   // the range stays reserved and waits for the next array of its size
     delete r;
+}
+
+// Does the freshly mapped array hold what is written into it?  (Only run on a range that carried an earlier array: re-mapping
+// into a range that never went back to the runtime is not the path that failed, but the failure's mechanism is not
+// established, so the first use of such a range is verified -- a pattern fill, 64 bytes of every piece read back, then zeroes.)
+// -> 0 = holds; otherwise a message in `why`
+bool ring_self_check(void *ptr, size_t total, size_t piece, char *why, size_t why_len) {
+    const uint32_t pat = 0x5AC3E1B7u;
+    hipError_t e = hipMemsetD32((hipDeviceptr_t)ptr, (int)pat, total / 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { snprintf(why, why_len, "pattern fill: %s", hipGetErrorString(e)); return false; }
+    const size_t pieces = total / piece;
+    uint32_t host[16];
+    size_t wrong = 0, first = 0;
+    for (size_t k = 0; k < pieces; ++k) {   // 64 bytes from the middle of every piece
+        e = hipMemcpy(host, (const char *)ptr + k * piece + piece / 2, sizeof host, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { snprintf(why, why_len, "read-back of piece %zu: %s", k, hipGetErrorString(e)); return false; }
+        bool ok = true;
+        for (uint32_t w : host) ok &= w == pat;
+        if (!ok && !wrong++) first = k;
+    }
+    if (wrong) { snprintf(why, why_len, "%zu of %zu pieces read back something else than the pattern (first: piece %zu)", wrong, pieces, first); return false; }
+    e = hipMemsetD32((hipDeviceptr_t)ptr, 0, total / 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { snprintf(why, why_len, "zero fill: %s", hipGetErrorString(e)); return false; }
+    return true;
 }
 }  // namespace
 
@@ -909,17 +948,36 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     }
     if (piece_bytes < gran || piece_bytes % gran || slot_bytes % piece_bytes)
         return fail(FMARL_EINVAL, "fmarl_ring_alloc: a slot must be a whole number of pieces, a piece a multiple of the allocation granularity");
-    const size_t per_slot = slot_bytes / piece_bytes, count = per_slot * (size_t)slots;
+    const size_t per_slot = slot_bytes / piece_bytes, count = per_slot * (size_t)slots, total = slot_bytes * (size_t)slots;
     RingAlloc *r = new (std::nothrow) RingAlloc();
     if (!r) return fail(FMARL_EINVAL, "fmarl_ring_alloc: out of host memory");
-    r->total = slot_bytes * (size_t)slots;
     r->piece = piece_bytes;
-    hipError_t e = hipMemAddressReserve(&r->ptr, r->total, (size_t)2 << 20, nullptr, 0);   // (the alignment must be a power of two; pieces need not be)
-    if (e != hipSuccess) {
-        (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
-        r->ptr = nullptr; ring_release(r);
-        return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e));
+    void *ptr = nullptr;
+    bool reused = false;
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        for (size_t k = 0; k < g_ranges.size() && !ptr; ++k)   // a kept range of exactly this size on this device
+            if (!g_ranges[k].in_use && g_ranges[k].dev == dev && g_ranges[k].total == total) {
+                g_ranges[k].in_use = true; r->range = k; ptr = g_ranges[k].ptr; reused = true; ++g_ring_reuses;
+            }
+        if (!ptr) {
+            if (g_ring_reserved + total > kRingReserveCap) {
+                delete r;
+                return fail(FMARL_EINVAL, "fmarl_ring_alloc: this process has reserved 8 TiB of address space for arrays of pieces (freed ranges are kept "
+                                          "and only re-used by arrays of the same size): allocate plainly");
+            }
+            hipError_t e = hipMemAddressReserve(&ptr, total, (size_t)2 << 20, nullptr, 0);   // (the alignment must be a power of two; pieces need not be)
+            if (e != hipSuccess) {
+                (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
+                delete r;
+                return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e));
+            }
+            g_ranges.push_back(RingRange{ptr, total, dev, true});
+            r->range = g_ranges.size() - 1;
+            g_ring_reserved += total;
+        }
     }
+    hipError_t e = hipSuccess;
     r->handles.reserve(count);
     for (size_t k = 0; k < count && e == hipSuccess; ++k) {   // physical pieces, in creation order
         hipMemGenericAllocationHandle_t h;
@@ -929,26 +987,62 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     // virtual piece j of slot t <- physical piece j * slots + t: a slot's pieces are spread evenly over the whole allocation
     for (size_t t = 0; t < (size_t)slots && e == hipSuccess; ++t)
         for (size_t j = 0; j < per_slot && e == hipSuccess; ++j) {
-            e = hipMemMap((char *)r->ptr + (t * per_slot + j) * piece_bytes, piece_bytes, 0, r->handles[j * (size_t)slots + t], 0);
+            e = hipMemMap((char *)ptr + (t * per_slot + j) * piece_bytes, piece_bytes, 0, r->handles[j * (size_t)slots + t], 0);
             if (e == hipSuccess) ++r->mapped;
         }
     if (e == hipSuccess) {
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice; acc.location.id = dev; acc.flags = hipMemAccessFlagsProtReadWrite;
-        e = hipMemSetAccess(r->ptr, r->total, &acc, 1);
+        // read / write for this device and for every device that has peer access to it (a learner rank's copy out of a time slot,
+        // tensor.to('cuda:1')): hipMalloc memory is peer-accessible once peer access is enabled, an array of pieces only for the
+        // devices named here.  Should the runtime refuse the peers, the array is still this device's.
+        std::vector<hipMemAccessDesc> acc(1);
+        acc[0].location.type = hipMemLocationTypeDevice; acc[0].location.id = dev; acc[0].flags = hipMemAccessFlagsProtReadWrite;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+        for (int d = 0; d < ndev; ++d) {
+            int can = 0;
+            if (d != dev && hipDeviceCanAccessPeer(&can, d, dev) == hipSuccess && can) {
+                hipMemAccessDesc a = acc[0]; a.location.id = d; acc.push_back(a);
+            }
+        }
+        e = hipMemSetAccess(ptr, total, acc.data(), acc.size());
+        if (e != hipSuccess && acc.size() > 1) { (void)hipGetLastError(); e = hipMemSetAccess(ptr, total, acc.data(), 1); }
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
-        ring_release(r);           // unmaps what was mapped, releases every piece, frees the range
+        ring_release(r);           // unmaps what was mapped, releases every piece; the range waits for the next request of its size
         return fail(FMARL_EHIP, "fmarl_ring_alloc: %s", hipGetErrorString(e));
     }
-    *base = r->ptr; *cookie = r;
+    char why[200] = "";
+    if (reused && !ring_self_check(ptr, total, piece_bytes, why, sizeof why)) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_ring_mutex);
+            ++g_ring_check_fails;
+        }
+        const size_t idx = r->range;
+        ring_release(r);
+        {   // this range is never handed out again
+            std::lock_guard<std::mutex> lock(g_ring_mutex);
+            g_ranges[idx].in_use = true;
+        }
+        return fail(FMARL_EHIP, "fmarl_ring_alloc: a re-used address range failed its verification (%s): allocate plainly", why);
+    }
+    *base = ptr; *cookie = r;
     return FMARL_OK;
 }
 
 int fmarl_ring_free(void *cookie) {
     if (!cookie) return fail(FMARL_EINVAL, "fmarl_ring_free: null cookie");
     ring_release((RingAlloc *)cookie);
+    return FMARL_OK;
+}
+
+int fmarl_ring_stats(uint64_t out[6]) {
+    if (!out) return fail(FMARL_EINVAL, "fmarl_ring_stats: null argument");
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    uint64_t idle = 0, kept = 0;
+    for (const RingRange &g : g_ranges) if (!g.in_use) { idle += g.total; ++kept; }
+    out[0] = g_ring_reserved; out[1] = idle; out[2] = g_ranges.size(); out[3] = kept; out[4] = g_ring_reuses; out[5] = g_ring_check_fails;
     return FMARL_OK;
 }
 

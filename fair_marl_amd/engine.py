@@ -625,7 +625,7 @@ class RolloutEngine:
     def rollout(self, action_tape, mode=None, use_graph=None, ring=None):
         """Run ``len(action_tape)`` auto-resetting steps from a persistent device tape (T, n, N) int32: the random-action
         rollout of the reference's throughput runs, or a scripted tape.  Outputs of the last step are in the engine's current
-        output set.  ``mode``:
+        output set (with ``ring``: the time slot of the last step becomes the current set, in every mode).  ``mode``:
 
         * ``'span'`` (default): ``step_span`` -- one launch per run of steps between episode ends (10 agents x 65 536 envs:
           0.250 -> 0.199 ms per step; 3 agents x 4 096 envs: 14.5 -> 11.5 us); nav_fairassign_fairrew_formation_graph, whose
@@ -642,16 +642,20 @@ class RolloutEngine:
         instead of every step overwriting the engine's current output set -- the trajectory exists afterwards, as the
         reference's runner keeps it (onpolicy/envs/env_wrappers.py:988-996 delivers every step's outputs)."""
         T = int(action_tape.shape[0])
-        if ring is not None and (T > ring.slots or mode == 'graph'):
-            raise ValueError('rollout: the ring holds %d slots, the tape %d steps (and graph replays write one output set)' % (ring.slots, T))
         if mode is None and use_graph is not None:
             mode = 'graph' if use_graph else 'eager'
         if mode is None:
             mode = 'span'
+        if ring is not None and (T > ring.slots or mode == 'graph'):
+            raise ValueError('rollout: the ring holds %d slots, the tape %d steps (and graph replays write one output set)' % (ring.slots, T))
+        if T == 0:
+            return
         if mode == 'span':
             if ring is not None:
                 self.use_outputs(ring.sets[0])
             self.step_span(action_tape, strides=ring.strides if ring is not None else None)
+            if ring is not None:   # as the eager mode and DeviceRolloutBuffer.insert_span leave it: the current set is the LAST step's
+                self.use_outputs(ring.sets[T - 1])
             return
         if mode == 'graph' and self._lean_capture_ok(T):
             # the cache holds the tape and the output set themselves (not their addresses: an address can be reused by another
@@ -726,22 +730,30 @@ class _SpreadBlock(object):
     ``__cuda_array_interface__``; tensors made from it (``torch.as_tensor``) keep it alive, the memory is unmapped with the last one."""
 
     def __init__(self, lib, device, shape, slot_bytes, slots):
+        self._cookie = None
         base, cookie = C.c_void_p(), C.c_void_p()
         with torch.cuda.device(device):
             rc = lib.fmarl_ring_alloc(int(slot_bytes), int(slots), 0, C.byref(base), C.byref(cookie))
         if rc:
             raise MemoryError(lib.fmarl_last_error().decode())
-        self._lib, self._cookie, self._device = lib, cookie, device
+        self._lib, self._cookie, self._device, self.nbytes = lib, cookie, device, int(slot_bytes) * int(slots)
         self.__cuda_array_interface__ = dict(shape=tuple(int(v) for v in shape), typestr='<f4', data=(int(base.value), False), version=2)
 
     def __del__(self):
+        cookie, self._cookie = self._cookie, None
+        if cookie is None or not cookie.value:
+            return
         try:
-            if self._cookie is not None and self._cookie.value:
-                torch.cuda.synchronize(self._device)   # no launch may still write here
-                self._lib.fmarl_ring_free(self._cookie)
-                self._cookie = None
-        except Exception:
-            pass
+            torch.cuda.synchronize(self._device)   # no launch may still write here
+        except Exception as e:   # (e.g. destroyed while some stream captures): the pieces are returned anyway, and it is said
+            import logging
+            logging.getLogger('fair_marl_amd').warning('time-slot array freed without a device synchronize: %s', e)
+        try:
+            if self._lib.fmarl_ring_free(cookie):
+                raise RuntimeError(self._lib.fmarl_last_error().decode())
+        except Exception as e:
+            import logging
+            logging.getLogger('fair_marl_amd').warning('fmarl_ring_free failed, %d bytes of device memory stay mapped: %s', self.nbytes, e)
 
 
 def alloc_time_slots(lib, device, shape, spread=None, zero=False, single=False):

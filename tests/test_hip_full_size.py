@@ -28,6 +28,10 @@ N_ENVS = 65536
 FORM_INFO = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13]   # record slots of fo.INFO_KEYS
 
 CASES = {
+    # BASELINE config 2 at its own size (4 096 envs x 3 agents): the one config whose launch geometry nothing else shares -- the
+    # library spreads the small batch over 512 workgroups of 8 envs (24 of 256 lanes carry agents), E * F = 99 leaves through the
+    # generic row windows
+    'cfg2': dict(mod=no, seed=36, stride=61, n=4096, kw=dict(num_agents=3, num_landmarks=3, num_obstacles=3)),
     # BASELINE config 3 (bench.py default): 8 envs per workgroup, wave-scan statistics, 16-byte row streaming, step_end_kernel
     'cfg3': dict(mod=no, seed=31, stride=1021, kw=dict(num_agents=32, num_landmarks=32, num_obstacles=8)),
     # the reference's own 10-agent scale (bench.py --config n10): odd row widths through the per-wave LDS windows
@@ -82,7 +86,7 @@ def test_full_batch_rollout_through_episode_ends_vs_oracle(case, epb_hint):
     mod, seed = c['mod'], c['seed']
     cfg = fm.EnvConfig(**c['kw'])
     ocfg = mod.Config(**{k: getattr(cfg, k) for k in mod.Config.__dataclass_fields__})
-    n, N = N_ENVS, cfg.N
+    n, N = c.get('n', N_ENVS), cfg.N
     sample = np.unique(np.concatenate([np.arange(0, n, c['stride']), [n - 1]]))
     eng = fm.RolloutEngine(cfg, n, device=DEV, seed=seed, async_reset=True, tune_placement=0, envs_per_workgroup=epb_hint)
     epb = eng.envs_per_workgroup
@@ -134,7 +138,7 @@ def test_full_batch_step_span_equals_step_by_step(case, epb_hint):
     fnav: all 53 steps are ONE launch (fairnav_span_kernel), with envs ending their episodes early at different steps inside it."""
     c = CASES[case]
     cfg = fm.EnvConfig(**c['kw'])
-    n, N, T = N_ENVS, cfg.N, 2 * cfg.episode_length + 3
+    n, N, T = c.get('n', N_ENVS), cfg.N, 2 * cfg.episode_length + 3
     a = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0)
     b = fm.RolloutEngine(cfg, n, device=DEV, seed=c['seed'], tune_placement=0, envs_per_workgroup=epb_hint)
     assert epb_hint == 0 or b.envs_per_workgroup == epb_hint
@@ -155,7 +159,7 @@ def test_full_batch_step_span_equals_step_by_step(case, epb_hint):
             assert torch.equal(a.field(k), b.field(k)), k
 
 
-@pytest.mark.parametrize('case', ['cfg3', 'cfg4', 'n10', 'fnav'])
+@pytest.mark.parametrize('case', ['cfg3', 'cfg4', 'n10', 'fnav', 'cfg2'])
 def test_full_batch_spans_into_time_slots_vs_oracle(case):
     """bench.py's headline mode at its own size and geometry: 65 536 envs, every step of an episode written to its own time slot
     of an OutputRing by ONE span launch + the episode-ending launch (step_span with per-step strides), then a second pass over
@@ -166,7 +170,7 @@ def test_full_batch_spans_into_time_slots_vs_oracle(case):
     mod, seed = c['mod'], c['seed']
     cfg = fm.EnvConfig(**c['kw'])
     ocfg = mod.Config(**{k: getattr(cfg, k) for k in mod.Config.__dataclass_fields__})
-    n, N, T = N_ENVS, cfg.N, cfg.episode_length
+    n, N, T = c.get('n', N_ENVS), cfg.N, cfg.episode_length
     sample = np.unique(np.concatenate([np.arange(0, n, c['stride']), [n - 1]]))
     import gc
     gc.collect()
@@ -183,6 +187,7 @@ def test_full_batch_spans_into_time_slots_vs_oracle(case):
         c0 = eng.launch_counts()[0]
         eng.rollout(tape, mode='span', ring=ring)
         assert eng.launch_counts()[0] - c0 == T and eng.phase == (-1 if case == 'fnav' else 0)
+        assert eng.outs is ring.sets[T - 1] and eng.obs.data_ptr() == ring.obs[T - 1].data_ptr()   # the current set = the LAST step's slot
         host_tape = tape.cpu().numpy()
         for t in range(T):
             ref = orc.step(host_tape[t][sample])

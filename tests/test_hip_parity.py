@@ -1786,7 +1786,15 @@ def test_time_slots_with_interleaved_physical_memory():
         assert (ring.spread == ['node_obs', 'adj']) == spread
         eng.reset()
         eng.rollout(tape, mode='span', ring=ring)
+        # what is current afterwards is the LAST step's slot in every mode (the span used to leave slot 0 selected: a policy reading
+        # eng.obs got the first step's observation, and the next step() overwrote slot 0)
+        assert eng.outs is ring.sets[24] and eng.obs.data_ptr() == ring.obs[24].data_ptr() and eng.node_obs.data_ptr() == ring.node_obs[24].data_ptr()
         eng.rollout(tape, mode='eager', ring=ring)
+        assert eng.outs is ring.sets[24]
+        with pytest.raises(ValueError):   # a graph replay writes one output set: refused under either spelling of the mode
+            eng.rollout(tape, use_graph=True, ring=ring)
+        with pytest.raises(ValueError):
+            eng.rollout(tape, mode='graph', ring=ring)
         rings.append(ring)
     torch.cuda.synchronize()
     for k in ('obs', 'reward', 'done', 'node_obs', 'adj_env', 'info_planes'):
@@ -1832,3 +1840,47 @@ def test_time_slots_after_a_freed_array_keep_what_is_written():
         gc.collect()
         torch.cuda.synchronize()
 
+
+def test_time_slot_allocator_reuses_its_address_ranges():
+    """fmarl_ring_free keeps the array's address range (it must not go back to the runtime: the test above) -- and the next array
+    of the same size is mapped into it: 50 allocate / write / check / free cycles of two alternating sizes reserve address space
+    twice, not a hundred times (fmarl_ring_stats), every array holds what is written into it, and the first use of a kept range
+    starts out zeroed (its verification pass)."""
+    import gc
+    from fair_marl_amd import _lib
+    from fair_marl_amd.engine import alloc_time_slots
+    lib = _lib.load()
+    gc.collect()
+    torch.cuda.synchronize()
+    stats = (C.c_uint64 * 6)()
+
+    def read():
+        assert lib.fmarl_ring_stats(stats) == 0
+        return [int(v) for v in stats]
+    shapes = [(2, 32768, 10, 16, 12), (3, 16384, 6, 16, 11)]
+    before = read()
+    reserved_after_first = None
+    for k in range(50):
+        shape = shapes[k % 2]
+        t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
+        assert interleaved
+        if k >= 2:
+            assert int((t != 0).sum()) == 0, 'a re-used range starts out zeroed (cycle %d)' % k
+        t.fill_(float(k + 1))
+        torch.cuda.synchronize()
+        flat = t.view(-1)
+        assert int((flat != float(k + 1)).sum()) == 0, 'array %d right after its fill' % k
+        assert int((flat.cpu() != float(k + 1)).sum()) == 0, 'array %d copied to the host' % k
+        del t, flat
+        gc.collect()
+        torch.cuda.synchronize()
+        now = read()
+        if k == 1:
+            reserved_after_first = now[0]
+        if k >= 1:
+            assert now[0] == reserved_after_first or k == 1
+    after = read()
+    total = sum(4 * int(np.prod(s)) for s in shapes)
+    assert after[0] - before[0] <= total, 'address space reserved once per size (kept ranges of an earlier test may even serve these)'
+    assert after[4] - before[4] >= 48 and after[5] == before[5], after   # 48 of the 50 requests came out of kept ranges, none failed its check
+    assert after[1] >= total   # both ranges idle again
