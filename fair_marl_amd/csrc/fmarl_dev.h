@@ -95,6 +95,7 @@ struct Params {
     const double2 *rot_table;   // (cos, sin) of i * 2 pi / N, one table for all envs
     // fairnav scenario: extra per-env LDS tables (byte offsets), knob and state
     int n_D, n_minprox, n_occ, n_match, n_rows, n_words;
+    int n_pre;   // Philox blocks of an env's new episode drawn ahead by all lanes in the in-kernel reset (they fit the env's part of the second region below n_words)
     double min_obs_dist;
     double *goal_occ;
     int8_t *goal_history, *goal_reached, *status;   // integer-valued in the reference (-1 / index, -1 / index, bool)
@@ -182,23 +183,31 @@ constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
 constexpr uint32_t kPhiloxTag = 0x464D4152u;
 
-struct PhiloxStream {
-    uint32_t k0, k1, env, episode, idx;
-    __device__ PhiloxStream(uint64_t seed, uint32_t env_, uint32_t episode_, uint32_t first = 0)
-        : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), env(env_), episode(episode_), idx(first) {}
-    // one 128-bit block -> two doubles in [0, 1) built like NumPy's random_double
-    __device__ void next(double &u0, double &u1) {
-        uint32_t c0 = idx++, c1 = env, c2 = episode, c3 = kPhiloxTag, a = k0, b = k1;
+// block `idx` of the stream (seed; idx, env, episode) -> two doubles in [0, 1) built like NumPy's random_double
+__device__ __forceinline__ void philox_block(uint64_t seed, uint32_t idx, uint32_t env, uint32_t episode, double &u0, double &u1) {
+    uint32_t c0 = idx, c1 = env, c2 = episode, c3 = kPhiloxTag, a = (uint32_t)seed, b = (uint32_t)(seed >> 32);
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            if (r) { a += kPhiloxW0; b += kPhiloxW1; }
-            uint64_t p0 = (uint64_t)kPhiloxM0 * c0, p1 = (uint64_t)kPhiloxM1 * c2;
-            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b;
-            c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-        }
-        const double s = 1.0 / 9007199254740992.0;
-        u0 = (double)((((uint64_t)c1 << 32) | c0) >> 11) * s;
-        u1 = (double)((((uint64_t)c3 << 32) | c2) >> 11) * s;
+    for (int r = 0; r < 10; ++r) {
+        if (r) { a += kPhiloxW0; b += kPhiloxW1; }
+        uint64_t p0 = (uint64_t)kPhiloxM0 * c0, p1 = (uint64_t)kPhiloxM1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    }
+    const double s = 1.0 / 9007199254740992.0;
+    u0 = (double)((((uint64_t)c1 << 32) | c0) >> 11) * s;
+    u1 = (double)((((uint64_t)c3 << 32) | c2) >> 11) * s;
+}
+
+struct PhiloxStream {
+    uint64_t seed;
+    uint32_t env, episode, idx, n_pre;
+    const double *pre;   // blocks 0 .. n_pre - 1 of this stream, drawn ahead by other lanes (u0, u1 pairs; the in-kernel reset of fairnav_pass)
+    __device__ PhiloxStream(uint64_t seed_, uint32_t env_, uint32_t episode_, uint32_t first = 0, const double *pre_ = nullptr, uint32_t n_pre_ = 0)
+        : seed(seed_), env(env_), episode(episode_), idx(first), n_pre(n_pre_), pre(pre_) {}
+    // one 128-bit block -> two doubles in [0, 1)
+    __device__ void next(double &u0, double &u1) {
+        if (idx < n_pre) { u0 = pre[2 * idx]; u1 = pre[2 * idx + 1]; ++idx; return; }
+        philox_block(seed, idx++, env, episode, u0, u1);
     }
     __device__ double2 uniform_pair(double lo, double hi) {
         double a, b; next(a, b);

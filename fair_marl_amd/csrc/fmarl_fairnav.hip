@@ -41,6 +41,8 @@ struct FairNavLds {
     __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2)
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
+    __device__ int *episode() const { return (int *)(base + p.lds_flag) + 2; }     // the env's episode counter (the key of its next placement)
+    __device__ double *predraw() const { return (double *)dead; }                  // in-kernel reset: the first Philox blocks of the new episode (over stat / D / ...: dead by then)
     __device__ double *D() const { return (double *)(dead + p.n_D); }               // [N][L] |x_a - goal_g|
     __device__ double *minprox() const { return (double *)(dead + p.n_minprox); }   // [L] min_a |x_a - goal_g|
     __device__ double *occ() const { return (double *)(dead + p.n_occ); }           // [L] landmark_poses_occupied
@@ -186,9 +188,9 @@ __device__ __forceinline__ int lexifair_upto3(const double *D, int L, int N, int
     return (int)((codes >> (6 * best + 2 * (lane < 3 ? lane : 0))) & 3ull);
 }
 
-template <int G>
+template <int G, int THREADS>
 __device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool only_flagged) {
-    const int group = threadIdx.x / G, ngroups = kThreads / G, lane = threadIdx.x % G;
+    const int group = threadIdx.x / G, ngroups = THREADS / G, lane = threadIdx.x % G;
     for (int el = group; el < nenv; el += ngroups) {
         const FairNavLds t(p, lds, el);
         if (only_flagged && t.skip()) continue;   // (group-uniform)
@@ -211,7 +213,7 @@ __device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds,
 // the reset pass that follows overwrites them -- so that one ended env does not send the whole workgroup down the per-lane
 // path (13 four-byte stores per row at a 52-byte stride: half the store rate; with episodes ending at all phases nearly every
 // workgroup has such an env in every step)
-template <bool ALL_ROWS = false>
+template <bool ALL_ROWS, int THREADS>
 __device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
     const int tid = threadIdx.x, N = p.N;
     if (o.node_obs) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOu
             const uint32_t k_wallf = pin_sgpr((uint32_t)p.lds_wallf), k_rows = pin_sgpr((uint32_t)p.n_rows);
             FastDiv dNE, dE;
             dNE.m = pin_sgpr(p.dC4.m); dNE.d = p.dC4.d; dE.m = pin_sgpr(p.dE.m); dE.d = p.dE.d;
-            for (uint32_t base = 0; base < total; base += kThreads) {
+            for (uint32_t base = 0; base < total; base += THREADS) {
                 const uint32_t q = base + tid, w0 = base + (tid & ~63u);
                 float row[13];
                 if (q < total) {
@@ -239,7 +241,7 @@ __device__ __forceinline__ void fairnav_emit_rows(const Params &p, const FmarlOu
                 flush_rows<13, true>(p, lds, row, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * 13);
             }
         } else {
-            for (uint32_t q = tid; q < total; q += kThreads) {
+            for (uint32_t q = tid; q < total; q += THREADS) {
                 const uint32_t e_l = p.dC4.div(q);
                 const FairNavLds te(p, lds, e_l);
                 if (te.skip()) continue;
@@ -286,11 +288,22 @@ struct PlacedEnvLds {
 //                 workgroup of a training run, where episodes end at all phases -- 0.052 ms per launch when no env ends,
 //                 0.086 when two or three per workgroup do.)
 //   STEP = false: the observation part of an explicit reset (fmarl_reset: placement and assignment by their own kernels).
-//   `resident` (a later step of a span): the static entities of the workgroup's envs are still in their LDS tables -- the previous
-//                 step left them there, and re-read them for the envs it reset.
-template <bool STEP>
+//   `carry` (span kernel): bit 0 = this agent's state arrives in `c` (left there by the previous step of the span), the static
+//                 entities of the workgroup's envs and their episode counters are still in the LDS tables -- nothing is loaded but the
+//                 action; bit 1 = the new state stays in `c` instead of going to global memory.  0 = a step of its own.
+//   THREADS       workgroup size: 192 when the envs' agent lanes fit three waves (the shipped FA+FR configuration: 64 envs x 3 agents)
+//                 -- a fourth wave would hold no agent, and without it the kernel has 168 vector registers per lane instead of 128:
+//                 what the state needs to stay in registers across a span (round 3 needed 181 for it at 256 threads and spilled).
+// (small integers packed: `bits` = status | (goal_history + 1) << 1 | (goal_reached + 1) << 9 | step << 17, `hits` = obstacle | agent << 16
+// collision counts -- a byte-sized field would still take a whole register; min_time is constant over an episode and re-read)
+struct FairnavCarry { double2 x, v; double pd, Dg, Tr, left, occ; uint32_t bits, hits; };
+__device__ __forceinline__ uint32_t fairnav_pack(double status, int hist, double gr, int step) {
+    return (status != 0.0 ? 1u : 0u) | ((uint32_t)(hist + 1) & 0xffu) << 1 | ((uint32_t)((int)gr + 1) & 0xffu) << 9 | (uint32_t)step << 17;
+}
+
+template <bool STEP, int THREADS>
 __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
-                                             const float *action_vec, int auto_reset, bool resident = false) {
+                                             const float *action_vec, int auto_reset, FairnavCarry &c, const int carry) {
     FMARL_TICKS_BEGIN
     const int tid = threadIdx.x, N = p.N, L = p.L;
     const int env0 = env_block(p) * p.epb;
@@ -303,21 +316,32 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     double *s_stat = t.stat();
     const bool flagged = STEP ? false : (in_range && p.reset_flag[env] != 0);
     const bool active = in_range;
+    const bool arrives = STEP && (carry & 1) != 0, keep = STEP && (carry & 2) != 0;
 
     double2 x = make_double2(0, 0), v = make_double2(0, 0);
-    double pd = 0, status = 0;
-    int step = 0;
-    if (active) {
+    double pd = 0, status = 0, occ_i = 0, mtime = 0;   // (mtime: written by the in-kernel reset, read by the info planes)
+    double Dg_old = 0, Tr_old = 0, left = 0, gr = 0;
+    int step = 0, hist_i = 0, noc_old = 0, nac_old = 0;
+    if (arrives) {
+        x = c.x; v = c.v; pd = c.pd; occ_i = c.occ;
+        status = (double)(c.bits & 1u); hist_i = (int)((c.bits >> 1) & 0xffu) - 1; gr = (double)((int)((c.bits >> 9) & 0xffu) - 1); step = (int)(c.bits >> 17) + 1;
+        Dg_old = c.Dg; Tr_old = c.Tr; left = c.left; noc_old = (int)(c.hits & 0xffffu); nac_old = (int)(c.hits >> 16);
+    } else if (active) {
         x = p.agent_pos[g]; v = p.agent_vel[g]; pd = p.p_dist[g]; status = (double)p.status[g];
-        t.pos()[i] = x;
-        t.occ()[i] = p.goal_occ[g]; t.hist()[i] = p.goal_history[g];   // L == N
+        occ_i = p.goal_occ[g]; hist_i = p.goal_history[g];   // L == N
         step = p.cur_step[env] + (STEP ? 1 : 0);
+        if (STEP && i == 0) *t.episode() = p.episode[env];
+    }
+    if (STEP && active && o.info) mtime = p.min_time[g];   // (constant over an episode: a cached load, issued here so that nothing waits for it)
+    if (active) {
+        t.pos()[i] = x;
+        t.occ()[i] = occ_i; t.hist()[i] = (int8_t)hist_i;
         if (i == 0) { t.words()[0] = N; t.words()[1] = 1; t.words()[2] = 0; }
     }
     // reset observation: workgroups without a freshly reset env have nothing to do (block-uniform exit)
     if (!STEP && !__syncthreads_or(flagged)) return;
     if (in_range && i == 0) *t.flag() = (STEP || flagged) ? 0 : 1;   // (a step emits every env: the ended ones after their reset)
-    if (!resident) load_statics(p, lds, env0, nenv);
+    if (!arrives) load_statics_range(p, lds, env0, 0, nenv, tid, THREADS);
     __syncthreads();
     FMARL_TICK(0);   // state loads, entity tables, barrier
     if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
@@ -336,10 +360,10 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICK(2);   // distance table
     if (STEP && !FMARL_SKIP(p, 64)) {
         // reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721)
-        if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv, false);
-        else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv, false);
-        else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv, false);
-        else fairnav_assign_tasks<32>(p, lds, nenv, false);
+        if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, false);
+        else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, false);
+        else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, false);
+        else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, false);
     } else if (active) {
         t.match()[i] = p.goal_match[g];
     }
@@ -348,7 +372,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
 
     // reward's status transition (nf:726-741) and the per-agent info bookkeeping (nf:489-573) only need
     // positions and the agent's own previous values
-    double Dg_old = 0, Tr_old = 0, Dg_new = 0, Tr_new = 0, left = 0, gr = 0, dgoal = 0;
+    double Dg_new = 0, Tr_new = 0, dgoal = 0;
     bool newly = false, done = false;
     if (active) {
         if (STEP) {
@@ -357,7 +381,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             if (newly) status = 1.0;
             done = status != 0.0 || step >= p.episode_length;   // environment.py:237-247
             if (!done) atomicAnd(&t.words()[1], 0);
-            Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left = p.dist_left[g]; gr = (double)p.goal_reached[g];
+            if (!arrives) { Dg_old = p.dists_to_goal[g]; Tr_old = p.times_required[g]; left = p.dist_left[g]; gr = (double)p.goal_reached[g]; }
             int near = 0;
             double dn = t.D()[i * L];
             for (int k = 1; k < L; ++k) { const double d = t.D()[i * L + k]; if (d < dn) { dn = d; near = k; } }
@@ -377,7 +401,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     __syncthreads();
     const bool ended = STEP && active && auto_reset && t.words()[1] != 0;   // every agent of the env is done: it is reset below
     const bool emit = STEP ? true : flagged;
-    FMARL_TICK(4);   // status transition, bookkeeping (four state loads), barrier
+    FMARL_TICK(4);   // status transition, bookkeeping, barrier
 
     if (STEP) {
         if (active) {   // what the step owes besides the observation: reward, done, info, the state -- none of it depends on the walk
@@ -403,12 +427,19 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             if (fr < -p.fair_rew) fr = -p.fair_rew;
             rew = fmin(fmax(rew + fr, -2 * p.collision_rew), p.goal_rew + p.fair_rew);
 
-            const int noc = p.num_obst_coll[g] + (ob_hit ? 1 : 0), nac = p.num_agent_coll[g] + ag_hits;
+            if (!arrives) { noc_old = p.num_obst_coll[g]; nac_old = p.num_agent_coll[g]; }
+            const int noc = noc_old + (ob_hit ? 1 : 0), nac = nac_old + ag_hits;
             const double2 vout = newly ? make_double2(0.0, 0.0) : v;   // nf:736-737
-            p.agent_pos[g] = x; p.agent_vel[g] = vout; p.p_dist[g] = pd; p.status[g] = (int8_t)status;
-            p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left; p.goal_reached[g] = (int8_t)gr;
-            p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac; p.goal_match[g] = t.match()[i];
-            if (i == 0) p.cur_step[env] = step;
+            if (keep) {
+                c.x = x; c.v = vout; c.pd = pd; c.Dg = Dg_new; c.Tr = Tr_new; c.left = left;
+                c.bits = fairnav_pack(status, 0, gr, step);   // (the history entry follows the walk)
+                c.hits = (uint32_t)noc | (uint32_t)nac << 16;
+            } else {
+                p.agent_pos[g] = x; p.agent_vel[g] = vout; p.p_dist[g] = pd; p.status[g] = (int8_t)status;
+                p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left; p.goal_reached[g] = (int8_t)gr;
+                p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac; p.goal_match[g] = t.match()[i];
+                if (i == 0) p.cur_step[env] = step;
+            }
             if (o.reward) o.reward[g] = (float)rew;
             if (o.done) o.done[g] = done;
             if (o.info) {   // nf:573-590
@@ -429,23 +460,41 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                 inf[FMARL_INFO_TIME_MEAN * plane] = (float)tm;
                 inf[FMARL_INFO_TIME_STDDEV * plane] = (float)ts;
                 inf[FMARL_INFO_TIME_MEAN_BY_STDDEV * plane] = (float)ratio_out(tm, ts + 0.0001);
-                inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)p.min_time[g];
+                inf[FMARL_INFO_MIN_TIME_TO_GOAL * plane] = (float)mtime;
                 inf[FMARL_INFO_INDIVIDUAL_REWARD * plane] = (float)rew;
             }
         }
         FMARL_TICK(6);   // reward, statistics, state stores, info planes
         // ---- the envs that ended: the reset of env_wrappers.py:859-865, in place.  (The barrier also separates the terminal step's
         // state stores and table reads above from the placement's stores to the same fields and its writes to the tables.)
+        // (flag: marks the envs the pre-draw and the restricted assignment below work on; written here so that the barrier that
+        // decides whether any env ended also publishes it -- nothing between the previous barrier and this point reads the flags)
+        if (in_range && i == 0 && auto_reset) *t.flag() = ended ? 0 : 1;
         if (__syncthreads_or(ended)) {
-            if (in_range && i == 0) {
-                p.reset_flag[env] = ended ? 1 : 0;
-                *t.flag() = ended ? 0 : 1;   // marks the envs the restricted assignment below works on
-                if (ended) {
-                    PlacedEnvLds pl{t.pos(), p, env};
-                    place_env(p, pl, kResetAuto, env, false);
-                }
+            if (in_range && i == 0) p.reset_flag[env] = ended ? 1 : 0;
+            // The placement is the reference's sequential rejection sampling on the env's own Philox stream, by ONE lane per ended
+            // env while the workgroup waits: eleven or more Philox blocks of ten dependent rounds each were 14 % of a wave's cycles
+            // with episodes ending at all phases (profiles/r4_ticks_fnav_steady.txt).  The blocks are counter-based, so the first
+            // p.n_pre of them are drawn here by all lanes side by side (one block each) into the env's part of the second LDS
+            // region (its tables there are dead by now); the placing lane then only reads them and runs the distance tests.
+            const int n_pre = p.n_pre;
+            for (int task = tid; task < nenv * n_pre; task += THREADS) {
+                const int e_l = task / n_pre, b = task - e_l * n_pre;
+                const FairNavLds te(p, lds, e_l);
+                if (te.skip()) continue;
+                double u0, u1;
+                philox_block(p.seed, (uint32_t)b, (uint32_t)(p.env_offset + env0 + e_l), (uint32_t)*te.episode(), u0, u1);
+                te.predraw()[2 * b] = u0; te.predraw()[2 * b + 1] = u1;
             }
-            FMARL_TICK(11);   // (measure builds) the placement itself, by the first lane of every ended env
+            __syncthreads();
+            FMARL_TICK(11);   // (measure builds) the barrier that found ended envs, the pre-draw
+            if (in_range && i == 0 && ended) {
+                PlacedEnvLds pl{t.pos(), p, env};
+                const int epi = *t.episode();
+                place_env(p, pl, kResetAuto, env, kPlaceEntities, epi, t.predraw(), n_pre);
+                *t.episode() = epi + 1;
+            }
+            FMARL_TICK(12);   // (measure builds) the placement itself, by the first lane of every ended env
             __threadfence_block();   // (walls: the static entities of the placed envs are re-read from the state below)
             __syncthreads();
             if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
@@ -456,6 +505,20 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                 t.occ()[i] = 0.0; t.hist()[i] = -1;
                 t.agentf()[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 t.posf()[i] = make_float2((float)nx.x, (float)nx.y);
+                // the per-agent vectors of reset_world (nf:233-238, :446-459), by the agent's own lane: into the registers a span
+                // carries, else into the state
+                if (p.has_max_speed) mtime = dist2(nx, t.pos()[N + i]) / p.max_speed;   // (goal_match reset to arange BEFORE min_time)
+                if (keep) {
+                    c.x = nx; c.v = make_double2(0.0, 0.0); c.pd = 0.0; c.Dg = -1.0; c.Tr = -1.0; c.left = -1.0;
+                    c.bits = fairnav_pack(0.0, 0, -1.0, 0); c.hits = 0;
+                }
+                else {   // (a span's inner step: the last step of the launch stores these from the registers)
+                    p.agent_vel[g] = make_double2(0.0, 0.0); p.p_dist[g] = 0.0; p.status[g] = 0;
+                    p.times_required[g] = -1.0; p.dists_to_goal[g] = -1.0; p.dist_left[g] = -1.0; p.goal_reached[g] = -1;
+                    p.num_obst_coll[g] = 0; p.num_agent_coll[g] = 0; p.goal_occ[g] = 0.0; p.goal_history[g] = -1;
+                    if (i == 0) p.cur_step[env] = 0;
+                }
+                if (p.has_max_speed) p.min_time[g] = mtime;   // (constant over the episode: not carried, re-read by the info planes)
             }
             __syncthreads();
             if (ended) {
@@ -466,16 +529,21 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                 t.minprox()[i] = m;
             }
             __syncthreads();
-            if (!FMARL_SKIP(p, 64)) {   // the assignment of the new episode (nf:469)
-                if (N <= 4) fairnav_assign_tasks<4>(p, lds, nenv, true);
-                else if (N <= 8) fairnav_assign_tasks<8>(p, lds, nenv, true);
-                else if (N <= 16) fairnav_assign_tasks<16>(p, lds, nenv, true);
-                else fairnav_assign_tasks<32>(p, lds, nenv, true);
+            // the assignment of the new episode (nf:469): nothing in this step reads it (the walk, the observation and the rows do not
+            // know the assignment; every step assigns afresh inside reward(agent 0)) -- it is state, and inside a span the last step
+            // of the launch stores its own: skipped there, with its barrier
+            if (!keep) {
+                if (!FMARL_SKIP(p, 64)) {
+                    if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, true);
+                    else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, true);
+                    else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, true);
+                    else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, true);
+                }
+                __syncthreads();
+                if (ended) p.goal_match[g] = t.match()[i];
             }
-            __syncthreads();
-            if (ended) p.goal_match[g] = t.match()[i];
             if (in_range && i == 0) *t.flag() = 0;   // every env emits (read again behind the walk's barriers)
-        }
+        } else if (in_range && i == 0) *t.flag() = 0;    // (no env of the workgroup ended)
         FMARL_TICK(9);   // in-kernel reset of the ended envs
     }
 
@@ -488,13 +556,13 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
         __syncthreads();
         // graph_observation(a): row of entity i on the snapshot (nf:1255-1283)
         bool far = false, free_empty = true;
-        int c = 0, best = -1;
+        int cc = 0, best = -1;
         if (active) {
             const double *Drow = t.D() + i * L;
             double dmin = Drow[0], bd = 1e300;
             for (int k = 0; k < L; ++k) {
                 const double d = Drow[k];
-                if (d < dmin) { dmin = d; c = k; }
+                if (d < dmin) { dmin = d; cc = k; }
                 if (t.occ()[k] != 1.0) { free_empty = false; if (d < bd) { bd = d; best = k; } }
             }
             far = !(dmin < p.min_obs_dist);
@@ -506,10 +574,10 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             const bool cleared = free_empty && astar < i;         // an earlier entity already cleared the flags
             NavRow r;
             r.pad = 0;
-            if (!far) { r.code = (int8_t)c; r.occ = cleared ? 0.f : (float)t.occ()[c]; r.hist = t.hist()[c]; }
+            if (!far) { r.code = (int8_t)cc; r.occ = cleared ? 0.f : (float)t.occ()[cc]; r.hist = t.hist()[cc]; }
             else if (!free_empty) { r.code = (int8_t)best; r.occ = (float)t.occ()[best]; r.hist = t.hist()[best]; }
             else if (astar == i) { r.code = -1; r.occ = 0.f; r.hist = t.hist()[i]; }
-            else { r.code = (int8_t)c; r.occ = 0.f; r.hist = t.hist()[c]; }   // after the clear every goal is free
+            else { r.code = (int8_t)cc; r.occ = 0.f; r.hist = t.hist()[cc]; }   // after the clear every goal is free
             t.rows()[a * N + i] = r;
         }
         __syncthreads();
@@ -536,7 +604,8 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             ob[4] = (float)(goal.x - xo.x); ob[5] = (float)(goal.y - xo.y); ob[6] = (float)og.g_occ; ob[7] = (float)og.g_hist;
             ob[8] = (float)(sec.x - xo.x); ob[9] = (float)(sec.y - xo.y); ob[10] = (float)og.second_occ;
         }
-        if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
+        if (keep) { c.occ = t.occ()[i]; c.bits = (c.bits & ~(0xffu << 1)) | ((uint32_t)((int)t.hist()[i] + 1) & 0xffu) << 1; }
+        else if (STEP || emit) { p.goal_occ[g] = t.occ()[i]; p.goal_history[g] = t.hist()[i]; }
         if (o.graph_record && emit) {   // what a learner on another GPU needs to rebuild this env's node_obs (fmarl.h)
             uint32_t *r = o.graph_record + g * (size_t)(5 + 3 * N);
             const float4 af = t.agentf()[i];
@@ -552,46 +621,45 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICK(7);   // obs, occupancy state, record
     // ---- emission (rows table, positions, velocities are final since the loop's last barrier)
     if (FMARL_SKIP(p, 32)) { FMARL_TICKS_END; return; }
-    fairnav_emit_rows<STEP>(p, o, lds, env0, nenv);   // (a step pass writes all rows: no env keeps its previous ones)
+    fairnav_emit_rows<STEP, THREADS>(p, o, lds, env0, nenv);   // (a step pass writes all rows: no env keeps its previous ones)
     FMARL_TICK(8);   // node rows
-    emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    emit_adj<true>(p, o, lds, env0, 0, nenv, threadIdx.x, THREADS);
     FMARL_TICK(10);   // adj
     FMARL_TICKS_END;
 }
 
-template <bool STEP>
-__device__ __forceinline__ void fairnav_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx,
-                                             const float *action_vec, int auto_reset, bool resident = false) {
+template <bool STEP, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                                 const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    fairnav_pass<STEP>(p, o, lds, action_idx, action_vec, auto_reset, resident);
-}
-
-template <bool STEP>
-__global__ __launch_bounds__(kThreads, 4) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
-                                                           const float *action_vec, int auto_reset) {
     // the shapes and table offsets re-read from the argument block where they are used (fmarl_dev.h span_params_reloaded) instead of
     // all being loaded at the top and spilled into vector lanes: 144 -> 30 spilled scalar registers, 0.0575 -> 0.0555 ms per launch
     // at 65 536 x 3 (-5 % with episodes ending at all phases, profiles/r4_notes.md)
-    fairnav_body<STEP>(span_params_reloaded(), o, action_idx, action_vec, auto_reset);
+    FairnavCarry c;
+    fairnav_pass<STEP, THREADS>(span_params_reloaded(), o, lds, action_idx, action_vec, auto_reset, c, 0);
 }
 
 // fmarl_step_span for nav_fairassign_fairrew_formation_graph: T steps of the workgroup's own envs in one launch, episode ends
-// included (the step resets its ended envs itself).  The state goes through global memory between the steps -- a workgroup
-// re-reads what it wrote itself: L2 hits -- and nothing is carried in registers: with a register carry the kernel needed 181
-// VGPRs (or spilled at 128) and ran SLOWER than a launch per step (round 3, profiles/r3_notes.md).  What the span saves is what
-// lies outside the waves' lifetimes: a wave of the step launch lives 36-44 us of the launch's 60 (dispatch, the write-back of
-// the L2 at the kernel's end) and the next launch starts 6 us later (profiles/r4_ticks_fnav.txt).
+// included (the step resets its ended envs itself).  Between the steps the agent's state stays in registers (FairnavCarry: only the
+// first step loads it, only the last one stores it), the static entities and the envs' episode counters in the LDS tables.  Round 4 sent the state through global memory every step (HBM traffic 1.34 x algorithmic): at 256 threads per workgroup the
+// carry did not fit 128 registers (181, or scratch); with the agent-less fourth wave gone (THREADS = 192) the budget is 168.
+// What the span saves besides: what lies outside the waves' lifetimes -- a wave of the step launch lives 36-44 us of the launch's 60
+// (dispatch, the write-back of the L2 at the kernel's end) and the next launch starts 6 us later (profiles/r4_ticks_fnav.txt).
 // All arguments are one struct, re-read from the argument block inside the time loop (span_params_reloaded): held in scalar
 // registers across a whole step -- shapes, eight output pointers, nine strides -- they spill twice as many registers.
 struct FairnavSpanArgs { Params p; FmarlOutputs o; SpanStrides s; const int32_t *action_idx; const float *action_vec; int T, auto_reset; };
-__global__ __launch_bounds__(kThreads, 4) void fairnav_span_kernel(FairnavSpanArgs) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_span_kernel(FairnavSpanArgs) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    FairnavCarry c = {};
     for (int t = 0;; ++t) {
         const FairnavSpanArgs &a = span_params_reloaded<FairnavSpanArgs>();
         if (t >= a.T) break;
         const FmarlOutputs ot = span_outputs(a.o, a.s, t);
-        fairnav_body<true>(a.p, ot, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
-                           a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset, t > 0);
-        span_step_done();   // the next step reads this step's state stores, and overwrites the LDS tables the emission read
+        fairnav_pass<true, THREADS>(a.p, ot, lds, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
+                                    a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset, c,
+                                    (t > 0 ? 1 : 0) | (t < a.T - 1 ? 2 : 0));
+        __syncthreads();   // the next step overwrites the LDS tables the emission read
     }
 }
 
@@ -599,8 +667,9 @@ __global__ __launch_bounds__(kThreads, 4) void fairnav_span_kernel(FairnavSpanAr
 // per agent and step [x, y, vx, vy, newly-stopped | (goal code, occupancy, history) x N] written by fairnav_kernel
 // (FmarlOutputs.graph_record) + the once-per-episode record of the static entities (fmarl_rebuild.hip layout).  Same LDS
 // tables, same emission code: bit-identical to the sender's.  n_envs is the caller's.
-__global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec,
-                                                                   const uint32_t *step_rec, int n_envs) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fairnav_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec,
+                                                                  const uint32_t *step_rec, int n_envs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, N = p.N;
     const int env0 = env_block(p) * p.epb;
@@ -619,12 +688,12 @@ __global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, Fma
         }
         if (i == 0) *t.flag() = 0;
     }
-    for (int k = tid; k < nenv * LO; k += kThreads) {
+    for (int k = tid; k < nenv * LO; k += THREADS) {
         const int e_l = k / LO, j = k - e_l * LO;
         const float *sp = (const float *)(ep_rec + (size_t)(env0 + e_l) * words) + 2 * (N + j);
         FairNavLds(p, lds, e_l).posf()[N + j] = make_float2(sp[0], sp[1]);
     }
-    for (int k = tid; k < nenv * p.W; k += kThreads) {
+    for (int k = tid; k < nenv * p.W; k += THREADS) {
         const int e_l = k / p.W, w = k - e_l * p.W;
         const FairNavLds t(p, lds, e_l);
         const uint32_t *q = ep_rec + (size_t)(env0 + e_l) * words + 2 * (N + LO) + 6 * w;
@@ -634,8 +703,8 @@ __global__ __launch_bounds__(kThreads) void fairnav_rebuild_kernel(Params p, Fma
         t.posf()[N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
     }
     __syncthreads();
-    fairnav_emit_rows(p, o, lds, env0, nenv);
-    emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
+    fairnav_emit_rows<false, THREADS>(p, o, lds, env0, nenv);
+    emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, THREADS);
 }
 
 }  // namespace fmarl

@@ -29,10 +29,10 @@ template <bool STEP> __global__ void formation_kernel(Params p, FmarlOutputs o, 
 __global__ void formation_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec, const uint32_t *step_rec, int n_envs);
 
 // fmarl_fairnav.hip
-template <bool STEP> __global__ void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
-                                                   const float *action_vec, int auto_reset);
+template <bool STEP, int THREADS> __global__ void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+                                                                const float *action_vec, int auto_reset);
 
-__global__ void fairnav_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec, const uint32_t *step_rec, int n_envs);
+template <int THREADS> __global__ void fairnav_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec, const uint32_t *step_rec, int n_envs);
 
 // fmarl_lexifair.hip
 void launch_lexifair_costs(const double *costs, int32_t *perm, int n_envs, int N, hipStream_t stream);

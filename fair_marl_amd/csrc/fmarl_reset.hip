@@ -81,17 +81,24 @@ __device__ __forceinline__ bool obstacle_hit(const Params &p, const PL &pl, cons
 // scenarios' variants): Philox draws in the reference's draw order, rejection sampling through `pl` (where the placed
 // positions are kept for the tests), per-agent vectors reset.  Shared by reset_place_kernel and the in-kernel reset of
 // fairnav_kernel (fmarl_fairnav.hip).  `stage`: positions only, into the staging fields `p` is bound to.
+// `what`: kPlaceFull = everything; kPlaceStage = positions only, into the staging fields `p` is bound to; kPlaceEntities (the
+// in-kernel reset of fairnav_pass) = the entities, walls, wall length, place_fails and the episode counter -- the per-agent vectors are
+// reset by the env's own agent lanes in parallel, `episode_in` is the caller's copy of the episode counter and `pre` / `n_pre` the
+// first blocks of the env's Philox stream drawn ahead by other lanes (PhiloxStream).
+enum PlaceWhat { kPlaceFull = 0, kPlaceStage = 1, kPlaceEntities = 2 };
 template <class PL>
-__device__ __forceinline__ void place_env(const Params &p, PL &pl, int mode, int env, bool stage) {
+__device__ __forceinline__ void place_env(const Params &p, PL &pl, int mode, int env, int what, int episode_in = 0,
+                                          const double *pre = nullptr, int n_pre = 0) {
     const int N = p.N, L = p.L;
     const size_t a0 = (size_t)env * N;
+    const bool stage = what != kPlaceFull;   // (the per-agent vectors are somebody else's)
     int episode = 0;
     if (mode == kResetInit) {
         for (int i = 0; i < N; ++i) { p.goal_match[a0 + i] = i; p.min_time[a0 + i] = __builtin_huge_val(); }
     } else {
-        episode = p.episode[env];
+        episode = what == kPlaceEntities ? episode_in : p.episode[env];
     }
-    PhiloxStream rng(p.seed, (uint32_t)(p.env_offset + env), (uint32_t)episode);
+    PhiloxStream rng(p.seed, (uint32_t)(p.env_offset + env), (uint32_t)episode, 0, pre, (uint32_t)n_pre);
     const bool formation = p.scenario == FMARL_SCENARIO_FORMATION, fairnav = p.scenario == FMARL_SCENARIO_FAIRNAV;
     if (mode == kResetInit)   // make_world: navigation_graph.py:183-185 (fairnav draws U(0.2, 0.4) there, then redraws)
         p.wall_length[env] = rng.uniform(0.2, fairnav ? 0.4 : 0.8) * p.world_size / 4;
@@ -118,7 +125,7 @@ __device__ __forceinline__ void place_env(const Params &p, PL &pl, int mode, int
         const int orient = formation ? 1 : rng.choice_hv();   // fair_graph_formation.py:276: always 'V', no draw
         const double axis = (w == 0 ? wall_position : -wall_position) * ws / 2;
         p.wall_orient[g] = orient; p.wall_axis[g] = axis;
-        if (!stage) { p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; }   // staged: derived from wall_length at commit
+        if (what != kPlaceStage) { p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; }   // staged: derived from wall_length at commit
         if (w == 0) { wall[0] = axis; wall[1] = -wlen; wall[2] = wlen; wall[3] = orient; }
         else { wall[4] = axis; wall[5] = -wlen; wall[6] = wlen; wall[7] = orient; }
     }
@@ -146,7 +153,8 @@ __device__ __forceinline__ void place_env(const Params &p, PL &pl, int mode, int
         if (!bad || tries >= kMaxTries) { fails += bad ? 1 : 0; pl.set_landmark(k, x); ++k; tries = 0; }
     }
     p.place_fails[env] = fails;   // (staging: `p` is bound to the staging twin, committed with the rest)
-    if (stage) return;   // min_time, episode counter: reset_commit_kernel
+    if (what == kPlaceEntities) p.episode[env] = episode + 1;
+    if (stage) return;   // min_time, (staging:) episode counter: reset_commit_kernel
     if (formation) {
         // fair_graph_formation.py:394-417: slots on the circle about landmark 0, occupancy cleared;
         // min_time against the agent's OWN slot index (:573-580); formation_complete cleared (:231)
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(64) void reset_place_kernel(Params p, int mode, con
     if (!stage) p.stage_valid[env] = 0;   // a synchronous reset consumes this episode index: staged data is stale
 
     Placed<LDS> pl{(float2 *)lds_raw, p, env, (int)threadIdx.x};
-    place_env(p, pl, mode, env, stage);
+    place_env(p, pl, mode, env, stage ? kPlaceStage : kPlaceFull);
 }
 
 // Asynchronous reset, step 2 of 2: make the staged episode the live one for the selected envs

@@ -141,6 +141,7 @@ struct Handle {
     unsigned long long cap_id;        // id of the stream capture the current call runs in (0 = not capturing)
     unsigned long long cap_stage_id;  // capture in which the staging of the next episode was last enqueued (0 = eagerly)
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
+    int span_threads;   // workgroup size of the span kernel (fairnav: 192 when the agent lanes fit three waves, else = threads)
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int *ev_steps;      // env steps each profiled launch covers (a span launch: many)
     int ev_cap, ev_n;
@@ -227,6 +228,14 @@ void launch_place(Handle *h, const Params &p, int mode, const uint8_t *mask, hip
 // the step kernels of the episode, and the episode-ending launch joins the branch through ev_staged.  A graph must not rely
 // on what the host knew about the staged data when it was captured, so a captured staging always clears the validity flags
 // first and leaves the host's own `stage_dirty` as it was (nothing ran).
+// nav_fairassign_fairrew_formation_graph kernels: the instantiation for the handle's workgroup size (TH = 192 or 256 threads)
+#define FMARL_FNAV(h, kernel, grid, lds, st, ...) FMARL_FNAV_T((h)->threads, kernel, grid, lds, st, __VA_ARGS__)
+#define FMARL_FNAV_T(threads, kernel, grid, lds, st, ...)                                               \
+    do {                                                                                                \
+        if ((threads) == 192) { constexpr int TH = 192; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
+        else { constexpr int TH = 256; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); }                    \
+    } while (0)
+
 int launch_stage(Handle *h, void *state, hipStream_t st) {
     HIP_OK(hipEventRecord(h->ev_commit, st));
     HIP_OK(hipStreamWaitEvent(h->side, h->ev_commit, 0));
@@ -271,8 +280,7 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
             hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs,
                                (const int32_t *)nullptr, (const float *)nullptr, 0);
         else if (p.scenario == FMARL_SCENARIO_FAIRNAV)
-            hipLaunchKernelGGL(fairnav_kernel<false>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs,
-                               (const int32_t *)nullptr, (const float *)nullptr, 0);
+            FMARL_FNAV(h, (fairnav_kernel<false, TH>), dim3(h->grid), h->lds_bytes, st, p, *outs, (const int32_t *)nullptr, (const float *)nullptr, 0);
         else
             hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
     } else if ((form || p.scenario == FMARL_SCENARIO_FAIRNAV) && mode != kResetInit) {
@@ -385,7 +393,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.lds_wallf = o2;  o2 += p.W * 16;
         p.lds_posf = o2;   o2 += p.E * 8;      // (16-byte reads of it only when E % 4 == 0: the table then is a multiple of 32 bytes)
         p.n_rows = o2;     o2 += p.N * p.N * 8;
-        p.lds_flag = o2;   o2 += 8;
+        p.lds_flag = o2;   o2 += 12;   // flag, policy-edge counter, the env's episode counter (FairNavLds::episode)
         p.lds_cnt = p.lds_flag + 4;
         p.lds_constf = p.lds_ego = o2;
         off = align16(o2);
@@ -400,6 +408,9 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         p.n_match = d;     d += p.N * 4;
         p.n_words = d;     d += 12;
         form_dead = p.lds2_bytes = (d + 7) / 8 * 8;
+        // in-kernel reset: this many blocks of the new episode's Philox stream are drawn side by side into the bytes below n_words
+        // (wall length, obstacles, wall position, wall orientations, agents, goals + a few rejected draws)
+        p.n_pre = p.n_words / 16 < p.O + p.W + p.N + p.L + 6 ? p.n_words / 16 : p.O + p.W + p.N + p.L + 6;
     }
     p.lds_env_bytes = off;
     p.stage_wave_bytes = staged ? align16(kStageRows * p.F * 4 + 64) : 0;   // + the window's offset inside its 64-byte aligned frame
@@ -423,7 +434,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 #ifdef FMARL_MEASURE
     if (const char *e = getenv("FMARL_FORM_WAVES")) form_waves = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : form_waves;
 #endif
-    h->threads = form ? 64 * form_waves : kThreads;
+    h->threads = form ? 64 * form_waves : kThreads;   // (fairnav: decided below, once the envs per workgroup are known)
     if (form) {
         int epw = 64 / p.N;
         if (epw < 1) { delete h; return fail(FMARL_EINVAL, "fmarl_create: fair_graph_formation is built for num_agents <= 32"); }
@@ -447,6 +458,11 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
 #endif
     if ((size_t)env_lds > 160 * 1024) { delete h; return fail(FMARL_EINVAL, "fmarl_create: one env does not fit LDS"); }
     p.epb = epb;
+    // nav_fairassign_fairrew_formation_graph: three waves when the envs' agent lanes fit them (64 envs x 3 agents: a fourth wave would
+    // hold no agent) -- 168 vector registers per lane at four workgroups per CU instead of 128 (fmarl_fairnav.hip FairnavCarry)
+    // -- for the span kernel only, which carries the state: one launch per step measured 4 % slower on three waves (the emission is
+    // shared by fewer waves) and has no carry to fit
+    h->span_threads = (fnav && epb * p.N <= 192) ? 192 : h->threads;
     p.lds_stage = align16(epb * p.lds_env_bytes);
     if (form) {   // the second region: epw envs per wave, the wave's part = its emission window
         p.stage_wave_bytes = p.epw * form_dead;
@@ -500,9 +516,10 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)fairnav_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)fairnav_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)fairnav_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        for (const void *f : {(const void *)fairnav_rebuild_kernel<192>, (const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 192>,
+                              (const void *)fairnav_kernel<true, 256>, (const void *)fairnav_kernel<false, 192>, (const void *)fairnav_kernel<false, 256>,
+                              (const void *)fairnav_span_kernel<192>, (const void *)fairnav_span_kernel<256>})
+            if (e2 == hipSuccess) e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
     }
     h->place_lds = (size_t)(p.O + p.N + p.L) * 64 * sizeof(float2);
@@ -709,8 +726,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     const bool prof = h->ev && h->ev_n < h->ev_cap && !h->cap_id && cs == hipStreamCaptureStatusNone;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     if (p.scenario == FMARL_SCENARIO_FAIRNAV)
-        hipLaunchKernelGGL(fairnav_kernel<true>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx,
-                           action_vec, auto_reset ? 1 : 0);
+        FMARL_FNAV(h, (fairnav_kernel<true, TH>), dim3(h->grid), h->lds_bytes, st, p, *outs, action_idx, action_vec, auto_reset ? 1 : 0);
     else if (p.scenario == FMARL_SCENARIO_FORMATION)
         hipLaunchKernelGGL(formation_kernel<true>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs, action_idx,
                            action_vec, auto_reset ? 1 : 0);
@@ -791,7 +807,7 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
             const bool prof = h->ev && h->ev_n < h->ev_cap;
             if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
             if (sc == FMARL_SCENARIO_FAIRNAV)
-                hipLaunchKernelGGL(fairnav_span_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, FairnavSpanArgs{p, o, s, a, av, k, 1});
+                FMARL_FNAV_T(h->span_threads, (fairnav_span_kernel<TH>), dim3(h->grid), h->lds_bytes, st, FairnavSpanArgs{p, o, s, a, av, k, 1});
             else if (sc == FMARL_SCENARIO_FORMATION)
                 hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             else
@@ -1343,7 +1359,7 @@ int fmarl_rebuild_graph_rec(void *handle, const float *obs, const void *episode_
     Params p = h->base;
     p.order = sc == FMARL_SCENARIO_NAVIGATION_GRAPH ? scatter_order(grid) : 1;   // (the caller's n_envs: a grid of its own)
     if (sc == FMARL_SCENARIO_FAIRNAV)
-        hipLaunchKernelGGL(fairnav_rebuild_kernel, dim3(grid), dim3(kThreads), h->lds_bytes, (hipStream_t)stream, p, o,
+        FMARL_FNAV(h, (fairnav_rebuild_kernel<TH>), dim3(grid), h->lds_bytes, (hipStream_t)stream, p, o,
                            (const uint32_t *)episode_record, (const uint32_t *)step_record, n_envs);
     else if (sc == FMARL_SCENARIO_FORMATION)
         hipLaunchKernelGGL(formation_rebuild_kernel, dim3(grid), dim3(h->threads), h->lds_bytes, (hipStream_t)stream, p, o,

@@ -1846,6 +1846,7 @@ def test_time_slot_allocator_reuses_its_address_ranges():
     of the same size is mapped into it: 50 allocate / write / check / free cycles of two alternating sizes reserve address space
     twice, not a hundred times (fmarl_ring_stats), every array holds what is written into it, and the first use of a kept range
     starts out zeroed (its verification pass)."""
+    import ctypes as C
     import gc
     from fair_marl_amd import _lib
     from fair_marl_amd.engine import alloc_time_slots

@@ -361,14 +361,16 @@ def test_hot_kernels_keep_their_register_and_scratch_budget():
     # scratch = 0: besides its cost, a scratch load is a VMEM load on gfx9 -- its s_waitcnt vmcnt(0) also waits for every global
     # store issued before it (the generic node emission ran at 2/3 of its rate while 24 bytes of a row lived in scratch)
     for part, max_vgpr, max_scratch, min_occ in (('11step_kernel', 96, 0, 5), ('16formation_kernelILb1', 120, 0, 4),
-                                                 ('14fairnav_kernelILb1', 128, 0, 4), ('17reset_emit_kernel', 96, 0, 5),
+                                                 ('14fairnav_kernelILb1ELi256', 128, 0, 4), ('14fairnav_kernelILb1ELi192', 128, 0, 4),
+                                                 ('17reset_emit_kernel', 96, 0, 5),
                                                  ('20rebuild_graph_kernel', 96, 0, 5), ('15step_end_kernel', 112, 0, 4),
                                                  # the span kernels (the bench's default launch mode) and the learner-side gather: the latter once
                                                  # compiled to 179 VGPRs = two waves per SIMD for a copy kernel (profiles/r3_notes.md)
                                                  ('16step_span_kernel', 160, 0, 3), ('21formation_span_kernel', 128, 0, 4),
                                                  ('23minibatch_gather_kernel', 112, 0, 4),
-                                                 # (its 112 bytes of scratch are thread-index arithmetic hoisted out of the time loop and
-                                                 # reloaded at loop depth 1, none of it inside the emission loops: profiles/r4_notes.md section 12)
-                                                 ('19fairnav_span_kernel', 128, 128, 4)):
+                                                 # three waves per workgroup (64 envs x 3 agents: the shipped configuration): 168 registers at four
+                                                 # workgroups per CU; six doubles of the carried state are spilled around the emission and reloaded at
+                                                 # the top of the next step (loop depth 1, none of it inside the emission loops: profiles/r5_notes.md)
+                                                 ('19fairnav_span_kernelILi192', 168, 64, 3)):
         vgpr, scratch, occ = find(part)
         assert vgpr <= max_vgpr and scratch <= max_scratch and occ >= min_occ, (part, vgpr, scratch, occ)

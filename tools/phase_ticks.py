@@ -15,7 +15,8 @@ from fair_marl_amd import _lib  # noqa: E402
 NAMES_NAV = ['loads+tables+barrier', 'physics+barrier', 'agent rows+barrier', 'scan statistics', 'stats+hits+reward+stores', 'node_obs',
              'adj (odd workgroups: first)', 'adj (even workgroups: last)']
 NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'reward+state+info (before the walk)',
-              'obs+occupancy state+record', 'node rows', 'in-kernel reset of the ended envs: the rest', 'adj', 'in-kernel reset: the placement (first lane of an ended env)']
+              'obs+occupancy state+record', 'node rows', 'in-kernel reset of the ended envs: the rest', 'adj', 'in-kernel reset: the barrier that finds ended envs + the pre-draw of their Philox blocks',
+              'in-kernel reset: the placement (first lane of an ended env)']
 NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
          'obs+record', 'stats+hits+reward', 'state stores', 'info planes', 'node rows', 'adj']
 
