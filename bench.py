@@ -213,6 +213,16 @@ EAGER_EPB = {}   # one launch per step: the library's choice everywhere (tools/r
 # steps per span launch when the records of a run travel to a learner rank (N > 1): a run's records can only leave when its launch
 # has ended, so the LAST run's gather of a timed region is exposed in full -- short runs keep it short, long runs save launches
 GATHER_SPAN_STEPS = 5   # (and the last runs of a region halve down to single steps: run_spans)
+# N > 1 without --span-steps: the run length is CHOSEN during the warm-up -- the first 8-GPU run cannot be repeated with another constant.
+# For every candidate a few runs with the exchange on; kept: the shortest length whose gather waits stall the rollout by less than
+# SPAN_TUNE_STALL of its time on every rank (short runs expose little at the end of a region; long runs save launch heads and tails).
+SPAN_TUNE_CANDIDATES = (3, 5, 8, 12)
+SPAN_TUNE_RUNS = 4
+SPAN_TUNE_STALL = 0.02
+# the secondary configs other than the headline's run in child processes of their own, started before this process touches the GPU,
+# smallest footprint first: what an entry measures then does not depend on what ran before it (profiles/r4_notes.md section 18: behind
+# the headline's 205 GB ring `n10 eager` read 0.206-0.273 ms per step, in a fresh process 0.2112-0.2119)
+SECONDARY_CHILD_ORDER = ('cfg2', 'fnav', 'cfg4', 'n10')
 
 
 def _use_ring(cfg, n_envs, slots, device):
@@ -449,6 +459,56 @@ def cpu_baseline(env_kw, n_envs, episodes, workers):
                        'slowest worker %.1f s, %.1f s wall incl. process start' % (workers, n_envs, ep, units, busy, wall))
 
 
+def secondary_child(name):
+    """`bench.py --secondary-child NAME`: every `secondary` entry of one config on a fresh process, as one JSON line."""
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    t0 = time.perf_counter()
+    entries = [secondary_line(n, mode, device) for n, mode in SECONDARY if n == name]
+    for e in entries:
+        e['process'] = 'child process of its own, started before the headline run touched the GPU'
+    os.write(result_fd, (json.dumps({'config': name, 'entries': entries, 'wall_s': time.perf_counter() - t0}) + '\n').encode())
+
+
+def run_secondary_children(headline):
+    """The secondary entries of every config but the headline's, each config in a fresh child process (this process must not have
+    initialised the GPU yet).  -> ({config: [entries]}, {config: error text}, wall seconds)"""
+    import subprocess
+    done, failed = {}, {}
+    t0 = time.perf_counter()
+    for name in SECONDARY_CHILD_ORDER:
+        if name == headline or not any(n == name for n, _ in SECONDARY):
+            continue
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--secondary-child', name], capture_output=True, text=True, timeout=300)
+            lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+            if res.returncode != 0 or len(lines) != 1:
+                raise RuntimeError('exit code %d: %s' % (res.returncode, res.stderr[-400:]))
+            done[name] = json.loads(lines[0])['entries']
+        except Exception as exc:   # the entries then run in this process after the headline, and say so
+            failed[name] = str(exc)[-400:]
+            print('bench.py: secondary child for %s failed (%s); its entries run in-process' % (name, exc), file=sys.stderr)
+    return done, failed, time.perf_counter() - t0
+
+
+def span_schedule(first, count, episode_length, span_steps, taper):
+    """Run lengths of the steps [first, first + count) as spans: a run ends at an episode end, after `span_steps` steps or with the
+    region; `taper` (the records of a run travel to a learner rank): the last stretch of the region halves down to single steps, so
+    that the gather nobody can hide -- the last one, behind which the region's closing synchronisation waits -- carries one step's
+    records instead of a whole run's."""
+    runs, t, end = [], first, first + count
+    while t < end:
+        k = min(episode_length - t % episode_length, end - t, span_steps)
+        if taper and end - t <= span_steps:
+            k = min(k, max(1, (end - t + 1) // 2))
+        runs.append(k)
+        t += k
+    return runs
+
+
 def launch_plan(launch, pipeline, scenario_name, gather, span_steps, episode_length):
     """(launch mode, most steps per span launch) of a run.  The launch mode never depends on the number of GPUs: spans, except for
     nav_fairassign_fairrew_formation_graph, which steps -- its envs end their episodes INSIDE a span, and the record of an episode's
@@ -501,6 +561,9 @@ def main():
     ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
                     'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
     ap.add_argument('--no-secondary', action='store_true', help='N=1: skip the other BASELINE configs after the headline region')
+    ap.add_argument('--secondary-child', default=None, choices=sorted(CONFIGS), help=argparse.SUPPRESS)   # (internal: run_secondary_children)
+    ap.add_argument('--no-span-tuning', action='store_true', help='N > 1: runs of GATHER_SPAN_STEPS steps instead of choosing the run length '
+                    'during the warm-up (SPAN_TUNE_CANDIDATES)')
     ap.add_argument('--learner-rebuild', type=int, default=0, metavar='K', help='rank 0 rebuilds node_obs / adj of K ranks\' gathered '
                     'steps (fmarl_rebuild_graph) inside the timed loop -- what a learner has to do with what arrives, since node_obs / '
                     'adj never travel; reported separately in the line (needs the gather: N > 1, --record-path or --rccl-selftest)')
@@ -508,6 +571,8 @@ def main():
                     help='N > 1: "nccl" is RCCL over xGMI (one GPU per rank); "gloo" rehearses the same exchange with '
                          'ranks sharing GPUs (local rank modulo the device count) -- its rate is not a result')
     args = ap.parse_args()
+    if args.secondary_child:
+        return secondary_child(args.secondary_child)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -536,6 +601,14 @@ def main():
         except Exception as exc:   # e.g. no process spawning on this host: fall back to one in-process worker
             print('bench.py: multi-process cpu baseline failed (%s); using one process' % exc, file=sys.stderr)
             cpu = cpu_baseline(spec['env'], spec['cpu_envs'], spec['cpu_episodes'], 1)
+    # the other configs' secondary entries: child processes, before this one touches the GPU (not under rocprofv3, whose preloaded
+    # tool has initialised the GPU already: no process may be started from here then -- the entries run in-process, and say so)
+    want_secondary = (world == 1 and not args.no_secondary and args.pipeline <= 1 and not args.graph and not args.eager and args.launch == 'auto'
+                      and args.slots == 'ring' and args.span_steps == 0 and not (args.record_path or args.n_envs or args.rccl_selftest))
+    under_profiler = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    child_entries, child_errors, child_wall = {}, {}, 0.0
+    if want_secondary and not under_profiler:
+        child_entries, child_errors, child_wall = run_secondary_children(args.config)
     # stdout carries exactly one JSON line.  Libraries write there too -- the GPU boxes export NCCL_DEBUG=VERSION and RCCL
     # prints a five-line version banner to stdout when the first communicator is created -- so from here on file descriptor 1
     # is stderr, and the line goes to the saved descriptor at the end.
@@ -566,6 +639,9 @@ def main():
     gather = (world > 1 or args.record_path) and not args.no_gather
     launch, span_steps = launch_plan('graph' if args.graph else ('step' if args.eager else args.launch), args.pipeline, cfg.scenario_name,
                                      gather, args.span_steps, ep)
+    tune_span = world > 1 and gather and launch == 'span' and args.span_steps == 0 and not args.no_span_tuning
+    span_len = [span_steps]      # steps per span launch (the tuning pass changes it)
+    plain = [False]              # True: spans as an N = 1 run enqueues them (time slots only, no record buffers, nothing exchanged)
     if fnav_sc and gather and launch == 'span':
         raise SystemExit('bench.py: nav_fairassign_fairrew_formation_graph ends episodes inside a span; with the trajectory gather its '
                          'per-episode records must be packed between launches: use --launch step (the default)')
@@ -601,7 +677,7 @@ def main():
     graph_words = eng.step_record_words if eng.emit_graph_record else 0
     tg = sg = None
     if gather and launch == 'span':   # the records of a whole run of steps travel in one collective (SURVEY section 8 e)
-        sg = tg = SpanGather(min(ep, span_steps), n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
+        sg = tg = SpanGather(min(ep, max((span_steps,) + (SPAN_TUNE_CANDIDATES if tune_span else ()))), n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
                              episode_words=eng.episode_record_words if episodes else 0, graph_words=graph_words, timing=True)
     elif gather:
         tg = TrajectoryGather(n_envs, cfg.N, cfg.obs_dim, device, dst=0, depth=depth, force_collective=args.rccl_selftest,
@@ -677,18 +753,14 @@ def main():
         if gather:
             tg.finish()
 
-    def run_spans(first, count):   # fmarl_step_span: runs of steps that end at an episode end, after span_steps steps or with the region
-        t, end = first, first + count
-        while t < end:
+    def run_spans(first, count, taper=True, finish=True):   # fmarl_step_span: runs of steps (span_schedule)
+        use_gather = gather and not plain[0]
+        t = first
+        for k in span_schedule(first, count, ep, span_len[0], taper and use_gather):
             off = t % ep
-            k = min(ep - off, end - t, span_steps)
-            if gather and end - t <= span_steps:
-                # the last stretch of a region: the runs halve down to single steps, so that the gather nobody can hide -- the last
-                # one, behind which the region's closing synchronisation waits -- carries one step's records instead of a whole run's
-                k = min(k, max(1, (end - t + 1) // 2))
             c = chunk[0]
             strides = None
-            if gather:
+            if use_gather:
                 rec = sg.span_record(c)          # waits for the gather that last used this buffer (run c - depth)
                 obs0, rew0, done0, graph0 = rec.first_step_buffers()
                 eng.use_outputs(record_set(c % depth, off if ring is not None else 0, obs0, rew0, done0, graph0))
@@ -699,7 +771,7 @@ def main():
                 eng.use_outputs(ring.sets[off])
                 strides = ring.strides
             eng.step_span(tape[off:off + k], strides=strides)
-            if gather and exchange[0]:
+            if use_gather and exchange[0]:
                 if inject_error and submits[0] == 1 and rank == world - 1:
                     raise RuntimeError('injected gather error (FMARL_BENCH_INJECT_GATHER_ERROR)')
                 sg.submit_span(c, k)
@@ -725,7 +797,7 @@ def main():
                     sg.submit_episode()
             chunk[0] = c + 1
             t += k
-        if gather:
+        if use_gather and finish:
             sg.finish()
 
     run = run_spans if launch == 'span' else run_steps
@@ -766,7 +838,43 @@ def main():
     # N > 1: the base the scaling is measured against -- the SAME K steps in the same launch mode with the same record writes, only
     # nothing is handed to the exchange: what every GPU does when it is alone.  Then untimed steps up to the same episode phase.
     first = W
-    base_elapsed = None
+    span_tuning = None
+    if tune_span:
+        # The run length, chosen here: for every candidate SPAN_TUNE_RUNS runs with the exchange on, timed
+        # like the region itself (barrier, max over ranks); a run's wait for the gather of the run `depth` before it is the stall
+        # the exchange causes in steady state (the closing waits of a pass are not counted: the timed region tapers its last runs).
+        table = []
+        for L in [c for c in SPAN_TUNE_CANDIDATES if c <= ep]:
+            span_len[0] = L
+            n_tune = SPAN_TUNE_RUNS * L
+            sg.host_wait_s, sg.waits = 0.0, 0
+            torch.cuda.synchronize(device)
+            sg.stream_wait_ms()
+            dist.barrier()
+            tt = time.perf_counter()
+            run_spans(first, n_tune, taper=False, finish=False)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - tt
+            row = torch.tensor([dt / n_tune * 1e3, sg.stream_wait_ms() / n_tune, sg.host_wait_s / n_tune * 1e3], dtype=torch.float64, device=device)
+            sg.finish()
+            torch.cuda.synchronize(device)
+            dist.all_reduce(row, op=dist.ReduceOp.MAX)
+            ms, stream_ms, host_ms = (float(v) for v in row.cpu())
+            table.append({'span_steps': L, 'ms_per_step': ms, 'stream_stalled_per_step': stream_ms, 'host_blocked_per_step': host_ms,
+                          'stall_frac': max(stream_ms, host_ms) / ms})
+            first += n_tune
+        ok = [r for r in table if r['stall_frac'] < SPAN_TUNE_STALL]
+        pick = min(ok, key=lambda r: r['span_steps']) if ok else min(table, key=lambda r: (r['stall_frac'], -r['span_steps']))
+        span_len[0] = span_steps = pick['span_steps']
+        span_tuning = {'candidates': table, 'chosen': span_steps, 'runs_per_candidate': SPAN_TUNE_RUNS,
+                       'rule': 'the shortest run length whose gather waits (max over ranks, of the compute stream / of the host) stay under %.0f %% of '
+                               'the time per step; none: the one with the smallest share' % (100 * SPAN_TUNE_STALL)}
+        pad = (W - first) % ep      # back to the episode phase the region would have started at without the tuning pass
+        run_spans(first, pad, taper=False)
+        first += pad
+        if episodes:
+            torch.cuda.synchronize(device)
+    base_elapsed = headline_elapsed = None
     if world > 1 and gather and launch != 'graph' and not args.no_scaling_base:
         exchange[0] = False
         dist.barrier()
@@ -782,6 +890,25 @@ def main():
         pad = (-K) % ep
         run(first, pad)
         first += pad
+        if launch == 'span':
+            # and the N = 1 HEADLINE's launch mode on the same GPUs: whole-episode spans into the time slots, no record buffers --
+            # what the driver's N = 1 line measures and divides the N = 8 value by.  ideal_vs_n1_headline = N x (the base above) /
+            # (this): the scaling a perfect exchange would show against that line (runs of five steps pay a head and a tail per run)
+            plain[0], keep_len = True, span_len[0]
+            span_len[0] = ep
+            dist.barrier()
+            torch.cuda.synchronize(device)
+            tb = time.perf_counter()
+            run(first, K)
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            tb1 = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
+            dist.all_reduce(tb1, op=dist.ReduceOp.MAX)
+            headline_elapsed = float(tb1.item())
+            first += K
+            run(first, pad)
+            first += pad
+            plain[0], span_len[0] = False, keep_len
         exchange[0] = True
         if episodes:   # the episode that is under way now: its record (the pass above submitted none)
             eng.pack_episode(out=tg.episode_record())
@@ -999,6 +1126,15 @@ def main():
                     'note': 'rank 0 rebuilds node_obs / adj of these ranks\' gathered steps (fmarl_rebuild_graph) inside the timed loop, '
                             'on the same stream as its own step kernels; the reference ships node_obs / adj instead '
                             '(onpolicy/envs/env_wrappers.py:983-996)'}
+        if span_tuning is not None:
+            out['multi_gpu']['span_tuning'] = span_tuning
+        if base_elapsed is not None and headline_elapsed is not None:
+            out['multi_gpu']['ideal_vs_n1_headline'] = world * headline_elapsed / base_elapsed
+            out['multi_gpu']['n1_headline_mode'] = {
+                'value_per_gpu': agents * K / headline_elapsed, 'ms_per_step': headline_elapsed / K * 1e3,
+                'note': 'the same %d steps as whole-episode spans into the time slots with no record buffers and nothing exchanged (the launch mode of '
+                        'the N = 1 line), max over the %d ranks; ideal_vs_n1_headline = n_gpus x scaling_base.value_per_gpu / this: what a perfect '
+                        'exchange would show against the N = 1 line -- the rest of a shortfall is the exchange (scaling_base.efficiency)' % (K, world)}
         if base_elapsed is not None:
             # weak scaling against what the same GPUs do when nothing is exchanged: the same K steps, launch mode, span length and
             # record writes on every rank, timed the same way (barrier, max over ranks) just before the timed region
@@ -1007,25 +1143,33 @@ def main():
                                    'efficiency': out['value'] / (world * base),
                                    'basis': 'the same %d steps in the same launch mode (%s%s, slots %s) with the same record writes and no exchange, '
                                             'max over the %d ranks; efficiency = value / (n_gpus x value_per_gpu).  The N = 1 line of this '
-                                            'bench carries the same configuration as `secondary` entry (%s, span%d) next to its own headline'
+                                            'bench carries runs of %d steps as `secondary` entry (%s, span%d) next to its own headline'
                                             % (K, launch, ' of at most %d steps' % span_steps if launch == 'span' else '', slots, world,
-                                               args.config, GATHER_SPAN_STEPS)}
+                                               GATHER_SPAN_STEPS, args.config, GATHER_SPAN_STEPS)}
         if cpu is not None:
             out['cpu_baseline'] = cpu
         if args.config in REFERENCE_CPU:
             out['reference_cpu'] = REFERENCE_CPU[args.config]
-        if (world == 1 and not args.no_secondary and pipe is None and launch == ('step' if fnav_sc else 'span') and slots == 'ring'
-                and args.span_steps == 0 and not (args.record_path or args.n_envs)):
+        if want_secondary and pipe is None:
             t_sec = time.perf_counter()
             # the headline config again over 300 steps (as spans, one launch per step, in runs of GATHER_SPAN_STEPS, into one output
-            # set), then every other BASELINE config that fits one GPU
+            # set) on the headline's own arrays; every other BASELINE config that fits one GPU: measured in child processes before
+            # this one touched the GPU (run_secondary_children), here only where that was not possible
             out['secondary'] = []
             for name, mode in SECONDARY:
+                if name in child_entries:
+                    if mode == [m for n, m in SECONDARY if n == name][0]:
+                        out['secondary'] += child_entries[name]
+                    continue
                 if name != args.config and arena is not None:   # the headline config's entries come first: then its slots go
                     arena = None
                     torch.cuda.empty_cache()
-                out['secondary'].append(secondary_line(name, mode, device, arena=arena if name == args.config else None))
-            out['secondary_wall_s'] = time.perf_counter() - t_sec
+                e = secondary_line(name, mode, device, arena=arena if name == args.config else None)
+                e['process'] = ('the headline\'s process, on the headline\'s arrays' if name == args.config else
+                                'the headline\'s process, after its ring was freed (%s): late entries vary with the device\'s allocation history'
+                                % ('under a profiler no child process may be started' if under_profiler else child_errors.get(name, 'child failed')))
+                out['secondary'].append(e)
+            out['secondary_wall_s'] = time.perf_counter() - t_sec + child_wall
             for e in out['secondary']:   # the other slot mode of the headline config, over 300 steps
                 if e['config'] == args.config and e['mode'] == 'span-same':
                     out['roofline']['frac_same_slot'] = e['frac']

@@ -266,10 +266,22 @@ struct PlacedEnvLds {
     __device__ void set_obstacle(int k, double2 x) { pos[p.N + p.L + k] = x; p.obstacle_pos[(size_t)env * p.O + k] = x; }
     __device__ void set_agent(int k, double2 x) { pos[k] = x; p.agent_pos[(size_t)env * p.N + k] = x; }
     __device__ void set_landmark(int k, double2 x) { pos[p.N + k] = x; p.landmark_pos[(size_t)env * p.L + k] = x; }
+    // The placing lane is alone in its wave and every LDS read is a round trip it waits for (a test per trip: 15 000 cycles per
+    // placement at three agents, profiles/r5_notes.md): four table entries are read per trip (the last one repeated past the end:
+    // harmless for an OR) and tested on the squared distance; only a pair within an ulp of the threshold takes the square root.
     __device__ bool any_closer(int kind, int k, double2 x, double thr) const {
+        const double2 *tab = kind == 0 ? pos + p.N + p.L : (kind == 1 ? pos : pos + p.N);
+        const double c2 = thr * thr, lo = c2 * (1.0 - 1e-15), hi = c2 * (1.0 + 1e-15);
         bool hit = false;
-        for (int j = 0; j < k; ++j)
-            hit |= closer_than(kind == 0 ? g_obstacle(j) : (kind == 1 ? g_agent(j) : g_landmark(j)), x, thr);
+        for (int j0 = 0; j0 < k; j0 += 4) {
+            const int last = k - 1;
+            const double2 q0 = tab[j0], q1 = tab[min(j0 + 1, last)], q2 = tab[min(j0 + 2, last)], q3 = tab[min(j0 + 3, last)];
+            const double s0 = (q0.x - x.x) * (q0.x - x.x) + (q0.y - x.y) * (q0.y - x.y), s1 = (q1.x - x.x) * (q1.x - x.x) + (q1.y - x.y) * (q1.y - x.y);
+            const double s2 = (q2.x - x.x) * (q2.x - x.x) + (q2.y - x.y) * (q2.y - x.y), s3 = (q3.x - x.x) * (q3.x - x.x) + (q3.y - x.y) * (q3.y - x.y);
+            hit |= (s0 < lo) | (s1 < lo) | (s2 < lo) | (s3 < lo);
+            const bool band = (!(s0 < lo) & !(s0 > hi)) | (!(s1 < lo) & !(s1 > hi)) | (!(s2 < lo) & !(s2 > hi)) | (!(s3 < lo) & !(s3 > hi));
+            if (band) hit |= closer_than(q0, x, thr) | closer_than(q1, x, thr) | closer_than(q2, x, thr) | closer_than(q3, x, thr);
+        }
         return hit;
     }
 };

@@ -835,7 +835,11 @@ __global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_kernel(
     Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, const float *action_vec, int T) {
     StepCarry c = {};
     for (int t = 0; t < T; ++t) {
+#ifdef FMARL_SPAN_RELOADED   // (A/B builds: the argument block re-read where it is used -- 172 -> 22 spilled scalar registers, 157 -> 145 VGPRs)
+        const Params &q = span_params_reloaded();
+#else
         const Params q = span_params(p);
+#endif
         const FmarlOutputs ot = span_outputs(o, s, t);
         step_body<false>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr, action_vec ? action_vec + (size_t)t * s.actions : nullptr,
                          0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));

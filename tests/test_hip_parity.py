@@ -334,18 +334,35 @@ def test_bench_multi_rank_rehearsal(world, extra):
     assert d['config']['launch_mode'] == ('span' if span else 'step') and d['config']['slots'].startswith('ring')
     assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
     assert 'cpu_baseline' not in d and d['n_ranks_seen'] == world
-    # the timed steps are [55, 85): warm-up [0, 5), the same 30 steps without the exchange [5, 35), 20 steps back to episode phase 5
-    # (the last stretch of a region tapers: its runs halve down to single steps, so that the exposed last gather is one step's)
-    if span and whole:   # [55, 75) = a run of 19 + the episode end, then [75, 85) as runs of 5, 3, 1, 1
-        assert d['config']['span_steps'] == 25
-        assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == 3
-        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(27 / 3) and 'one per run of steps (5 ' in d['multi_gpu']['collectives']
-    elif span:           # five runs of 5 steps (the fourth = a run of 4 + the episode end), then 3, 1, 1
-        assert d['config']['span_steps'] == bench.GATHER_SPAN_STEPS == 5
-        assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == 6
-        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(27 / 6) and 'one per run of steps (8 ' in d['multi_gpu']['collectives']
+    # the timed steps start at episode phase 5: warm-up [0, 5), (runs of steps without --span-steps: the tuning passes, then back to phase
+    # 5), the same 30 steps without the exchange, 20 steps back to phase 5, (spans:) the same 30 steps in the N = 1 line's launch mode
+    # and 20 more.  The last stretch of a region tapers: its runs halve down to single steps, so that the exposed last gather is one step's.
+    if span:
+        L = d['config']['span_steps']
+        m = d['multi_gpu']
+        if whole:
+            assert L == 25 and 'span_tuning' not in m
+        else:   # the run length was chosen during the warm-up (all candidates tried, the rule applied to the table in the line)
+            st = m['span_tuning']
+            assert [r['span_steps'] for r in st['candidates']] == list(bench.SPAN_TUNE_CANDIDATES) and st['chosen'] == L
+            ok = [r['span_steps'] for r in st['candidates'] if r['stall_frac'] < bench.SPAN_TUNE_STALL]
+            assert L == (min(ok) if ok else min(st['candidates'], key=lambda r: (r['stall_frac'], -r['span_steps']))['span_steps'])
+            assert all(r['ms_per_step'] > 0 and r['stall_frac'] >= 0 for r in st['candidates'])
+        runs = bench.span_schedule(5, 30, 25, L, True)
+        assert sum(runs) == 30 and runs[-1] == 1
+        # a run that reaches the episode end (phase 24) leaves its last step to the episode-ending launch; a run of one step is a step launch
+        lens = [k - 1 if (5 + sum(runs[:j]) + k) % 25 == 0 else k for j, k in enumerate(runs)]
+        lens = [k for k in lens if k >= 2]
+        assert d['roofline']['kernel'] == 'step_span_kernel' and d['roofline']['kernel_launches'] == len(lens)
+        assert d['roofline']['kernel_steps_per_launch'] == pytest.approx(sum(lens) / len(lens))
+        assert 'one per run of steps (%d ' % len(runs) in m['collectives']
+        # what a perfect exchange would show against the N = 1 line: n_gpus x (the same runs without the exchange) / (the N = 1 launch mode)
+        assert m['ideal_vs_n1_headline'] == pytest.approx(world * d['scaling_base']['value_per_gpu'] / m['n1_headline_mode']['value_per_gpu'], rel=1e-9)
+        if L == 5:
+            assert lens == [5, 5, 5, 4, 5, 3] and len(runs) == 8
     else:
         assert d['roofline']['kernel_launches'] == 30 and d['roofline']['kernel_steps_per_launch'] == 1.0
+        assert 'span_tuning' not in d['multi_gpu'] and 'ideal_vs_n1_headline' not in d['multi_gpu']
     assert '512 envs per GPU' in d['config']['workload'] and d['roofline']['traffic'] is None   # --n-envs: no replayed 65 536-env counters
     assert 'secondary' not in d and d['config']['auto_resets_timed'] == 1
     m = d['multi_gpu']
@@ -383,7 +400,9 @@ def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus():
     assert one['roofline']['kernel'] == two['roofline']['kernel'] == 'step_span_kernel'
     assert one['roofline']['slots'] == two['roofline']['slots'] == 'ring'
     assert one['config']['auto_resets_timed'] == two['config']['auto_resets_timed'] == 1
-    assert one['config']['span_steps'] == 25 and two['config']['span_steps'] == 5 and 'scaling_base' in two and 'scaling_base' not in one
+    import bench
+    assert one['config']['span_steps'] == 25 and two['config']['span_steps'] in bench.SPAN_TUNE_CANDIDATES and 'scaling_base' in two and 'scaling_base' not in one
+    assert two['multi_gpu']['span_tuning']['chosen'] == two['config']['span_steps'] and two['multi_gpu']['ideal_vs_n1_headline'] > 0
 
 
 def test_bench_exchange_through_rccl_with_one_rank():

@@ -334,6 +334,14 @@ def test_bench_launch_plan_is_the_same_for_every_number_of_gpus():
     assert bench.launch_plan('auto', 1, fnav, False, 0, 25)[0] == bench.launch_plan('auto', 1, fnav, True, 0, 25)[0] == 'step'
     assert bench.launch_plan('step', 1, nav, True, 0, 25)[0] == 'step' and bench.launch_plan('span', 2, nav, False, 0, 25)[0] == 'step'
     assert bench.launch_plan('auto', 1, nav, True, 12, 25) == ('span', 12) and bench.launch_plan('auto', 1, nav, False, 99, 25) == ('span', 25)
+    # the runs of a region: episode ends and the run length split it; with a gather the last stretch halves down to single steps
+    assert bench.span_schedule(55, 30, 25, 5, True) == [5, 5, 5, 5, 5, 3, 1, 1] and bench.span_schedule(55, 30, 25, 5, False) == [5] * 6
+    assert bench.span_schedule(5, 30, 25, 25, True) == [20, 5, 3, 1, 1] and bench.span_schedule(0, 50, 25, 25, False) == [25, 25]
+    assert bench.span_schedule(5, 30, 25, 12, True) == [12, 8, 5, 3, 1, 1] and bench.span_schedule(7, 0, 25, 5, True) == []
+    for L in bench.SPAN_TUNE_CANDIDATES:
+        for first in (0, 5, 24):
+            runs = bench.span_schedule(first, 30, 25, L, True)
+            assert sum(runs) == 30 and max(runs) <= L and runs[-1] == 1
     # the formula of SURVEY section 8(d) and the state-once-per-launch variant of it
     import fair_marl_amd as fm
     cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
