@@ -81,6 +81,7 @@ struct Params {
     float edge_thr;          // (float)max_edge_dist: the policy-edge threshold of the fused processAdj count
     uint64_t seed;
     FastDiv dNEF, dEF, dF, dEE, dE, dNE, dC4, dNC4, dEE4, dE4;
+    FastDiv dP, dN;          // small batches (step_body SMALL): contact partners per agent (N + O + W), agents per env
     int ablate;              // -DFMARL_MEASURE builds only (tools/ablate.sh): bit mask of phases to skip
     int vec_node, vec_adj;   // 16-byte emission paths usable (E*F % 4 == 0 / E % 4 == 0)
     int scan_stats;          // N is a power of two <= 64: the agent-loop statistics run as wave scans (seg_mixed_stats)

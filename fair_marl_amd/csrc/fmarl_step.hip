@@ -312,16 +312,20 @@ __device__ __forceinline__ void emit_adj(const Params &p, const FmarlOutputs &o,
 
 
 // node_obs rows of any shape (E F not a multiple of 4, or more than four 16-byte groups per ego block).
-template <bool GLOBAL>
-__device__ __forceinline__ void emit_node_rows_generic(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+// WAVES_ONLY (small batches, step_body<false, true>): the callers are the workgroup's waves 1 .. 3 (`thr` = tid - 64 of `nthr` = 192
+// threads) while wave 0 is still busy with the agents' reward / info -- no workgroup barrier in here; nenv <= 64.
+template <bool GLOBAL, bool WAVES_ONLY = false>
+__device__ __forceinline__ void emit_node_rows_generic(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv,
+                                                       const int thr = threadIdx.x, const int nthr = kThreads) {
     constexpr int F = GLOBAL ? 7 : 11;
-    const int tid = threadIdx.x;
     const uint32_t NE = p.N * p.E, total = nenv * NE;
     float *dst = o.node_obs + (size_t)env0 * NE * F;
-    const bool some_skip = __syncthreads_or(tid < nenv && EnvLds(p, lds, tid).skip());
+    bool some_skip;
+    if constexpr (WAVES_ONLY) some_skip = __ballot((int)(thr & 63) < nenv && EnvLds(p, lds, thr & 63).skip()) != 0;   // (every wave reads all flags itself)
+    else some_skip = __syncthreads_or(thr < nenv && EnvLds(p, lds, thr).skip());
     if (!some_skip) {   // every env of the workgroup emits: rows leave through the LDS windows, 16 bytes per lane
-        for (uint32_t base = 0; base < total; base += kThreads) {
-            const uint32_t q = base + tid, w0 = base + (tid & ~63u);
+        for (uint32_t base = 0; base < total; base += nthr) {
+            const uint32_t q = base + thr, w0 = base + (thr & ~63u);
             float row[F];
             if (q < total) {
                 const uint32_t el = p.dNE.div(q), r = q - el * NE, i = p.dE.div(r), e = r - i * p.E;
@@ -330,7 +334,7 @@ __device__ __forceinline__ void emit_node_rows_generic(const Params &p, const Fm
             flush_rows<F>(p, lds, row, w0 < total ? (int)min(64u, total - w0) : 0, dst + (size_t)w0 * F);
         }
     } else {            // some envs keep their previous rows (reset in flight): per-lane stores of the rest
-        for (uint32_t q = tid; q < total; q += kThreads) {
+        for (uint32_t q = thr; q < total; q += nthr) {
             const uint32_t el = p.dNE.div(q);
             const EnvLds t(p, lds, el);
             if (t.skip()) continue;
@@ -342,6 +346,16 @@ __device__ __forceinline__ void emit_node_rows_generic(const Params &p, const Fm
             for (int f = 0; f < F; ++f) d[f] = row[f];
         }
     }
+}
+
+// The graph outputs of a small batch (generic row shapes, no policy-edge count) by the workgroup's waves 1 .. 3.
+__device__ __forceinline__ void emit_graph_waves(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv) {
+    const int thr = (int)threadIdx.x - 64, nthr = kThreads - 64;
+    if (o.node_obs) {
+        if (p.feat_global) emit_node_rows_generic<true, true>(p, o, lds, env0, nenv, thr, nthr);
+        else emit_node_rows_generic<false, true>(p, o, lds, env0, nenv, thr, nthr);
+    }
+    emit_adj(p, o, lds, env0, 0, nenv, thr, nthr);   // (o.edge_nnz == nullptr: no barrier inside)
 }
 
 // Emission of the graph outputs of the workgroup's envs.
@@ -526,6 +540,137 @@ __device__ __forceinline__ double2 agent_force(const Params &p, const char *base
     return make_double2(Fx, Fy);
 }
 
+// ---- small batches (step_body SMALL): the contact pairs side by side.
+// A workgroup of a small batch holds all its agents in wave 0 (8 envs x 3 agents at BASELINE config 2): agent_force walks an agent's
+// partners one after the other -- a near pair is a hundred dependent float64 instructions -- while three waves and most of the
+// first have nothing to do, and the launch takes as long as that chain.  Here thread q of the workgroup evaluates ONE (agent,
+// partner) pair, q = agent * P + partner (P = N + O + W partners; nenv N P <= 256), into its wave's own LDS window (free at this point
+// of a step: the emission waves wrote theirs before they arrived here); after a barrier the agent's lane adds its P contributions in
+// agent_force's order -- near pairs first, then the float32 band, each in partner order -- so the sums are the same bits.
+struct PairSlots {
+    double2 *c;   // [64] contribution of the wave's pair l
+    int *cls;     // [64] 0 = none, 1 = near (float64), 2 = the float32 band
+    __device__ __forceinline__ PairSlots(const Params &p, char *lds, uint32_t wave) {
+        char *w = lds + p.lds_stage + wave * p.stage_wave_bytes;
+        c = (double2 *)w; cls = (int *)(w + 64 * sizeof(double2));
+    }
+};
+__device__ __forceinline__ void pair_contributions(const Params &p, char *lds, int nenv) {
+    const uint32_t q = threadIdx.x, P = p.N + p.O + p.W;
+    int cls = 0;
+    double cx = 0.0, cy = 0.0;
+    if (q < (uint32_t)nenv * p.N * P) {
+        const uint32_t al = p.dP.div(q), k = q - al * P, el = p.dN.div(al), i = al - el * p.N;
+        const double2 *s_pos = (const double2 *)(lds + (size_t)el * p.lds_env_bytes + p.lds_pos);
+        const int first_wall = p.N + p.L + p.O;
+        const int b = (int)k < p.N ? (int)k : (int)k + p.L;       // partner index -> entity index
+        const double dmin_e = 2 * kEntitySize, dmin_w = kEntitySize + kWallWidth;
+        const double far_e = (dmin_e + 37.0 * kContactMargin) * (dmin_e + 37.0 * kContactMargin);
+        const double mid_e = (dmin_e + 24.0 * kContactMargin) * (dmin_e + 24.0 * kContactMargin);
+        const double far_w = (dmin_w + 37.0 * kContactMargin) * (dmin_w + 37.0 * kContactMargin);
+        const double mid_w = (dmin_w + 24.0 * kContactMargin) * (dmin_w + 24.0 * kContactMargin);
+        const double2 x = s_pos[i], pq = s_pos[b];
+        const double dx = x.x - pq.x, dy = x.y - pq.y, d2 = dx * dx + dy * dy;
+        const bool wall = b >= first_wall;
+        const bool ok = b != (int)i;
+        const bool in_far = !(d2 > (wall ? far_w : far_e)), in_mid = !(d2 > (wall ? mid_w : mid_e));
+        cls = (ok & in_mid) ? 1 : ((ok & in_far) ? 2 : 0);
+        if (cls == 1) {
+            double inv_d;
+            const double d = sqrt_inv_pos(d2, inv_d);
+            const double dmin = wall ? dmin_w : dmin_e;
+            const double c = kContactForce * softplus_pen((dmin - d) * (1.0 / kContactMargin), kContactMargin) * inv_d;
+            cx = c * dx; cy = c * dy;
+        } else if (cls == 2) {
+            const float fdx = (float)dx, fdy = (float)dy;
+            const float r = rsqrtf(fdx * fdx + fdy * fdy), d = 1.0f / r;
+            const float dmin = wall ? (float)dmin_w : (float)dmin_e;
+            const float e = __expf((dmin - d) * (float)(1.0 / kContactMargin));
+            const float c = (float)(kContactForce * kContactMargin) * e * r;
+            cx = (double)(c * fdx); cy = (double)(c * fdy);
+        }
+    }
+    const PairSlots w(p, lds, threadIdx.x >> 6);
+    w.c[threadIdx.x & 63] = make_double2(cx, cy);
+    w.cls[threadIdx.x & 63] = cls;
+}
+// agent_force with the pairs' contributions taken from the windows (agent `al` of the workgroup = thread al)
+__device__ __forceinline__ double2 agent_force_pairs(const Params &p, char *lds, const char *base, uint32_t al, size_t g,
+                                                     const int32_t *action_idx, const float *action_vec, const double2 x, const int a_pre) {
+    double ux, uy;
+    if (action_idx) {
+        const int a = a_pre >= 0 ? a_pre : action_idx[g];
+        ux = kSensitivity * (double)((a == 1) - (a == 2));
+        uy = kSensitivity * (double)((a == 3) - (a == 4));
+    } else {
+        const float *a = action_vec + g * 5;
+        ux = ((double)a[1] - (double)a[2]) * kSensitivity;
+        uy = ((double)a[3] - (double)a[4]) * kSensitivity;
+    }
+    double Fx = ux, Fy = uy;
+    const uint32_t P = p.N + p.O + p.W, q0 = al * P;
+    // (P <= 32: agent_force's one block of partners.)  Four slots per LDS round trip -- all eight reads in flight at once -- and the
+    // sums taken under a select, in order: a read per trip made this loop a third of the physics phase at three agents
+    for (int want = 1; want <= 2; ++want) {
+        for (uint32_t k0 = 0; k0 < P; k0 += 4) {
+            int cl[4];
+            double2 cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t q = q0 + min(k0 + j, P - 1);
+                const PairSlots w(p, lds, q >> 6);
+                cl[j] = k0 + j < P ? w.cls[q & 63] : 0;
+                cc[j] = w.c[q & 63];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool take = cl[j] == want;
+                const double nx = Fx + cc[j].x, ny = Fy + cc[j].y;
+                Fx = take ? nx : Fx; Fy = take ? ny : Fy;
+            }
+        }
+    }
+    // core.py:317-326 + :407-462 walls proper (as agent_force)
+    const double *wl = (const double *)(base + p.lds_wall);
+    for (int w = 0; w < p.W; ++w) {
+        double axis = wl[w * 4], e0 = wl[w * 4 + 1], e1 = wl[w * 4 + 2];
+        bool horiz = wl[w * 4 + 3] == 0.0;
+        double ppar = horiz ? x.x : x.y, pperp = horiz ? x.y : x.x;
+        const double s = kEntitySize;
+        if (ppar < e0 - s || ppar > e1 + s) continue;
+        double sin_t = 0.0, cos_t = 1.0;
+        if (ppar < e0 || ppar > e1) {
+            sin_t = (ppar < e0 ? ppar - e0 : ppar - e1) / s;
+            cos_t = sqrt_pos(fmax(1.0 - sin_t * sin_t, 0.0));
+        }
+        const double dmin = cos_t * s + 0.5 * kWallWidth;
+        double dpos = pperp - axis, d = fabs(dpos);
+        double pen = softplus_pen(-(d - dmin) / kWallContactMargin, kWallContactMargin);
+        double fm = kWallContactForce * dpos / d * pen;
+        double fperp = cos_t * fm, fpar = sin_t * fabs(fm);
+        Fx += horiz ? fpar : fperp;
+        Fy += horiz ? fperp : fpar;
+    }
+    return make_double2(Fx, Fy);
+}
+// three mixed_stats side by side (the fairness scalar's vector and the two info planes' vectors): the same operations per
+// vector, one pass -- the three dependent chains overlap instead of following each other
+__device__ __forceinline__ void mixed_stats3(const double *f1, const double *s1, int sp1, const double *f2, const double *s2, int sp2,
+                                             const double *f3, const double *s3, int sp3, int n, double &m1, double &sd1, double &m2,
+                                             double &sd2, double &m3, double &sd3) {
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j = 0; j < n; ++j) {
+        a1 += (j < sp1) ? f1[j] : s1[j]; a2 += (j < sp2) ? f2[j] : s2[j]; a3 += (j < sp3) ? f3[j] : s3[j];
+    }
+    m1 = a1 / n; m2 = a2 / n; m3 = a3 / n;
+    double q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double d1 = ((j < sp1) ? f1[j] : s1[j]) - m1, d2 = ((j < sp2) ? f2[j] : s2[j]) - m2, d3 = ((j < sp3) ? f3[j] : s3[j]) - m3;
+        q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+    }
+    sd1 = sqrt(q1 / n); sd2 = sqrt(q2 / n); sd3 = sqrt(q3 / n);
+}
+
 // core.py:338-356 integrate_state: updates x, v, pd
 __device__ __forceinline__ void integrate_agent(const Params &p, const double2 F, double2 &x, double2 &v, double &pd) {
     v.x = v.x * (1 - kDamping) + F.x * kDt;
@@ -553,11 +698,17 @@ __device__ __forceinline__ void world_step_agent(const Params &p, const char *ba
 // `carry` (span kernels): bit 0 = this agent's state arrives in `c` (left there by the previous step of the span) and the static
 // entities are still in the workgroup's LDS tables -- nothing is loaded but the action; bit 1 = the new state stays in `c`
 // for the next step of the span instead of going to global memory.  0 = a step of its own (loads and stores everything).
-struct StepCarry { double2 x, v; double pd, Dg, Tr, left, mtime; int noc, nac, match, step; };
+struct StepCarry { double2 x, v; double pd, Dg, Tr, left, mtime; int noc, nac, match, step, a_next; };   // (a_next: SMALL only -- the next step's action index, loaded a step ahead; -1 = none)
 
-template <bool FOLD>
+// SMALL (small batches of generic row shapes: all the workgroup's agents sit in wave 0, e.g. BASELINE config 2 -- 4 096 envs x 3 agents = 8
+// envs per workgroup): from the barrier behind which the emission's tables are final, wave 0 goes on with the agents' statistics, reward,
+// observation and info planes while waves 1 .. 3 emit node_obs and adj -- the two halves of a step's dependent chain side by side (the
+// launch of a batch that does not fill the chip takes as long as ONE workgroup's chain).  Never with FOLD (its commit has barriers) or a
+// policy-edge count.
+template <bool FOLD, bool SMALL = false>
 __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o, const int32_t *action_idx, const float *action_vec,
-                                          int auto_reset, StepCarry &c, const int carry) {
+                                          int auto_reset, StepCarry &c, const int carry, const int32_t *next_action_idx = nullptr) {
+    static_assert(!(FOLD && SMALL), "step_body: the folded episode end has workgroup barriers behind the agents' part");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x;
     const int env0 = env_block(p) * p.epb;
@@ -576,6 +727,14 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     int step = 0, match = 0;
     double Dg_old = 0, Tr_old = 0, left_old = 0;
     int noc_old = 0, nac_old = 0;
+    // SMALL: the agent's action index is a load from the tape in HBM -- a few thousand cycles that the contact forces used to wait
+    // for at the head of every step.  It is issued here with the state loads, and a span issues the NEXT step's a step ahead.
+    int a_now = -1;
+    if constexpr (SMALL) {
+        if ((carry & 1) && c.a_next >= 0) a_now = c.a_next;
+        else if (active && action_idx) a_now = action_idx[g];
+        c.a_next = (active && next_action_idx) ? next_action_idx[g] : -1;
+    }
     if (carry & 1) {   // (s_pos[i] already holds x: the previous step of the span wrote it, two barriers ago)
         x = c.x; v = c.v; pd = c.pd; match = c.match; step = c.step + 1;
         Dg_old = c.Dg; Tr_old = c.Tr; left_old = c.left; noc_old = c.noc; nac_old = c.nac; mtime = c.mtime;
@@ -599,7 +758,15 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     FMARL_TICK(0);   // state loads, entity tables, barrier (a carried step: nothing)
     // ---- World.step (core.py:250-274) ---------------------------------------------------------
     double2 goal = make_double2(0, 0);
-    if (active) {
+    if constexpr (SMALL) {
+        pair_contributions(p, lds, nenv);
+        __syncthreads();
+        if (active) {
+            const double2 F = agent_force_pairs(p, lds, base, (uint32_t)tid, g, action_idx, action_vec, x, a_now);
+            goal = s_pos[p.N + match];
+            integrate_agent(p, F, x, v, pd);
+        }
+    } else if (active) {
         const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x);
         goal = s_pos[p.N + match];
         integrate_agent(p, F, x, v, pd);
@@ -627,6 +794,14 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     }
     __syncthreads();
     FMARL_TICK(2);   // agent rows of the emission tables, statistics inputs, barrier
+    if constexpr (SMALL) {
+        if (tid >= 64) {   // waves 1 .. 3: the emission (pos / agentf / ego / posf / wall / flag are final since the barrier above)
+            emit_graph_waves(p, o, lds, env0, nenv);
+            FMARL_TICK(5);   // node_obs + adj by the emission waves
+            FMARL_TICKS_END;
+            return;
+        }
+    }
 
     // Statistics of the sequential agent loop.  N a power of two (an env = an aligned run of lanes of one wave):
     // wave scans of (mean, M2) runs, every lane taking part (idle lanes carry zeros); otherwise loops over LDS below.
@@ -651,19 +826,44 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         // fairness scalar of obs_i / reward_i (:764-769, :849-854): p_dist statistics while this
         // agent's dists_to_goal is still -1, otherwise the statistics info_{i-1} left behind.
         double fairness, m, sd;
+        bool info_stats_done = false;
         if (FMARL_SKIP(p, 2)) { m = 1.0; sd = 1.0; }
         else if (p.scan_stats) { m = f_m; sd = f_sd; }
+        else if (SMALL && o.info) {   // the three statistics of this step in one pass (a small batch waits for this lane's chain)
+            const bool unset = Dg_old == -1.0;
+            mixed_stats3(unset ? s_stat : s_stat + 2 * p.N, unset ? s_stat : s_stat + p.N, unset ? p.N : i,
+                         s_stat + 2 * p.N, s_stat + p.N, i + 1, s_stat + 4 * p.N, s_stat + 3 * p.N, i + 1, p.N, m, sd, dm, ds, tm, ts);
+            info_stats_done = true;
+        }
         else if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
         else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd);
         fairness = ratio_out(m, sd + 0.0001);
 
         // collisions (:701-705, :650-684)
         int ag_hits = 0;
+        bool ob_hit = false;
+        if constexpr (SMALL) {   // four table entries per LDS round trip (the last one repeated past the end; counted under a predicate)
+            const double thr_hit = 1.05 * (kEntitySize + kEntitySize);
+            for (int j0 = 0; j0 < p.N; j0 += 4) {
+                double2 qj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qj[j] = s_pos[min(j0 + j, p.N - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ag_hits += (j0 + j < p.N && j0 + j != i && closer_than(x, qj[j], thr_hit)) ? 1 : 0;
+            }
+            for (int k0 = 0; k0 < p.O; k0 += 4) {
+                double2 qk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qk[k] = s_pos[p.N + p.L + min(k0 + k, p.O - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ob_hit |= closer_than(qk[k], x, thr_hit);
+            }
+        } else {
         for (int j = 0; j < (FMARL_SKIP(p, 4) ? 0 : p.N); ++j)
             if (j != i && closer_than(x, s_pos[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
-        bool ob_hit = false;
         for (int k = 0; k < p.O; ++k)
             ob_hit |= closer_than(s_pos[p.N + p.L + k], x, 1.05 * (kEntitySize + kEntitySize));
+        }
         const double *wl = (const double *)(base + p.lds_wall);
         for (int w = 0; w < p.W; ++w)
             ob_hit |= wall_box_hit(x, wl[w * 4], wl[w * 4 + 1], wl[w * 4 + 2], (int)wl[w * 4 + 3]);
@@ -698,7 +898,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         if (o.info && !FMARL_SKIP(p, 8)) {
             // info_callback (:577-647): statistics after this agent's own update (entries <= i fresh).
             // Field-major records: info[k][env][agent], every store is lane-contiguous.
-            if (!p.scan_stats) {
+            if (!p.scan_stats && !info_stats_done) {
                 mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
                 mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
             }
@@ -786,7 +986,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     FMARL_TICK(4);   // statistics from LDS (other N), hits, reward, state / obs / info stores
     // emission only reads pos / agentf / wall / flag, all final since the barrier above
 #ifdef FMARL_MEASURE
-    if (!FMARL_SKIP(p, 32)) {   // emit_graph with clocks between its parts (odd workgroups write adj first)
+    if (!SMALL && !FMARL_SKIP(p, 32)) {   // emit_graph with clocks between its parts (odd workgroups write adj first)
         const bool adj_first = (blockIdx.x & 1) != 0;
         if (adj_first) emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
         FMARL_TICK(6);   // adj (odd workgroups)
@@ -804,7 +1004,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         FMARL_TICK(7);   // adj (even workgroups)
     }
 #else
-    if (!FMARL_SKIP(p, 32)) emit_graph(p, o, lds, env0, nenv);
+    if constexpr (!SMALL) { if (!FMARL_SKIP(p, 32)) emit_graph(p, o, lds, env0, nenv); }
 #endif
     FMARL_TICKS_END;
 }
@@ -828,6 +1028,13 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
 // the static entities in the LDS tables (StepCarry): only the first step loads the state, only the last one stores it, and
 // the step body's own barriers are all the ordering the steps need (a step's first LDS writes come two barriers after its
 // start, by when every wave has left the previous step's emission).
+// one launch per step of a small batch (step_body SMALL)
+__global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_small_kernel(
+    Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
+    StepCarry c;
+    step_body<false, true>(p, o, action_idx, action_vec, auto_reset, c, 0);
+}
+
 #ifndef FMARL_SPAN_BLOCKS
 #define FMARL_SPAN_BLOCKS 3
 #endif
@@ -843,6 +1050,19 @@ __global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_kernel(
         const FmarlOutputs ot = span_outputs(o, s, t);
         step_body<false>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr, action_vec ? action_vec + (size_t)t * s.actions : nullptr,
                          0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));
+    }
+}
+
+// the span of a small batch (step_body SMALL): between the steps the emission waves wait at the next step's first barrier, which is
+// also what keeps the next step's table writes behind their reads
+__global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_small_kernel(
+    Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, const float *action_vec, int T) {
+    StepCarry c = {};
+    for (int t = 0; t < T; ++t) {
+        const Params q = span_params(p);
+        const FmarlOutputs ot = span_outputs(o, s, t);
+        step_body<false, true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr, action_vec ? action_vec + (size_t)t * s.actions : nullptr,
+                               0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0), (action_idx && t < T - 1) ? action_idx + (size_t)(t + 1) * s.actions : nullptr);
     }
 }
 

@@ -142,6 +142,7 @@ struct Handle {
     unsigned long long cap_stage_id;  // capture in which the staging of the next episode was last enqueued (0 = eagerly)
     size_t place_lds;   // dynamic LDS of reset_place_kernel<true> (0: positions stay in global memory)
     int span_threads;   // workgroup size of the span kernel (fairnav: 192 when the agent lanes fit three waves, else = threads)
+    bool small_ok;      // navigation_graph: the small-batch kernels apply (fmarl_step.hip step_body SMALL) unless the call counts policy edges
     hipEvent_t *ev;     // profiling: 2 * ev_cap events around step-kernel launches
     int *ev_steps;      // env steps each profiled launch covers (a span launch: many)
     int ev_cap, ev_n;
@@ -463,6 +464,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // -- for the span kernel only, which carries the state: one launch per step measured 4 % slower on three waves (the emission is
     // shared by fewer waves) and has no carry to fit
     h->span_threads = (fnav && epb * p.N <= 192) ? 192 : h->threads;
+    h->small_ok = false;   // (decided below, once the emission shapes are known)
     p.lds_stage = align16(epb * p.lds_env_bytes);
     if (form) {   // the second region: epw envs per wave, the wave's part = its emission window
         p.stage_wave_bytes = p.epw * form_dead;
@@ -498,6 +500,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.dEE4.set(p.vec_adj ? p.E * (p.E / 4) : 1);
     p.dE4.set(p.vec_adj ? p.E / 4 : 1);
     if (fnav) p.dC4.set(p.N * p.E);   // fairnav emission: (ego, entity) rows per env
+    // small batches of navigation_graph (all agents of a workgroup in its first wave, rows of generic shape): waves 1 .. 3 emit while
+    // wave 0 finishes the agents' part (step_body SMALL).  The statistics blocks, which share the emission windows' region, must sit
+    // inside wave 0's window: the emission waves write the other three.
+    const int partners = p.N + p.O + p.W;   // (every wave's window also takes its 64 contact pairs: 16 + 4 bytes each)
+    h->small_ok = !form && !fnav && !p.vec_node && staged && epb * p.N <= 64 && partners <= 32 && epb * p.N * partners <= kThreads &&
+                  p.stage_wave_bytes >= 64 * 20 && (!stat_shared || (size_t)epb * p.stat_stride <= (size_t)p.stage_wave_bytes);
+    p.dP.set(partners); p.dN.set(p.N);
     {   // FastDiv (fmarl_dev.h) is exact only while dividend * divisor < 2^40: check every divisor against the largest
         // dividend its call sites form (indices inside one workgroup's share of an output array)
         const uint64_t E = p.E, N = p.N, F = p.F, EE = E * E, e = epb, lim = 1ull << 40;
@@ -510,6 +519,8 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_end_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_span_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_span_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_span_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)rebuild_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
@@ -732,6 +743,9 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
                            action_vec, auto_reset ? 1 : 0);
     else if (fold)
         hipLaunchKernelGGL(step_end_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec, 1);
+    else if (h->small_ok && !outs->edge_nnz)
+        hipLaunchKernelGGL(step_small_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
+                           auto_reset ? 1 : 0);
     else
         hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
                            auto_reset ? 1 : 0);
@@ -810,6 +824,8 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
                 FMARL_FNAV_T(h->span_threads, (fairnav_span_kernel<TH>), dim3(h->grid), h->lds_bytes, st, FairnavSpanArgs{p, o, s, a, av, k, 1});
             else if (sc == FMARL_SCENARIO_FORMATION)
                 hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
+            else if (h->small_ok && !o.edge_nnz)
+                hipLaunchKernelGGL(step_span_small_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             else
                 hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = k; ++h->ev_n; }
@@ -885,60 +901,42 @@ int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, i
 
 // ---- time-slot arrays with interleaved physical memory (include/fmarl.h fmarl_ring_alloc)
 namespace {
-// A virtual address range this process reserved for an array of pieces.  Ranges are NEVER given back to the runtime
-// (hipMemAddressFree): on this stack (ROCm 7.2, MI355X) a range that is freed and handed out again by a later
-// hipMemAddressReserve keeps stale translations in the GPU for a while -- an array mapped there read back zeroes in up to 70 %
-// of its bytes right after a fill, other bytes changed seconds later, two reads of the same element disagreed
-// (tools/vmm_reuse_probe.py; tests/test_hip_parity.py test_time_slots_after_a_freed_array_keep_what_is_written).  With the
-// ranges kept out of the runtime's circulation: none of it.  What that costs is address space, and it is bounded here: a freed
-// array's range goes to a free list and the next request of the same (device, size) maps its fresh physical pieces into it --
-// the common case (a sweep, a test suite, an engine rebuilt with the same shape) reserves nothing new -- and a request that would
-// take the reservations past kRingReserveCap is refused with an error instead of growing without bound.
-struct RingRange { void *ptr; size_t total; int dev; bool in_use; };
+// A virtual address range this process reserved for an array of pieces.  An address that has carried a mapping is NEVER used again,
+// neither by the runtime (hipMemAddressFree) nor by this allocator: on this stack (ROCm 7.2, MI355X) the GPU keeps translations of
+// an unmapped range for a while.  Round 4 found it with ranges that went back to the runtime and came out of a later
+// hipMemAddressReserve again (an array mapped there read back zeroes in up to 70 % of its bytes right after a fill, other bytes
+// changed seconds later: tools/vmm_reuse_probe.py); round 5 tried to re-use a KEPT range for the next array of the same size --
+// fresh pieces mapped into a range that never left the process -- and hit the same fault: the new array passed a fill / read-back
+// through the copy engines and then lost 20 MiB of a kernel's fill (tests/test_hip_parity.py
+// test_time_slots_after_a_freed_array_keep_what_is_written, third array; profiles/r5_notes.md).  Writes through a stale translation land in
+// physical memory that has been released: not a path to keep "verified".  So freed ranges stay reserved and idle.  What that costs is
+// address space, and it is bounded and visible: the reservations are counted (fmarl_ring_stats) and a request that would take them
+// past the cap -- 8 TiB of the 47 bits, FMARL_RING_RESERVE_CAP_GB overrides -- is refused with an error: allocate plainly then.
 struct RingAlloc {
-    size_t range = 0;                       // index into g_ranges
-    size_t piece = 0, mapped = 0;           // `mapped` virtual pieces from the start of the range are mapped
+    void *ptr = nullptr;
+    size_t total = 0, piece = 0, mapped = 0;   // `mapped` virtual pieces from the start of the range are mapped
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
 std::mutex g_ring_mutex;
-std::vector<RingRange> g_ranges;
-uint64_t g_ring_reserved = 0, g_ring_reuses = 0, g_ring_check_fails = 0;
-constexpr uint64_t kRingReserveCap = (uint64_t)8 << 40;   // 8 TiB of the 47-bit address space
+uint64_t g_ring_reserved = 0, g_ring_live = 0, g_ring_ranges = 0, g_ring_live_ranges = 0, g_ring_refused = 0;
+uint64_t ring_reserve_cap() {
+    static const uint64_t cap = [] {
+        const char *e = getenv("FMARL_RING_RESERVE_CAP_GB");
+        const double gb = e ? atof(e) : 0.0;
+        return gb > 0.0 ? (uint64_t)(gb * 1073741824.0) : (uint64_t)8 << 40;
+    }();
+    return cap;
+}
 
 void ring_release(RingAlloc *r) {
     if (!r) return;
-    std::lock_guard<std::mutex> lock(g_ring_mutex);
-    RingRange &g = g_ranges[r->range];
-    for (size_t k = 0; k < r->mapped; ++k) (void)hipMemUnmap((char *)g.ptr + k * r->piece, r->piece);   // (piece by piece, as they were mapped)
+    for (size_t k = 0; r->ptr && k < r->mapped; ++k) (void)hipMemUnmap((char *)r->ptr + k * r->piece, r->piece);   // (piece by piece, as they were mapped)
     for (auto h : r->handles) (void)hipMemRelease(h);
-    g.in_use = false;   // the range stays reserved and waits for the next array of its size
-    delete r;
-}
-
-// Does the freshly mapped array hold what is written into it?  (Only run on a range that carried an earlier array: re-mapping
-// into a range that never went back to the runtime is not the path that failed, but the failure's mechanism is not
-// established, so the first use of such a range is verified -- a pattern fill, 64 bytes of every piece read back, then zeroes.)
-// -> 0 = holds; otherwise a message in `why`
-bool ring_self_check(void *ptr, size_t total, size_t piece, char *why, size_t why_len) {
-    const uint32_t pat = 0x5AC3E1B7u;
-    hipError_t e = hipMemsetD32((hipDeviceptr_t)ptr, (int)pat, total / 4);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { snprintf(why, why_len, "pattern fill: %s", hipGetErrorString(e)); return false; }
-    const size_t pieces = total / piece;
-    uint32_t host[16];
-    size_t wrong = 0, first = 0;
-    for (size_t k = 0; k < pieces; ++k) {   // 64 bytes from the middle of every piece
-        e = hipMemcpy(host, (const char *)ptr + k * piece + piece / 2, sizeof host, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { snprintf(why, why_len, "read-back of piece %zu: %s", k, hipGetErrorString(e)); return false; }
-        bool ok = true;
-        for (uint32_t w : host) ok &= w == pat;
-        if (!ok && !wrong++) first = k;
+    if (r->ptr) {   // the range stays reserved, idle from here on
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        g_ring_live -= r->total; --g_ring_live_ranges;
     }
-    if (wrong) { snprintf(why, why_len, "%zu of %zu pieces read back something else than the pattern (first: piece %zu)", wrong, pieces, first); return false; }
-    e = hipMemsetD32((hipDeviceptr_t)ptr, 0, total / 4);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { snprintf(why, why_len, "zero fill: %s", hipGetErrorString(e)); return false; }
-    return true;
+    delete r;
 }
 }  // namespace
 
@@ -967,32 +965,25 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     const size_t per_slot = slot_bytes / piece_bytes, count = per_slot * (size_t)slots, total = slot_bytes * (size_t)slots;
     RingAlloc *r = new (std::nothrow) RingAlloc();
     if (!r) return fail(FMARL_EINVAL, "fmarl_ring_alloc: out of host memory");
+    r->total = total;
     r->piece = piece_bytes;
-    void *ptr = nullptr;
-    bool reused = false;
     {
         std::lock_guard<std::mutex> lock(g_ring_mutex);
-        for (size_t k = 0; k < g_ranges.size() && !ptr; ++k)   // a kept range of exactly this size on this device
-            if (!g_ranges[k].in_use && g_ranges[k].dev == dev && g_ranges[k].total == total) {
-                g_ranges[k].in_use = true; r->range = k; ptr = g_ranges[k].ptr; reused = true; ++g_ring_reuses;
-            }
-        if (!ptr) {
-            if (g_ring_reserved + total > kRingReserveCap) {
-                delete r;
-                return fail(FMARL_EINVAL, "fmarl_ring_alloc: this process has reserved 8 TiB of address space for arrays of pieces (freed ranges are kept "
-                                          "and only re-used by arrays of the same size): allocate plainly");
-            }
-            hipError_t e = hipMemAddressReserve(&ptr, total, (size_t)2 << 20, nullptr, 0);   // (the alignment must be a power of two; pieces need not be)
-            if (e != hipSuccess) {
-                (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
-                delete r;
-                return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e));
-            }
-            g_ranges.push_back(RingRange{ptr, total, dev, true});
-            r->range = g_ranges.size() - 1;
-            g_ring_reserved += total;
+        if (g_ring_reserved + total > ring_reserve_cap()) {
+            ++g_ring_refused;
+            delete r;
+            return fail(FMARL_EINVAL, "fmarl_ring_alloc: the address space this process may reserve for arrays of pieces is used up (freed arrays keep "
+                                      "their ranges: the GPU holds on to translations of unmapped addresses; FMARL_RING_RESERVE_CAP_GB, default 8192): allocate plainly");
         }
+        hipError_t e = hipMemAddressReserve(&r->ptr, total, (size_t)2 << 20, nullptr, 0);   // (the alignment must be a power of two; pieces need not be)
+        if (e != hipSuccess) {
+            (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
+            delete r;
+            return fail(FMARL_EHIP, "fmarl_ring_alloc: hipMemAddressReserve: %s", hipGetErrorString(e));
+        }
+        g_ring_reserved += total; g_ring_live += total; ++g_ring_ranges; ++g_ring_live_ranges;
     }
+    void *ptr = r->ptr;
     hipError_t e = hipSuccess;
     r->handles.reserve(count);
     for (size_t k = 0; k < count && e == hipSuccess; ++k) {   // physical pieces, in creation order
@@ -1025,23 +1016,8 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
-        ring_release(r);           // unmaps what was mapped, releases every piece; the range waits for the next request of its size
+        ring_release(r);           // unmaps what was mapped, releases every piece; the range stays reserved (and counted)
         return fail(FMARL_EHIP, "fmarl_ring_alloc: %s", hipGetErrorString(e));
-    }
-    char why[200] = "";
-    if (reused && !ring_self_check(ptr, total, piece_bytes, why, sizeof why)) {
-        (void)hipGetLastError();
-        {
-            std::lock_guard<std::mutex> lock(g_ring_mutex);
-            ++g_ring_check_fails;
-        }
-        const size_t idx = r->range;
-        ring_release(r);
-        {   // this range is never handed out again
-            std::lock_guard<std::mutex> lock(g_ring_mutex);
-            g_ranges[idx].in_use = true;
-        }
-        return fail(FMARL_EHIP, "fmarl_ring_alloc: a re-used address range failed its verification (%s): allocate plainly", why);
     }
     *base = ptr; *cookie = r;
     return FMARL_OK;
@@ -1056,9 +1032,8 @@ int fmarl_ring_free(void *cookie) {
 int fmarl_ring_stats(uint64_t out[6]) {
     if (!out) return fail(FMARL_EINVAL, "fmarl_ring_stats: null argument");
     std::lock_guard<std::mutex> lock(g_ring_mutex);
-    uint64_t idle = 0, kept = 0;
-    for (const RingRange &g : g_ranges) if (!g.in_use) { idle += g.total; ++kept; }
-    out[0] = g_ring_reserved; out[1] = idle; out[2] = g_ranges.size(); out[3] = kept; out[4] = g_ring_reuses; out[5] = g_ring_check_fails;
+    out[0] = g_ring_reserved; out[1] = g_ring_reserved - g_ring_live; out[2] = g_ring_ranges; out[3] = g_ring_ranges - g_ring_live_ranges;
+    out[4] = ring_reserve_cap(); out[5] = g_ring_refused;
     return FMARL_OK;
 }
 

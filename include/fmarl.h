@@ -319,17 +319,16 @@ int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, i
  * library's choice (<= 16 MiB, a divisor of slot_bytes); otherwise a multiple of the allocation granularity that divides
  * slot_bytes.  FMARL_EINVAL when the slot size has no such divisor, FMARL_EHIP when the device has no virtual memory management:
  * allocate plainly then.  The memory belongs to the caller until fmarl_ring_free(cookie) (no launch may still use it).
- * fmarl_ring_free returns the physical memory; the array's virtual address range stays reserved by the process (a range that goes
- * back to the runtime and is reserved again reads back stale data on this stack: tools/vmm_reuse_probe.py) and is handed to the
- * next fmarl_ring_alloc of the same total size on the same device, whose first use of it is verified (pattern fill, a sample of
- * every piece read back; the array then starts out zeroed).  Reservations are capped at 8 TiB per process: past that, and when
- * the verification fails, FMARL_EINVAL / FMARL_EHIP -- allocate plainly.  Access is granted to the allocating device and to every
- * device that has peer access to it. */
+ * fmarl_ring_free returns the physical memory; the array's virtual address range stays reserved, idle, for the life of the process:
+ * on this stack the GPU holds on to translations of unmapped addresses, whether the range goes back to the runtime and is reserved
+ * again (round 4) or stays with the process and gets fresh pieces mapped into it (round 5: tried, same fault) -- an address that
+ * has carried a mapping is never used again (tools/vmm_reuse_probe.py).  The reservations are
+ * counted and capped (8 TiB per process; FMARL_RING_RESERVE_CAP_GB overrides): past the cap FMARL_EINVAL -- allocate plainly.
+ * Access is granted to the allocating device and to every device that has peer access to it. */
 int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **base, void **cookie);
 int fmarl_ring_free(void *cookie);
-/* The allocator's books: out[0] bytes of address space reserved so far, [1] of them idle (kept ranges no array is mapped into),
- * [2] ranges reserved, [3] of them idle, [4] requests served from a kept range, [5] kept ranges that failed their verification
- * (retired).  A process that allocates and frees arrays of the same size over and over keeps [0] constant. */
+/* The allocator's books: out[0] bytes of address space reserved so far, [1] of them idle (ranges of freed arrays), [2] ranges
+ * reserved, [3] of them idle, [4] the cap on [0] in bytes, [5] requests refused at the cap. */
 int fmarl_ring_stats(uint64_t out[6]);
 
 /* --- pieces exported on their own -------------------------------------------------------- */

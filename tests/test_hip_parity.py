@@ -1860,13 +1860,15 @@ def test_time_slots_after_a_freed_array_keep_what_is_written():
         torch.cuda.synchronize()
 
 
-def test_time_slot_allocator_reuses_its_address_ranges():
-    """fmarl_ring_free keeps the array's address range (it must not go back to the runtime: the test above) -- and the next array
-    of the same size is mapped into it: 50 allocate / write / check / free cycles of two alternating sizes reserve address space
-    twice, not a hundred times (fmarl_ring_stats), every array holds what is written into it, and the first use of a kept range
-    starts out zeroed (its verification pass)."""
+def test_time_slot_allocator_keeps_books_and_a_cap():
+    """fmarl_ring_free keeps the array's address range reserved and idle for good (an address that carried a mapping is never used again:
+    the test above; re-using a kept range for the next array of the same size was tried in round 5 and lost a kernel's writes the same
+    way) -- so the reservations are counted and capped: fmarl_ring_stats follows every allocate / free, and a process whose cap is
+    used up (FMARL_RING_RESERVE_CAP_GB, here in a child process) gets a clear refusal and a plain allocation instead."""
     import ctypes as C
     import gc
+    import subprocess
+    import sys
     from fair_marl_amd import _lib
     from fair_marl_amd.engine import alloc_time_slots
     lib = _lib.load()
@@ -1877,30 +1879,33 @@ def test_time_slot_allocator_reuses_its_address_ranges():
     def read():
         assert lib.fmarl_ring_stats(stats) == 0
         return [int(v) for v in stats]
-    shapes = [(2, 32768, 10, 16, 12), (3, 16384, 6, 16, 11)]
-    before = read()
-    reserved_after_first = None
-    for k in range(50):
-        shape = shapes[k % 2]
+    shape = (2, 32768, 6, 16, 11)
+    nbytes = 4 * int(np.prod(shape))
+    b = read()
+    assert b[4] == 8 << 40 and b[0] >= b[1] and b[2] >= b[3]
+    for k in range(3):
         t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
         assert interleaved
-        if k >= 2:
-            assert int((t != 0).sum()) == 0, 'a re-used range starts out zeroed (cycle %d)' % k
+        a = read()
+        assert a[0] - b[0] == (k + 1) * nbytes and a[1] - b[1] == k * nbytes and a[2] - b[2] == k + 1 and a[3] - b[3] == k   # one live, k idle
         t.fill_(float(k + 1))
         torch.cuda.synchronize()
-        flat = t.view(-1)
-        assert int((flat != float(k + 1)).sum()) == 0, 'array %d right after its fill' % k
-        assert int((flat.cpu() != float(k + 1)).sum()) == 0, 'array %d copied to the host' % k
-        del t, flat
+        assert int((t != float(k + 1)).sum()) == 0
+        del t
         gc.collect()
         torch.cuda.synchronize()
-        now = read()
-        if k == 1:
-            reserved_after_first = now[0]
-        if k >= 1:
-            assert now[0] == reserved_after_first or k == 1
-    after = read()
-    total = sum(4 * int(np.prod(s)) for s in shapes)
-    assert after[0] - before[0] <= total, 'address space reserved once per size (kept ranges of an earlier test may even serve these)'
-    assert after[4] - before[4] >= 48 and after[5] == before[5], after   # 48 of the 50 requests came out of kept ranges, none failed its check
-    assert after[1] >= total   # both ranges idle again
+        a = read()
+        assert a[1] - b[1] == (k + 1) * nbytes and a[3] - b[3] == k + 1
+    code = ("import torch, ctypes as C\nfrom fair_marl_amd import _lib\nfrom fair_marl_amd.engine import alloc_time_slots\n"
+            "lib = _lib.load(); dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
+            "shape = (2, 32768, 6, 16, 11)\n"
+            "a, ia = alloc_time_slots(lib, dev, shape, spread=None); del a; torch.cuda.synchronize()\n"
+            "b, ib = alloc_time_slots(lib, dev, shape, spread=None)   # past the cap of 0.3 GiB: a plain allocation\n"
+            "b.fill_(2.0); ok = int((b != 2.0).sum()) == 0\n"
+            "s = (C.c_uint64 * 6)(); lib.fmarl_ring_stats(s)\n"
+            "try:\n    alloc_time_slots(lib, dev, shape, spread=True); raised = False\nexcept MemoryError as e:\n    raised = 'FMARL_RING_RESERVE_CAP_GB' in str(e)\n"
+            "print('RESULT', ia, ib, ok, int(s[5]), raised)\n")
+    env = dict(os.environ, FMARL_RING_RESERVE_CAP_GB='0.3', PYTHONPATH=os.path.dirname(HERE))
+    res = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=env, cwd=os.path.dirname(HERE))
+    line = [l for l in res.stdout.splitlines() if l.startswith('RESULT')]
+    assert line and line[0].split()[1:] == ['True', 'False', 'True', '1', 'True'], (res.stdout[-2000:], res.stderr[-2000:])

@@ -85,7 +85,7 @@ def test_entry_points_validate_arguments_on_the_host(lib):
     assert lib.fmarl_ring_alloc(0, 4, 0, C.byref(base), C.byref(cookie)) == 1 and lib.fmarl_ring_alloc(1 << 20, 0, 0, C.byref(base), C.byref(cookie)) == 1
     assert lib.fmarl_ring_free(None) == 1 and lib.fmarl_ring_stats(None) == 1
     stats = (C.c_uint64 * 6)()
-    assert lib.fmarl_ring_stats(stats) == 0 and stats[0] >= stats[1] and stats[2] >= stats[3]
+    assert lib.fmarl_ring_stats(stats) == 0 and stats[0] >= stats[1] and stats[2] >= stats[3] and stats[4] == 8 << 40
     assert lib.fmarl_store_stream(None, 4096, 0, 0, 1, 0, None) == 1 and lib.fmarl_store_stream(buf, 64, 1, 100, 1, 0, None) == 1
     assert lib.fmarl_store_stream(buf, 1 << 20, 2, 4096, 2, 0, None) == 1 and b'coprime' in lib.fmarl_last_error()   # 256 chunks, order 2: not a permutation
     assert lib.fmarl_pack_episode(h, None, None, None) == 1 and lib.fmarl_rebuild_graph(h, None, None, 4, None, None, None) == 1

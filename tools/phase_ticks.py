@@ -32,6 +32,9 @@ def main():
     gen = torch.Generator(device='cuda:0'); gen.manual_seed(2)
     eng.reset()
     tape = torch.randint(0, 5, (25, n, cfg.N), device='cuda:0', generator=gen, dtype=torch.int32)
+    if os.environ.get('FMARL_TICKS_SPAN'):   # the LAST step of one span launch of FMARL_TICKS_SPAN steps (every step rewrites the wave's row)
+        eng.step_span(tape[:int(os.environ['FMARL_TICKS_SPAN'])].contiguous())
+        steps = 0
     for t in range(steps):
         eng.step(tape[t % 25])
     lib = _lib.load()
@@ -58,6 +61,11 @@ def main():
     rows = np.zeros((waves, 16), dtype=np.uint32)
     lib.fmarl_measure_rows.argtypes = [C.c_void_p, C.c_int]
     assert lib.fmarl_measure_rows(rows.ctypes.data, waves) == 0
+    if name not in ('fnav', 'cfg4') and eng.envs_per_workgroup * cfg.N <= 64:   # small batches (step_body SMALL): wave 0 = the agents, waves 1 .. 3 = the emission
+        for label, sel in (('wave 0 of a workgroup (agents)', rows[0::4]), ('waves 1 .. 3 (emission)', np.concatenate([rows[1::4], rows[2::4], rows[3::4]]))):
+            print('%s: %.0f cycles per wave' % (label, sel[:, :14].sum() / len(sel)))
+            for k, nm in enumerate(NAMES_NAV):
+                print('    %-26s %8.0f cycles' % (nm, sel[:, k].mean()))
     start, end = rows[:, 15].astype(np.int64), rows[:, 14].astype(np.int64)
     t0 = start.min()
     print('wave starts (us after the first, 100 MHz clock): percentiles 10/50/90/99/100 = %s' % np.round(np.percentile((start - t0) / 100.0, [10, 50, 90, 99, 100]), 1))
