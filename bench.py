@@ -63,7 +63,7 @@ SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg3', 'span5'), ('cfg3', 's
              ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'span'), ('fnav', 'pipeline2'), ('fnav', 'steady'), ('fnav', 'steady-span'),
              ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
 # nav_fairassign_fairrew_formation_graph where a training run is: a threshold at which goals are reached, so that episodes end
-# env by env, and enough untimed steps for the envs' episode phases to be uniform (mode 'steady'; tools/fnav_steady.py)
+# env by env, and enough untimed steps for the envs' episode phases to be uniform (mode 'steady'; tools/archive/fnav_steady.py)
 STEADY = dict(min_dist_thresh=0.5, pre_steps=600)
 
 

@@ -364,7 +364,7 @@ __device__ __forceinline__ void emit_graph(const Params &p, const FmarlOutputs &
     const uint32_t NEF = p.N * p.E * p.F, EF = p.E * p.F, EE = p.E * p.E;
     // odd workgroups write adj first: the two output streams are then mixed over the chip at any time, instead of every
     // workgroup of a generation being in the node stream and then every one in the adj stream (cfg 3, one launch per step:
-    // 1.602 -> 1.592 ms and 1.490 -> 1.479 on two boxes, profiles/r3_notes.md)
+    // 1.602 -> 1.592 ms and 1.490 -> 1.479 on two boxes, profiles/archive/r3_notes.md)
     const bool adj_first = (blockIdx.x & 1) != 0;
     if (adj_first) emit_adj(p, o, lds, env0, 0, nenv, tid, kThreads);
     if (o.node_obs && p.vec_node) {

@@ -386,7 +386,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         // the env's block packed to 8 bytes, 8-byte row records: 352 + 272 = 624 bytes per env at N = 3, i.e. 64 envs per
         // workgroup in 39 KB = 1 024 workgroups for 65 536 envs, ALL resident at once (four per CU).  With 640 bytes per env the
         // workgroup took exactly 40 960 bytes and only three fit a CU: 768 workgroups ran, then the other 256 -- two generations
-        // of a 31 us chain, 65 us per launch; 40 320 bytes is the most that was seen to fit four (profiles/r3_notes.md)
+        // of a 31 us chain, 65 us per launch; 40 320 bytes is the most that was seen to fit four (profiles/archive/r3_notes.md)
         int o2 = 0;
         p.lds_pos = o2;    o2 += p.E * 16;
         p.lds_agentf = o2; o2 += p.N * 16;
@@ -400,7 +400,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         off = align16(o2);
         // Tables nobody reads once the emission starts: a region of their own behind all envs' blocks, which the waves' emission
         // windows alias (13.5 KB that used to sit beside the envs' tables: 36 -> 58 envs per workgroup in the shipped FA+FR
-        // configuration, and the launch time falls with the number of workgroups: tools/epb_sweep.py fnav)
+        // configuration, and the launch time falls with the number of workgroups: tools/archive/epb_sweep.py fnav)
         int d = 0;
         p.lds_stat = d;    d += 5 * p.N * 8;        // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
         p.n_D = d;         d += p.N * p.L * 8;
@@ -430,7 +430,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     if (epb < 1) epb = 1;
     // fair_graph_formation: every env lives inside one wave (fmarl_formation.hip), 64 / N envs per wave, and no wave ever waits
     // for another one.  Workgroups of ONE wave (the scheduler placing 64-lane units) measured slower than four waves per
-    // workgroup: 0.295 vs 0.274 ms per launch at BASELINE config 4, two waves 0.276-0.286 (profiles/r3_cfg4_notes.md)
+    // workgroup: 0.295 vs 0.274 ms per launch at BASELINE config 4, two waves 0.276-0.286 (profiles/archive/r3_cfg4_notes.md)
     int form_waves = kThreads / 64;
 #ifdef FMARL_MEASURE
     if (const char *e = getenv("FMARL_FORM_WAVES")) form_waves = atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : form_waves;

@@ -99,7 +99,7 @@ class RolloutEngine:
         How fast the store stream of the emission runs depends, on SOME boxes, on which physical pages the two allocations
         happened to get, and on the pair rather than on either buffer: 1.36 to 1.54 ms per emission launch over the pairs
         of one process at BASELINE config 3, repeatable to 0.2 % for a given pair; on most boxes all pairs agree within 2 %.
-        ``profiles/r2_placement_tcc.md`` has the counters: the L2 -> fabric write requests are spread evenly over the 128
+        ``profiles/archive/r2_placement_tcc.md`` has the counters: the L2 -> fabric write requests are spread evenly over the 128
         TCC channels for fast and slow pairs alike (no aliasing the kernel could undo); the slow pair back-pressures a few
         channels harder (DRAM credit stalls, max over channels +12 %), a property of the physical page placement that
         neither the kernel nor the caller controls.  So the remedy is to measure: every pair of 3 node_obs x ``candidates``

@@ -2,7 +2,7 @@
 
 A step kernel over 65 536 envs has a head (every workgroup loads, then computes, then stores at the same time) and a
 tail (the last workgroups of the grid run on a nearly empty chip); at BASELINE config 4 the two are about a sixth of the
-launch (profiles/NOTES.md, the two-stream probe of round 2: the launch time is 0.05 ms + 0.255 ms per 65 536 envs).  Envs are independent
+launch (profiles/archive/NOTES.md, the two-stream probe of round 2: the launch time is 0.05 ms + 0.255 ms per 65 536 envs).  Envs are independent
 (the reference steps them in separate OS processes, onpolicy/envs/env_wrappers.py:951-1026), so consecutive steps of
 DIFFERENT envs need no ordering: the batch is split into k contiguous sub-batches, each a ``RolloutEngine`` on its own
 stream with ``env_offset`` so that the union is the same set of envs with the same random streams, and the tail of one
@@ -75,7 +75,7 @@ class PipelinedRollout:
         int32 device tape per sub-batch (a slice of a (T, n_envs, N) tape along the env axis is not contiguous: split the
         tape once, ``split_tape``).  With spans (the engines' default mode) a sub-batch's run of steps is one launch, and the
         launch boundaries of one sub-batch -- the episode-ending step between two runs, where the chip drains and refills --
-        fall into the other's steady state: 10 agents x 65 536 envs 0.181 -> 0.163 ms per step (profiles/r3_notes.md).
+        fall into the other's steady state: 10 agents x 65 536 envs 0.181 -> 0.163 ms per step (profiles/archive/r3_notes.md).
         ``rings``: one ``OutputRing`` per sub-batch (``new_rings``) -- step t of every sub-batch goes to its time slot t."""
         if len(action_tapes) != self.k:
             raise ValueError('expected %d per-sub-batch tapes, got %d' % (self.k, len(action_tapes)))

@@ -245,7 +245,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
  * between the steps; 65 536 x 3: 0.059 -> 0.050 ms per step, profiles/r4_notes.md).
  * The scripted / random-action rollout of the reference's throughput runs; a policy in the loop needs fmarl_step.  Not
  * capturable into a hipGraph (it decides on the host where episodes end; it needs no graph: an episode is three launches).
- * Measured (profiles/r3_notes.md): 10 agents x 65 536 envs 0.250 -> 0.199 ms per step, 3 agents x 4 096 envs 14.5 -> 11.5 us. */
+ * Measured (profiles/archive/r3_notes.md): 10 agents x 65 536 envs 0.250 -> 0.199 ms per step, 3 agents x 4 096 envs 14.5 -> 11.5 us. */
 typedef struct FmarlSpan {
     int64_t obs, node_obs, adj, reward, done, info, edge_nnz, graph_record;   /* per-step strides of the outputs, in elements */
     int64_t actions;   /* per-step stride of the action tape in elements: n * N for dense action_idx, n * N * 5 for action_vec */
@@ -314,7 +314,7 @@ int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, i
  * contiguous, but their PHYSICAL memory is interleaved: the array is backed by slots * slot_bytes / piece_bytes physical pieces
  * (hipMemCreate), and virtual piece j of slot t is mapped to physical piece j * slots + t -- every slot is spread evenly over the
  * whole allocation.  Why: MI355X takes a store stream at 5.7-6.0 TB/s when its target is one contiguous 8 GB region and at 6.8-7.1
- * TB/s when the same bytes are spread over 160 GB, even in pieces of 32 MiB (tools/spread_probe.hip, profiles/r4_notes.md) -- a
+ * TB/s when the same bytes are spread over 160 GB, even in pieces of 32 MiB (tools/archive/spread_probe.hip, profiles/r4_notes.md) -- a
  * launch that writes ONE time slot (a policy in the loop: fmarl_step) gets the rate of the whole ring.  piece_bytes = 0: the
  * library's choice (<= 16 MiB, a divisor of slot_bytes); otherwise a multiple of the allocation granularity that divides
  * slot_bytes.  FMARL_EINVAL when the slot size has no such divisor, FMARL_EHIP when the device has no virtual memory management:

@@ -1275,7 +1275,7 @@ def test_exhausted_rejection_sampling_is_reported():
 
 
 def test_placement_probe_is_bounded(monkeypatch, caplog):
-    """RolloutEngine's output-placement probe (profiles/r2_placement_tcc.md): runs on request, never changes results,
+    """RolloutEngine's output-placement probe (profiles/archive/r2_placement_tcc.md): runs on request, never changes results,
     and steps aside -- with a log line -- when its candidate allocations would not fit beside what owns the HBM."""
     import logging
     cfg = fm.EnvConfig(num_agents=4, num_landmarks=4, num_obstacles=4)

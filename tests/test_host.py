@@ -373,7 +373,7 @@ def test_hot_kernels_keep_their_register_and_scratch_budget():
                                                  ('17reset_emit_kernel', 96, 0, 5),
                                                  ('20rebuild_graph_kernel', 96, 0, 5), ('15step_end_kernel', 112, 0, 4),
                                                  # the span kernels (the bench's default launch mode) and the learner-side gather: the latter once
-                                                 # compiled to 179 VGPRs = two waves per SIMD for a copy kernel (profiles/r3_notes.md)
+                                                 # compiled to 179 VGPRs = two waves per SIMD for a copy kernel (profiles/archive/r3_notes.md)
                                                  ('16step_span_kernel', 160, 0, 3), ('21formation_span_kernel', 128, 0, 4),
                                                  ('23minibatch_gather_kernel', 112, 0, 4),
                                                  # three waves per workgroup (64 envs x 3 agents: the shipped configuration): 168 registers at four

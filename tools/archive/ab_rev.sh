@@ -1,7 +1,7 @@
 #!/bin/bash
 # measurement aid (GPU box): whole revisions against the working tree on ONE box -- each revision is a git worktree under _ab/<rev>
 # with its own library and its own bench.py (build container: git worktree add _ab/<rev> <rev>; build it there).
-#   tools/ab_rev.sh <config> <steps> <rounds> <rev> [<rev> ...]     "." = the working tree
+#   tools/archive/ab_rev.sh <config> <steps> <rounds> <rev> [<rev> ...]     "." = the working tree
 R=$(cd "$(dirname "$0")/.." && pwd)
 CFG=$1; STEPS=$2; ROUNDS=$3; shift 3
 for r in $(seq 1 $ROUNDS); do for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # measurement aid (GPU box): alternate library variants on ONE box (box-to-box spread is larger than most changes).
-#   tools/abrun.sh <config> <steps> <rounds> <name> [<name> ...]      name "ship" = the shipped libfmarl.so
+#   tools/archive/abrun.sh <config> <steps> <rounds> <name> [<name> ...]      name "ship" = the shipped libfmarl.so
 # Extra bench.py arguments through ABRUN_ARGS; environment for the variants (e.g. FMARL_ABLATE) is inherited.
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 CFG=$1; STEPS=$2; ROUNDS=$3; shift 3

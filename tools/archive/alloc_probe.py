@@ -1,7 +1,7 @@
 """measurement aid (GPU box): does the rate of a pure store stream depend on WHEN in a process its buffer was allocated?  A fresh process
 allocates a large buffer, streams into it (fmarl_store_stream, scattered 64 KB chunks), frees it (torch.cuda.empty_cache), allocates
 and frees a few odd-sized tensors, allocates the large buffer again, ... -- and the same with the buffer kept and re-used.
-usage: python tools/alloc_probe.py [GB=60] [rounds=5]"""
+usage: python tools/archive/alloc_probe.py [GB=60] [rounds=5]"""
 import ctypes as C
 import math
 import os

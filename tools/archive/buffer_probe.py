@@ -1,6 +1,6 @@
 """measurement aid (GPU box): DeviceRolloutBuffer at full size -- allocation time, ms per step of an episode inserted as one span + the
 episode-ending step, and as 25 insert_step calls (a policy in the loop: step kernel + the masks of the runner's insert).
-usage: python tools/buffer_probe.py [config=cfg3]      (FMARL_RING_SPREAD=0: plain allocations)"""
+usage: python tools/archive/buffer_probe.py [config=cfg3]      (FMARL_RING_SPREAD=0: plain allocations)"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """measurement aid (GPU box): step-kernel time against envs per workgroup (FmarlConfig.envs_per_workgroup).
-usage: python tools/epb_sweep.py <config> <epb> [<epb> ...]      (0 = the library's choice)"""
+usage: python tools/archive/epb_sweep.py <config> <epb> [<epb> ...]      (0 = the library's choice)"""
 import os
 import sys
 

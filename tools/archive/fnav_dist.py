@@ -1,5 +1,5 @@
 """measurement aid (GPU box): per-launch times of fairnav_kernel<true> over 100 steps from a lockstep start (hipEvents per launch):
-launches in which no env ends, launches with a reset pass, the launch that ends the episode.  usage: python tools/fnav_dist.py"""
+launches in which no env ends, launches with a reset pass, the launch that ends the episode.  usage: python tools/archive/fnav_dist.py"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, '/root/repo')

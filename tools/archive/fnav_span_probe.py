@@ -1,6 +1,6 @@
 """measurement aid (GPU box): nav_fairassign_fairrew_formation_graph, 65 536 x 3 -- a launch per step against fmarl_step_span
 (fairnav_span_kernel: all steps of the tape in one launch), into one output set and into time slots; also checks that both leave
-the same state.  usage: python tools/fnav_span_probe.py [steps=100] [min_dist_thresh]"""
+the same state.  usage: python tools/archive/fnav_span_probe.py [steps=100] [min_dist_thresh]"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """measurement aid (GPU box): fairnav_kernel<true> launch times once the envs' episodes have drifted apart (a threshold at which
-goals are reached, so that episodes end at all phases): usage python tools/fnav_steady.py [min_dist_thresh] [steps]"""
+goals are reached, so that episodes end at all phases): usage python tools/archive/fnav_steady.py [min_dist_thresh] [steps]"""
 import os
 import sys
 

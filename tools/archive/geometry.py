@@ -1,5 +1,5 @@
 """measurement aid (GPU box): workgroups / threads / LDS bytes / envs per workgroup of every bench config (fmarl_launch_geometry) and how
-many of those workgroups a CU holds by LDS -- 161 280 usable bytes is what was measured (profiles/r3_notes.md).  usage: python tools/geometry.py"""
+many of those workgroups a CU holds by LDS -- 161 280 usable bytes is what was measured (profiles/archive/r3_notes.md).  usage: python tools/archive/geometry.py"""
 import sys; sys.path.insert(0,'/root/repo')
 import bench, fair_marl_amd as fm
 for name in ('cfg3','n10','cfg2','cfg4','fnav'):

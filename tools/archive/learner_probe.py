@@ -1,6 +1,6 @@
 """measurement aid (GPU box): the learner-side kernels of the rollout buffer (fmarl_compute_returns, fmarl_advantages,
 fmarl_minibatch_gather) timed with HIP events on the current stream against their algorithmic bytes.
-usage: python tools/learner_probe.py [n_envs] [num_agents]   (navigation_graph shapes, T = 25)"""
+usage: python tools/archive/learner_probe.py [n_envs] [num_agents]   (navigation_graph shapes, T = 25)"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """measurement aid (GPU box): n10 (10 agents x 65 536 envs) one launch per step and as spans against envs per workgroup, fresh engines
-with the placement probe on, two rounds.  usage: python tools/n10_epb.py"""
+with the placement probe on, two rounds.  usage: python tools/archive/n10_epb.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, '/root/repo')

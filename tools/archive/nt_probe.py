@@ -1,6 +1,6 @@
 """measurement aid (GPU box): plain against non-temporal 16-byte stores in the pure store streams (fmarl_store_stream shapes 1 / 2 against
 3 / 4), scattered chunk order, one step's byte count of cfg 3.  Round 4: non-temporal is 5-10 % SLOWER in every shape; the emission keeps
-plain stores.  usage: python tools/nt_probe.py"""
+plain stores.  usage: python tools/archive/nt_probe.py"""
 import ctypes as C, sys, torch, math
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

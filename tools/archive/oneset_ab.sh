@@ -1,6 +1,6 @@
 #!/bin/bash
 # measurement aid (GPU box): one launch per step into ONE output set (the engine's own node_obs / adj) -- plain allocations
-# (FMARL_RING_SPREAD=0) against arrays made of hipMemCreate pieces (the default).  usage: bash tools/oneset_ab.sh [config=cfg3]
+# (FMARL_RING_SPREAD=0) against arrays made of hipMemCreate pieces (the default).  usage: bash tools/archive/oneset_ab.sh [config=cfg3]
 cd "$(dirname "$0")/.."
 for r in 1 2; do for sp in 0 1; do
   echo -n "pieces=$sp: "; FMARL_RING_SPREAD=$sp python bench.py --config ${1:-cfg3} --launch step --slots same --steps 100 --warmup 25 --no-cpu-baseline --no-secondary 2>/dev/null \

@@ -6,7 +6,7 @@
 //   3 XCD regions, golden the same with the golden-section order inside the eighth
 //   4 bit reversal        f(b) = bit-reversed b (n a power of two)
 // and with `persist` workgroups that live for the whole launch (0 = one workgroup per chunk).
-// build + run on the box: hipcc -O3 --offload-arch=gfx950 tools/order_probe.hip -o /tmp/order && /tmp/order
+// build + run on the box: hipcc -O3 --offload-arch=gfx950 tools/archive/order_probe.hip -o /tmp/order && /tmp/order
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

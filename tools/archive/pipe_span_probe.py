@@ -1,4 +1,4 @@
-"""measurement aid (GPU box): k sub-batches on k streams, each running its steps as spans.  usage: python tools/pipe_span_probe.py <config> <k>"""
+"""measurement aid (GPU box): k sub-batches on k streams, each running its steps as spans.  usage: python tools/archive/pipe_span_probe.py <config> <k>"""
 import os
 import sys
 import time

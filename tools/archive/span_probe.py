@@ -1,5 +1,5 @@
 """measurement aid (GPU box): fmarl_step_span (one launch per run of steps between episode ends) against one launch per step.
-usage: python tools/span_probe.py <config> [episodes]"""
+usage: python tools/archive/span_probe.py <config> [episodes]"""
 import os
 import sys
 import time

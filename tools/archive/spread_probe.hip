@@ -2,7 +2,7 @@
 // One 160 GB buffer; a launch writes `bytes` (one step of cfg 3: 8.3 GB) as pieces of `piece` bytes, piece k at offset k * stride * piece:
 // stride 1 = one contiguous 8.3 GB region (a time slot), stride 19 = the same bytes spread over the whole buffer (what a slot would
 // be if the slots of a ring were interleaved piece by piece).  Workgroups take their pieces in scattered order, a wave streams its
-// quarter of a piece (1 KiB per store instruction).  build + run on the box: hipcc -O3 --offload-arch=gfx950 tools/spread_probe.hip -o /tmp/spread && /tmp/spread
+// quarter of a piece (1 KiB per store instruction).  build + run on the box: hipcc -O3 --offload-arch=gfx950 tools/archive/spread_probe.hip -o /tmp/spread && /tmp/spread
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
