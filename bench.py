@@ -214,8 +214,8 @@ EAGER_EPB = {}   # one launch per step: the library's choice everywhere (tools/r
 # has ended, so the LAST run's gather of a timed region is exposed in full -- short runs keep it short, long runs save launches
 GATHER_SPAN_STEPS = 5   # (and the last runs of a region halve down to single steps: run_spans)
 # N > 1 without --span-steps: the run length is CHOSEN during the warm-up -- the first 8-GPU run cannot be repeated with another constant.
-# For every candidate a few runs with the exchange on; kept: the shortest length whose gather waits stall the rollout by less than
-# SPAN_TUNE_STALL of its time on every rank (short runs expose little at the end of a region; long runs save launch heads and tails).
+# For every candidate a few runs with the exchange on; kept: the fastest length (time per step, waits included, max over ranks) among
+# those whose gather waits stall the rollout by less than SPAN_TUNE_STALL of its time (pick_span_length).
 SPAN_TUNE_CANDIDATES = (3, 5, 8, 12)
 SPAN_TUNE_RUNS = 4
 SPAN_TUNE_STALL = 0.02
@@ -507,6 +507,15 @@ def span_schedule(first, count, episode_length, span_steps, taper):
         runs.append(k)
         t += k
     return runs
+
+
+def pick_span_length(table):
+    """Among the run lengths whose gather waits (max over ranks; of the compute stream or of the host) stay under 2 % of the time per step:
+    the one with the lowest measured time per step, ties to the shorter; if every length stalls: the lowest time per step of all.
+    (Long runs save launch heads and tails, short runs keep the exposed gathers small: the measured time per step, waits included,
+    is what the run is after -- the stall share only decides who is admissible.)"""
+    ok = [r for r in table if r['stall_frac'] < SPAN_TUNE_STALL] or table
+    return min(ok, key=lambda r: (r['ms_per_step'], r['span_steps']))
 
 
 def launch_plan(launch, pipeline, scenario_name, gather, span_steps, episode_length):
@@ -863,12 +872,9 @@ def main():
             table.append({'span_steps': L, 'ms_per_step': ms, 'stream_stalled_per_step': stream_ms, 'host_blocked_per_step': host_ms,
                           'stall_frac': max(stream_ms, host_ms) / ms})
             first += n_tune
-        ok = [r for r in table if r['stall_frac'] < SPAN_TUNE_STALL]
-        pick = min(ok, key=lambda r: r['span_steps']) if ok else min(table, key=lambda r: (r['stall_frac'], -r['span_steps']))
+        pick = pick_span_length(table)
         span_len[0] = span_steps = pick['span_steps']
-        span_tuning = {'candidates': table, 'chosen': span_steps, 'runs_per_candidate': SPAN_TUNE_RUNS,
-                       'rule': 'the shortest run length whose gather waits (max over ranks, of the compute stream / of the host) stay under %.0f %% of '
-                               'the time per step; none: the one with the smallest share' % (100 * SPAN_TUNE_STALL)}
+        span_tuning = {'candidates': table, 'chosen': span_steps, 'runs_per_candidate': SPAN_TUNE_RUNS, 'rule': pick_span_length.__doc__}
         pad = (W - first) % ep      # back to the episode phase the region would have started at without the tuning pass
         run_spans(first, pad, taper=False)
         first += pad

@@ -193,12 +193,10 @@ __device__ __forceinline__ void flush_rows(const Params &p, char *lds, const flo
     __builtin_amdgcn_wave_barrier();
 }
 
-// adj for any E: a lane owns one 16-byte aligned chunk of the workgroup's region (4 entries, possibly of two rows
-// or envs), computes |x_a - x_b| for each and stores 16 bytes; the ragged ends and chunks that touch an env which
-// keeps its previous matrix fall back to 4-byte stores.  Shared by the three scenarios (same LDS tables).
-// Fused processAdj count (onpolicy/algorithms/utils/gnn.py:307-326): while a lane walks its chunks
-// of the adj region it counts the entries with 0 < d < max_edge_dist; the chunks of one env are consecutive, so the lane
-// hands its subtotal to the env's LDS counter only when it moves on to the next env.
+// Fused processAdj count (onpolicy/algorithms/utils/gnn.py:307-326): while a lane walks its entries of the adj
+// region (emit_adj: 16-byte chunks of four entries when E % 4 == 0, else emit_adj_generic's flat dword walk) it counts those with
+// 0 < d < max_edge_dist; a lane's entries of one env are consecutive, so it hands its subtotal to the env's LDS counter only when it
+// moves on to the next env.  Shared by the three scenarios (same LDS tables).
 struct EdgeCount {   // plain values only (no reference to the kernel's Params: that would pin the struct in scratch memory)
     const char *slots;   // counter of env 0 of the workgroup; the others follow at a stride of lds_env_bytes
     int stride, cur, cnt;
@@ -221,6 +219,8 @@ __device__ __forceinline__ void emit_sync(uint32_t nthr) {
 // The caller's `nthr` threads (index `thr`) emit the envs [el_begin, el_end) of the workgroup.
 // MODE 0: no policy-edge count, 1: count, 2: decided at run time (`count`; one copy of the loop -- for kernels that inline
 // this more than once and would run out of registers with two copies each, i.e. fairnav_kernel)
+// Contract: `nthr` is a multiple of 64 and >= 64 (whole waves: `thr >> 6` is the caller's wave index, uniform per wave) -- callers
+// pass 64 (one wave that owns its envs), 192 (the emission waves of a small batch) or the workgroup size.
 // Any E, any alignment (round 4): every wave takes a contiguous share of the envs -- their matrices are one contiguous run of
 // floats in memory -- and walks it as a flat index space, 64 entries per store instruction (one dword per lane, 256 contiguous
 // bytes: plain stores of that shape run at the full store rate).  (env, a, b) of a lane's first entry come from two divisions,

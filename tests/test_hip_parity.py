@@ -345,8 +345,7 @@ def test_bench_multi_rank_rehearsal(world, extra):
         else:   # the run length was chosen during the warm-up (all candidates tried, the rule applied to the table in the line)
             st = m['span_tuning']
             assert [r['span_steps'] for r in st['candidates']] == list(bench.SPAN_TUNE_CANDIDATES) and st['chosen'] == L
-            ok = [r['span_steps'] for r in st['candidates'] if r['stall_frac'] < bench.SPAN_TUNE_STALL]
-            assert L == (min(ok) if ok else min(st['candidates'], key=lambda r: (r['stall_frac'], -r['span_steps']))['span_steps'])
+            assert L == bench.pick_span_length(st['candidates'])['span_steps']
             assert all(r['ms_per_step'] > 0 and r['stall_frac'] >= 0 for r in st['candidates'])
         runs = bench.span_schedule(5, 30, 25, L, True)
         assert sum(runs) == 30 and runs[-1] == 1

@@ -338,6 +338,12 @@ def test_bench_launch_plan_is_the_same_for_every_number_of_gpus():
     assert bench.span_schedule(55, 30, 25, 5, True) == [5, 5, 5, 5, 5, 3, 1, 1] and bench.span_schedule(55, 30, 25, 5, False) == [5] * 6
     assert bench.span_schedule(5, 30, 25, 25, True) == [20, 5, 3, 1, 1] and bench.span_schedule(0, 50, 25, 25, False) == [25, 25]
     assert bench.span_schedule(5, 30, 25, 12, True) == [12, 8, 5, 3, 1, 1] and bench.span_schedule(7, 0, 25, 5, True) == []
+    # the run length of an N > 1 run: the fastest admissible candidate (gather waits under 2 % of the time per step), else the fastest
+    rows = [dict(span_steps=3, ms_per_step=1.40, stall_frac=0.0), dict(span_steps=5, ms_per_step=1.31, stall_frac=0.01),
+            dict(span_steps=8, ms_per_step=1.28, stall_frac=0.05), dict(span_steps=12, ms_per_step=1.26, stall_frac=0.30)]
+    assert bench.pick_span_length(rows)['span_steps'] == 5
+    assert bench.pick_span_length([dict(r, stall_frac=0.5) for r in rows])['span_steps'] == 12
+    assert bench.pick_span_length([dict(r, stall_frac=0.0) for r in rows])['span_steps'] == 12
     for L in bench.SPAN_TUNE_CANDIDATES:
         for first in (0, 5, 24):
             runs = bench.span_schedule(first, 30, 25, L, True)
