@@ -190,9 +190,7 @@ def moved_bytes(cfg, agents, steps):
     (the per-step formula counts them every step)."""
     per_step = algorithmic_bytes(cfg)
     C = 2 * (cfg.num_landmarks + cfg.num_obstacles) + 6 * cfg.num_walls
-    once = 4.0 * (2 * 12 + C / cfg.N)
-    if cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph':
-        once = 4.0 * C / cfg.N   # (its span keeps the static entities in LDS; the state goes through global memory every step)
+    once = 4.0 * (2 * 12 + C / cfg.N)   # (all three scenarios' spans since round 5: nav_fairassign_fairrew_formation_graph carries its state too)
     return agents * ((per_step - once) * steps + once)
 
 
@@ -223,6 +221,12 @@ SPAN_TUNE_STALL = 0.02
 # smallest footprint first: what an entry measures then does not depend on what ran before it (profiles/r4_notes.md section 18: behind
 # the headline's 205 GB ring `n10 eager` read 0.206-0.273 ms per step, in a fresh process 0.2112-0.2119)
 SECONDARY_CHILD_ORDER = ('cfg2', 'fnav', 'cfg4', 'n10')
+
+
+def _small_batch(cfg, eng):
+    """navigation_graph batches whose workgroups hold all their agents in one wave and emit rows of generic shape run the small-batch
+    kernels (fmarl_step.hip step_body SMALL: step_small_kernel / step_span_small_kernel) -- BASELINE config 2."""
+    return cfg.scenario_name == 'navigation_graph' and eng.envs_per_workgroup * cfg.N <= 64 and (cfg.E * cfg.node_feat) % 4 != 0
 
 
 def _use_ring(cfg, n_envs, slots, device):
@@ -323,15 +327,16 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     k_step = float(np.sum(kernel_ms)) / (c1[0] - c0[0])       # step-kernel time per step (a span launch covers many)
     per_step = launch_bytes(cfg, n * cfg.N, c0, c1)
     folded = c1[1] - c0[1] > 0
-    kern = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
+    small = _small_batch(cfg, eng)
+    kern = KERNEL_NAMES.get(cfg.scenario_name, ('step_small_kernel' if small else 'step_kernel') + (' / step_end_kernel' if folded else ''))
     if rmode == 'span':
         kern = {'fair_graph_formation': 'formation_span_kernel + formation_kernel<true>',
-                'nav_fairassign_fairrew_formation_graph': 'fairnav_span_kernel'}.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel')
+                'nav_fairassign_fairrew_formation_graph': 'fairnav_span_kernel'}.get(cfg.scenario_name, ('step_span_small_kernel' if small else 'step_span_kernel') + ' + step_end_kernel')
     span_text = 'fmarl_step_span: one launch per run of steps between episode ends%s (%d envs per workgroup), the episode-ending step a launch of its own' \
                 % (' and at most %d steps' % run_len if run_len else '', eng.envs_per_workgroup)
     if cfg.scenario_name == 'nav_fairassign_fairrew_formation_graph':
         span_text = ('fmarl_step_span: the %d steps of the tape as ONE launch (%d envs per workgroup); episodes end env by env and the step '
-                     'resets them itself, the state goes through L2 between the steps' % (ep, eng.envs_per_workgroup))
+                     'resets them itself; the state stays in registers between the steps (three waves per workgroup)' % (ep, eng.envs_per_workgroup))
     steps_per_launch = (c1[0] - c0[0]) / max(1, len(kernel_ms))
     epw = eng.envs_per_workgroup
     ring_bytes = ring.nbytes if ring is not None else 0
@@ -1008,12 +1013,12 @@ def main():
             bytes_per_launch = agents * algorithmic_bytes(cfg) * steps_per_launch
             bytes_moved = moved_bytes(cfg, agents, steps_per_launch)
             kernel_name = {'fair_graph_formation': 'formation_span_kernel',
-                           'nav_fairassign_fairrew_formation_graph': 'fairnav_span_kernel'}.get(cfg.scenario_name, 'step_span_kernel')
+                           'nav_fairassign_fairrew_formation_graph': 'fairnav_span_kernel'}.get(cfg.scenario_name, 'step_span_small_kernel' if _small_batch(cfg, eng) else 'step_span_kernel')
         else:
             k_avg_ms = float(kernel_ms.mean()) if kernel_ms.size else float('nan')
             steps_per_launch = 1.0
             bytes_per_launch = bytes_per_step / sub   # a launch steps one sub-batch
-            kernel_name = KERNEL_NAMES.get(cfg.scenario_name, 'step_kernel / step_end_kernel' if folded else 'step_kernel')
+            kernel_name = KERNEL_NAMES.get(cfg.scenario_name, ('step_small_kernel' if _small_batch(cfg, eng) else 'step_kernel') + (' / step_end_kernel' if folded else ''))
         achieved = bytes_per_launch / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tkey = '%s/%s%s' % (args.config, launch, '-ring' if slots == 'ring' else '')
@@ -1029,7 +1034,7 @@ def main():
             'span': 'fmarl_step_span: runs of steps (up to the episode end%s) as ONE launch each in which every workgroup walks its own envs through '
                     'time (%d envs per workgroup; %s), the step that ends an episode %s: %d launches for the %d timed steps'
                     % ('' if span_steps >= ep else ', at most %d steps' % span_steps, eng.envs_per_workgroup,
-                       'state through L2, static entities in LDS between the steps' if fnav_sc else 'state in registers, static entities in LDS between the steps',
+                       'state in registers, static entities in LDS between the steps',
                        'inside the span (this scenario resets its ended envs in the step)' if fnav_sc else 'as a launch of its own', len(kernel_ms), K),
             'step': ('%d sub-batches of %d envs on their own streams, one fmarl_step call per sub-batch and step'
                      % (args.pipeline, n_envs // args.pipeline) if pipe is not None else 'one fmarl_step call per step'),

@@ -263,7 +263,7 @@ __device__ __forceinline__ void formation_row(const Params &p, char *lds, int el
 // (three times the write requests for the same bytes).  The window is the wave's part of the second LDS region: its envs'
 // tables there are dead by now, and it is private to the wave (wave-local ordering).  The frame starts at the previous
 // 64-byte boundary of gdst (rows are 16-byte aligned, so the offset is whole chunks): lane quads then write whole blocks.
-__device__ __forceinline__ void formation_flush_rows(const Params &p, char *lds, float4 c0, float4 c1, float4 c2, uint32_t nrows,
+__device__ __forceinline__ void formation_flush_rows(const Params &p, char *lds, const float4 &c0, const float4 &c1, const float4 &c2, uint32_t nrows,
                                                      float4 *gdst) {
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *buf = (float4 *)(lds + p.lds_stage + wave * p.stage_wave_bytes);
@@ -273,7 +273,7 @@ __device__ __forceinline__ void formation_flush_rows(const Params &p, char *lds,
     float4 *gal = gdst - shift;
     // all LDS reads first, then the stores (at most 3 chunks per lane: 3 * 63 + 3 <= 192)
     const bool in0 = lane >= shift && lane < end, in1 = lane + 64 < end, in2 = lane + 128 < end;
-    float4 v0 = make_float4(0, 0, 0, 0), v1 = v0, v2 = v0;
+    float4 v0, v1, v2;   // (each only read under the predicate it was loaded under: no initialisers -- they were twelve moves per window)
     if (in0) v0 = buf[lane];
     if (in1) v1 = buf[lane + 64];
     if (in2) v2 = buf[lane + 128];
@@ -297,7 +297,7 @@ __device__ __forceinline__ void formation_emit_rows(const Params &p, const Fmarl
         const uint32_t R = p.f_rows;
         for (uint32_t w0 = 0; w0 < total; w0 += R) {
             const uint32_t nrows = min(R, total - w0);
-            float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0;
+            float4 c0, c1, c2;   // (lanes beyond nrows never write theirs to the window)
             if ((uint32_t)lane < nrows) formation_row(p, lds, el0w, w0 + lane, c0, c1, c2);
             formation_flush_rows(p, lds, c0, c1, c2, nrows, dst + (size_t)w0 * 3);
         }
@@ -316,7 +316,7 @@ __device__ __forceinline__ void formation_emit_rows(const Params &p, const Fmarl
 // is this step's value for j < split -- the path length pd[j] while agent j is still under way (bit j of open), else
 // the value frozen at its arrival -- and the previous step's value (stale[j]) for j >= split.
 __device__ __forceinline__ void travelled_stats(const double *pd, const double *stale, uint32_t open, int n, int split,
-                                                double &mean, double &sd) {
+                                                double &mean, double &sd, double &m2) {
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += (j < split && ((open >> j) & 1u)) ? pd[j] : stale[j];
     mean = s / n;
@@ -325,9 +325,9 @@ __device__ __forceinline__ void travelled_stats(const double *pd, const double *
         const double d = ((j < split && ((open >> j) & 1u)) ? pd[j] : stale[j]) - mean;
         q += d * d;
     }
+    m2 = q;
     sd = sqrt_pos(q / n);
 }
-
 // What one agent's thread carries from one step of a span to the next (formation_span_kernel): everything a step reads at its
 // head.  `carry` bit 0 = this step's state arrives here (left by the previous step of the span; the static entities are still in
 // the envs' LDS tables) -- nothing is loaded but the action; bit 1 = the new state stays here instead of going to global memory.
@@ -611,9 +611,10 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             const bool open = Tr_old == -1.0;
             const double Dg_new = open ? pd : Dg_old;
             const double delta = dist2(x, t.slot_new()[t.g_new()[i]]);   // ff:665
-            double fairness, m, sd;   // ff:623-628, same stale/fresh rule as navigation_graph
-            if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, N, N, m, sd);
-            else travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i, m, sd);
+            double fairness, m, sd, m2 = 0.0;   // ff:623-628, same stale/fresh rule as navigation_graph
+            const bool base = Dg_old != -1.0;   // (m, m2) describe the vector the info statistics differ from in this agent's entry
+            if (!base) mixed_stats(s_stat, s_stat, N, N, m, sd);
+            else travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i, m, sd, m2);
             fairness = ratio_out(m, sd + 0.0001);
             int ag_hits = 0;
             for (int j = 0; j < N; ++j)
@@ -646,8 +647,11 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             if (o.done) o.done[g] = step >= p.episode_length;
             FMARL_TICK(9);   // state stores
             if (o.info) {   // ff:477-499
-                double dm, ds;
-                travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i + 1, dm, ds);
+                // ff:477-499: the same vector with this agent's own entry fresh -- one entry replaced (its path length for the frozen
+                // value, if it is still under way), else unchanged
+                double dm = m, ds = sd, unused;
+                if (!base) travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i + 1, dm, ds, unused);
+                else if (open) replaced_entry_stats(m, m2, N, Dg_old, pd, dm, ds);
                 const size_t plane = (size_t)p.n_envs * N;
                 float *inf = o.info + g;
                 inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left;

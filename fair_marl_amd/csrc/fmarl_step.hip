@@ -172,7 +172,7 @@ __device__ __forceinline__ void flush_rows(const Params &p, char *lds, const flo
         const float4 *b4 = (const float4 *)buf + first4 + lane;
         float4 *g4 = (float4 *)gal + first4 + lane;
         const uint32_t nk = last4 > first4 + lane ? last4 - first4 - lane : 0;   // chunks j with 64 j < nk are this lane's
-        float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+        float4 c0, c1, c2, c3;   // (each only read under the predicate it was loaded under: no initialisers -- sixteen moves per window)
         if (nk > 0) c0 = b4[0];
         if (K > 1 && nk > 64) c1 = b4[64];
         if (K > 2 && nk > 128) c2 = b4[128];
@@ -437,6 +437,29 @@ __device__ __forceinline__ void mixed_stats(const double *fresh, const double *s
         q += d * d;
     }
     sd = sqrt(q / n);
+}
+
+// mixed_stats that also hands out M2 = the sum of squared deviations from the mean
+__device__ __forceinline__ void mixed_stats_m2(const double *fresh, const double *stale, int n, int split, double &mean, double &sd, double &m2) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += (j < split) ? fresh[j] : stale[j];
+    mean = s / n;
+    double q = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double d = ((j < split) ? fresh[j] : stale[j]) - mean;
+        q += d * d;
+    }
+    m2 = q;
+    sd = sqrt(q / n);
+}
+// The statistics of a vector that differs from one with known (mean, M2) in ONE entry, `was` -> `now` (Welford's update for a
+// replaced sample).  For OUTPUT-only statistics -- the info planes' mean / std after the agent's own entry went from its stale to its
+// fresh value: float32 outputs compared at 1e-5 -- instead of two more passes over the vector (float64: error ~1e-15).
+__device__ __forceinline__ void replaced_entry_stats(double mean, double m2, int n, double was, double now, double &mean2, double &sd2) {
+    const double d = now - was;
+    mean2 = mean + d * rcp_small((double)n);
+    const double q = m2 + d * ((now - mean2) + (was - mean));
+    sd2 = sqrt_pos(fmax(q, 0.0) * rcp_small((double)n));
 }
 
 // First half of World.step (core.py:250-274) for agent i of one env: action force (core.py:277-298 with the
@@ -825,8 +848,8 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
 
         // fairness scalar of obs_i / reward_i (:764-769, :849-854): p_dist statistics while this
         // agent's dists_to_goal is still -1, otherwise the statistics info_{i-1} left behind.
-        double fairness, m, sd;
-        bool info_stats_done = false;
+        double fairness, m, sd, base_m2 = 0.0;
+        bool info_stats_done = false, base_stats = false;   // base_stats: (m, base_m2) describe the vector the info statistics differ from in entry i
         if (FMARL_SKIP(p, 2)) { m = 1.0; sd = 1.0; }
         else if (p.scan_stats) { m = f_m; sd = f_sd; }
         else if (SMALL && o.info) {   // the three statistics of this step in one pass (a small batch waits for this lane's chain)
@@ -836,7 +859,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
             info_stats_done = true;
         }
         else if (Dg_old == -1.0) mixed_stats(s_stat, s_stat, p.N, p.N, m, sd);
-        else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd);
+        else { mixed_stats_m2(s_stat + 2 * p.N, s_stat + p.N, p.N, i, m, sd, base_m2); base_stats = true; }
         fairness = ratio_out(m, sd + 0.0001);
 
         // collisions (:701-705, :650-684)
@@ -899,7 +922,9 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
             // info_callback (:577-647): statistics after this agent's own update (entries <= i fresh).
             // Field-major records: info[k][env][agent], every store is lane-contiguous.
             if (!p.scan_stats && !info_stats_done) {
-                mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
+                // (:600-602) the fairness scalar's vector with this agent's own entry fresh: one entry replaced
+                if (base_stats) replaced_entry_stats(m, base_m2, p.N, Dg_old, Dg_new, dm, ds);
+                else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
                 mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
             }
             const size_t plane = (size_t)p.n_envs * p.N;

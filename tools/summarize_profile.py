@@ -27,10 +27,16 @@ def one(pattern):
     return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)   # gpurun merges: older runs stay around
 
 
+def is_kernel(full_name, k):
+    """`full_name`: a demangled kernel name of the trace; `k`: 'step_kernel', 'formation_kernel<true>' (any further template arguments match)."""
+    name = full_name.split('(')[0].split('::')[-1].strip()
+    return name.split('<')[0] == k.split('<')[0] and name.startswith(k.rstrip('>'))
+
+
 def counter_mean(path, kernel, counter):
     names = kernel if isinstance(kernel, tuple) else (kernel,)
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
-            if any(k in r['Kernel_Name'] for k in names) and r['Counter_Name'] == counter]
+            if any(is_kernel(r['Kernel_Name'], k) for k in names) and r['Counter_Name'] == counter]
     return float(np.mean(vals)), float(np.max(vals)), len(vals)
 
 
@@ -38,10 +44,11 @@ bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlin
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % stem))
 mode = bench['config'].get('launch_mode', 'step')
+small = 'small' in bench['roofline'].get('kernel', '')   # (small batches of navigation_graph run the step_small / step_span_small kernels)
 if mode == 'span':   # the dominant kernel is the span kernel (a launch = a run of steps)
-    kname = {'cfg4': 'formation_span_kernel', 'fnav': 'fairnav_span_kernel'}.get(cfg, 'step_span_kernel')
+    kname = {'cfg4': 'formation_span_kernel', 'fnav': 'fairnav_span_kernel'}.get(cfg, 'step_span_small_kernel' if small else 'step_span_kernel')
 else:
-    kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
+    kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_small_kernel' if small else 'step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
 w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), kname, 'WRITE_SIZE')
 traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
@@ -70,7 +77,7 @@ with open(out, 'w') as f:
                                                        float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
     rl = bench['roofline']
     knames = kname if isinstance(kname, tuple) else (kname,)
-    krows = [r for r in rows if any(r['Name'].split('(')[0].split('::')[-1] == k for k in knames)]
+    krows = [r for r in rows if any(is_kernel(r['Name'], k) for k in knames)]
     calls = sum(int(r['Calls']) for r in krows)
     krow = dict(AverageNs=sum(float(r['TotalDurationNs']) for r in krows) / calls, Calls=calls)
     kname = ' + '.join(knames)
@@ -84,7 +91,7 @@ with open(out, 'w') as f:
         # per-launch durations of the span kernel from the kernel trace (a launch = a run of steps; --stats averages the
         # warm-up's launches in as well)
         def span_launches(pattern):
-            rows_ = [r for r in csv.DictReader(open(one(pattern))) if knames[0] in r['Kernel_Name']]
+            rows_ = [r for r in csv.DictReader(open(one(pattern))) if is_kernel(r['Kernel_Name'], knames[0])]
             return [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows_]
         d = span_launches('trace/*/*kernel_trace.csv')
         f.write('\nSpan launches of the traced run (ms each, in order; the bench line above reports %.1f steps per launch and measured '
