@@ -88,7 +88,7 @@ struct Params {
     int lds_stage, stage_wave_bytes;   // generic shapes: per-wave LDS window the rows go through (offset from the LDS base, bytes per wave)
     int stat_stride;   // statistics block of env el: LDS base + lds_stat + el * stat_stride (lds_env_bytes, or 5 N doubles when the blocks share the emission windows' region)
     // formation scenario: extra per-env LDS tables (byte offsets) and state
-    int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words;
+    int f_slot_new, f_slot_old, f_g, f_masks, f_theta, f_words, f_slotf;
     int lds2_bytes, f_rows;   // second LDS region, lds_stage + el * lds2_bytes: tables dead once the emission starts (formation: lds_stat,
                               // f_slot_old, f_theta, f_words; fairnav: lds_stat, n_D, n_minprox, n_occ, n_match, n_words) / formation: rows per window
     double2 *slot_pos;

@@ -187,6 +187,8 @@ struct FormLds {
     __device__ double *wall() const { return (double *)(base + p.lds_wall); }
     __device__ int *flag() const { return (int *)(base + p.lds_flag); }
     __device__ double2 *slot_new() const { return (double2 *)(base + p.f_slot_new); }
+    __device__ float2 *slotf() const { return (float2 *)(base + p.f_slotf); }       // (float)slot_new: what the node rows read
+    __device__ const float4 *wallf() const { return (const float4 *)(base + p.lds_wallf); }   // (e0, axis + w/2, e1, axis - w/2) in f32
     __device__ double2 *slot_old() const { return (double2 *)(dead + p.f_slot_old); }
     // small per-agent indices as bytes (N <= 32): slot of the matching on the current / previous slots, nearest slot
     // within thr (-1: none), and at [3 N] the nearest previous slot of agent 0
@@ -202,13 +204,12 @@ struct FormLds {
     __device__ uint32_t *openmask() const { return (uint32_t *)(dead + p.lds_stat + 2 * p.N * 8); }   // bit j: agent j has not arrived yet
     __device__ bool skip() const { return *flag() != 0; }
 
-    // goal of agent entity e as seen in the graph row of ego i (ff:916-943)
-    __device__ double2 graph_goal(uint32_t i, uint32_t e) const {
+    // goal of agent entity e as seen in the graph row of ego i (ff:916-943), as the float32 rounding the row starts from
+    __device__ float2 graph_goal(uint32_t i, uint32_t e) const {
         const int nr = near_new()[e];
-        if (nr >= 0) return slot_new()[nr];
-        if ((masks()[3 * i] >> e) & 1) return slot_new()[g_new()[i]];
-        const float2 pf = posf()[e];   // (its own position: the float32 rounding the row starts from)
-        return make_double2((double)pf.x, (double)pf.y);
+        if (nr >= 0) return slotf()[nr];
+        if ((masks()[3 * i] >> e) & 1) return slotf()[g_new()[i]];
+        return posf()[e];   // (its own position)
     }
 };
 
@@ -244,12 +245,11 @@ __device__ __forceinline__ void formation_row(const Params &p, char *lds, int el
     if (e < N) {
         const float2 ve = te.velf()[e];
         vx = ve.x; vy = ve.y;
-        const double2 gl = te.graph_goal(a, e);
-        gx = (float)gl.x - pi.x; gy = (float)gl.y - pi.y;
+        const float2 gl = te.graph_goal(a, e);
+        gx = gl.x - pi.x; gy = gl.y - pi.y;
         fl = (float)((te.masks()[3 * a + 1] >> e) & 1);
     } else if (e >= first_wall) {
-        const double *wl = te.wall() + (e - first_wall) * 4;   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
-        const float4 wc = make_float4((float)wl[1], (float)(wl[0] + kWallWidth / 2), (float)wl[2], (float)(wl[0] - kWallWidth / 2));
+        const float4 wc = te.wallf()[e - first_wall];   // corners (e0, axis + w/2), (e1, axis - w/2): ff:963-964
         t7 = wc.x - pi.x; t8 = wc.y - pi.y; t9 = wc.z - pi.x; t10 = wc.w - pi.y;
     }
     const float type = e < N ? 0.f : (e < N + p.L ? 1.f : (e < first_wall ? 2.f : 3.f));
@@ -458,6 +458,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             P = t.slot_old()[i];
         }
         t.slot_new()[i] = P;
+        t.slotf()[i] = make_float2((float)P.x, (float)P.y);
     }
     wave_sync();
     FMARL_TICK(2);   // angle keys, ring test, slots
@@ -545,6 +546,12 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
         const uint32_t *sm = (const uint32_t *)tw.vdual();
         const uint32_t NEAR = sm[N], PN = sm[N + 1], NN = full & ~NEAR;
         const int near0 = *tw.near_old0();
+        // Ego 0 (whose observation reads the PREVIOUS slots), then the question whether the other egos depend on each other at all:
+        // once every near slot is in the mask (ego 0's row events put them there) and the mask is not full, nothing an ego a >= 1
+        // does changes it -- its near slot is in it already, and nobody can find every slot taken -- so every ego reads the same
+        // mask and the agent lanes evaluate theirs side by side below (`fast`: the common case; this serial walk was 5 % of a
+        // step on six lanes of a wave).  Otherwise the walk goes on one ego after the other, as before.
+        bool fast = false;
         for (int a = 0; a < N; ++a) {
             uint32_t code;
             if (STEP && a == 0) {
@@ -570,8 +577,23 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
                 }
             }
             m[3 * a] = mb; m[3 * a + 1] = mf; m[3 * a + 2] = code;
+            if (a == 0 && N >= 3 && (occ & PN) == PN && occ != full) { fast = true; break; }
         }
         tw.words()[2] = occ;
+        ((uint32_t *)tw.vdual())[N + 2] = fast ? 1u : 0u;   // (N >= 3: the table has N doubles = 2 N words)
+    }
+    wave_sync();
+    if (active && i >= 1 && N >= 3 && ((const uint32_t *)t.vdual())[N + 2] != 0 && !FMARL_SKIP(p, 128)) {
+        // ego i on the mask ego 0 left (branch_event's near / free-slot cases, then the closed form of its N row events)
+        const uint32_t *sm = (const uint32_t *)t.vdual();
+        const uint32_t occ1 = t.words()[2], NEAR = sm[N], NN = full & ~NEAR;
+        const int nri = t.near_new()[i], ga = t.g_new()[i];
+        const uint32_t smg = sm[ga];
+        const uint32_t later = smg ? ~((2u << __builtin_ctz(smg)) - 1u) : 0u;
+        uint32_t *m = t.masks();
+        m[3 * i] = NN;
+        m[3 * i + 1] = NEAR | (NN & (((occ1 >> ga) & 1u) ? full : later));
+        m[3 * i + 2] = nri >= 0 ? 1u : (2u | ((occ1 >> ga) & 1u));
     }
     wave_sync();
     FMARL_TICK(6);   // entity sets + walk
@@ -739,6 +761,7 @@ __global__ __launch_bounds__(kThreads) void formation_rebuild_kernel(Params p, F
         t.posf()[i] = pf; t.pos()[i] = make_double2((double)pf.x, (double)pf.y);
         t.velf()[i] = make_float2(__uint_as_float(r[2]), __uint_as_float(r[3]));
         t.slot_new()[i] = make_double2((double)__uint_as_float(r[4]), (double)__uint_as_float(r[5]));
+        t.slotf()[i] = make_float2(__uint_as_float(r[4]), __uint_as_float(r[5]));
         t.masks()[3 * i] = r[6]; t.masks()[3 * i + 1] = r[7]; t.masks()[3 * i + 2] = 0;
         t.near_new()[i] = (int8_t)(r[8] & 0xff); t.g_new()[i] = (int8_t)((r[8] >> 8) & 0xff);
         if (i == 0) *t.flag() = 0;
@@ -758,6 +781,7 @@ __global__ __launch_bounds__(kThreads) void formation_rebuild_kernel(Params p, F
         const float *qf = (const float *)q;
         double *wl = t.wall() + w * 4;   // (float)e0 / (float)e1 travel: the sender's corner words are their float32 roundings too
         wl[0] = axis; wl[1] = (double)qf[2]; wl[2] = (double)qf[3]; wl[3] = (double)qf[4];
+        ((float4 *)(t.base + p.lds_wallf))[w] = make_float4(qf[2], (float)(axis + kWallWidth / 2), qf[3], (float)(axis - kWallWidth / 2));
         t.pos()[N + LO + w] = qf[4] == 0.f ? make_double2(0.0, axis) : make_double2(axis, 0.0);
         t.posf()[N + LO + w] = qf[4] == 0.f ? make_float2(0.f, (float)axis) : make_float2((float)axis, 0.f);
     }

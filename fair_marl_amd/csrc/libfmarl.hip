@@ -364,12 +364,13 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     p.lds_cnt = p.lds_flag + 4;   // (formation: the occupancy word of the previous pass, dead once the emission starts)
     p.has_posf = 1;   // f32 copy of the entity positions: adj and the node rows start from it (all three scenarios)
     p.lds_posf = off;   off = align16(off + (p.has_posf ? p.E * 8 : 0));
-    p.has_wallf = !form;   // the formation kernel converts the corners from the f64 wall table (LDS budget: five workgroups per CU)
+    p.has_wallf = 1;   // f32 wall corner words (round 5: the formation scenario too -- its kernels run four workgroups per CU by registers, and at 24 envs per workgroup the LDS has 300 bytes per env to spare: the rows no longer convert corners and slots per row)
     p.lds_wallf = off;  off = align16(off + (p.has_wallf ? p.W * 16 : 0));
     p.lds_constf = off; off = align16(off + (!form && !fnav ? 16 : 0));
     int form_dead = 0;   // bytes per env in the second LDS region (formation, fairnav)
     if (form) {   // fmarl_formation.hip FormLds
         p.f_slot_new = off; off = align16(off + p.N * 16);
+        p.f_slotf = off;    off = align16(off + p.N * 8);
         p.f_g = off;        off = align16(off + 3 * p.N + 1);
         p.f_masks = off;    off = align16(off + (3 * p.N * 4 > p.N * 8 ? 3 * p.N * 4 : p.N * 8));
         // Tables nobody reads once the emission starts live in a region of their own behind all envs' blocks (offsets relative
