@@ -768,6 +768,15 @@ def alloc_time_slots(lib, device, shape, spread=None, zero=False, single=False):
     if (T >= 2 or single) and (spread or (spread is None and slot_bytes >= (64 << 20))):
         try:
             t = torch.as_tensor(_SpreadBlock(lib, device, shape, slot_bytes, T), device=device)
+            if os.environ.get('FMARL_RING_VERIFY') == '1':
+                # opt-in: a KERNEL's fill read back by a kernel (the fault that re-used address ranges showed -- include/fmarl.h
+                # fmarl_ring_alloc -- passed a fill / read-back through the copy engines and lost a kernel's writes); costs two
+                # passes over the array
+                t.fill_(1.25)
+                if bool((t != 1.25).any()):
+                    del t
+                    raise MemoryError('fmarl_ring_alloc: the array did not hold a kernel\'s fill (FMARL_RING_VERIFY)')
+                zero = True
             if zero:
                 t.zero_()
             return t, True

@@ -1895,6 +1895,13 @@ def test_time_slot_allocator_keeps_books_and_a_cap():
         torch.cuda.synchronize()
         a = read()
         assert a[1] - b[1] == (k + 1) * nbytes and a[3] - b[3] == k + 1
+    os.environ['FMARL_RING_VERIFY'] = '1'   # (the opt-in kernel fill / read-back of a fresh array)
+    try:
+        t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
+        assert interleaved and int((t != 0).sum()) == 0
+        del t
+    finally:
+        del os.environ['FMARL_RING_VERIFY']
     code = ("import torch, ctypes as C\nfrom fair_marl_amd import _lib\nfrom fair_marl_amd.engine import alloc_time_slots\n"
             "lib = _lib.load(); dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
             "shape = (2, 32768, 6, 16, 11)\n"
