@@ -1004,8 +1004,13 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
         // devices named here.  Should the runtime refuse the peers, the array is still this device's.
         std::vector<hipMemAccessDesc> acc(1);
         acc[0].location.type = hipMemLocationTypeDevice; acc[0].location.id = dev; acc[0].flags = hipMemAccessFlagsProtReadWrite;
+        // (opt-in, FMARL_RING_PEER_ACCESS=1: mapping a 200 GB ring into seven more devices' page tables is not something every
+        // process of a job should pay for, and no multi-GPU box has exercised it yet; without it a peer's read of a time slot goes
+        // through a staging copy on this device -- the trajectory exchange of bench.py never reads peers' slots)
         int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
+        const char *peer_env = getenv("FMARL_RING_PEER_ACCESS");
+        if (!(peer_env && peer_env[0] == '1')) ndev = 0;
+        else if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); ndev = 0; }
         for (int d = 0; d < ndev; ++d) {
             int can = 0;
             if (d != dev && hipDeviceCanAccessPeer(&can, d, dev) == hipSuccess && can) {

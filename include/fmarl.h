@@ -324,7 +324,8 @@ int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, i
  * again (round 4) or stays with the process and gets fresh pieces mapped into it (round 5: tried, same fault) -- an address that
  * has carried a mapping is never used again (tools/vmm_reuse_probe.py).  The reservations are
  * counted and capped (8 TiB per process; FMARL_RING_RESERVE_CAP_GB overrides): past the cap FMARL_EINVAL -- allocate plainly.
- * Access is granted to the allocating device and to every device that has peer access to it. */
+ * Access is granted to the allocating device; with FMARL_RING_PEER_ACCESS=1 in the environment also to every device that has peer
+ * access to it (hipMalloc memory is peer-accessible once peer access is enabled, an array of pieces only for the devices named). */
 int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **base, void **cookie);
 int fmarl_ring_free(void *cookie);
 /* The allocator's books: out[0] bytes of address space reserved so far, [1] of them idle (ranges of freed arrays), [2] ranges
