@@ -9,7 +9,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fair_marl_amd import _lib  # noqa: E402
 
 gb = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fair_marl_amd as fm  # noqa: E402
 from fair_marl_amd.rollout_buffer import DeviceRolloutBuffer  # noqa: E402
 

@@ -3,7 +3,7 @@
 plain stores.  usage: python tools/archive/nt_probe.py"""
 import ctypes as C, sys, torch, math
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fair_marl_amd import _lib
 lib=_lib.load(); dev=torch.device('cuda:0')
 nbytes=8317*1000*1000//16*16

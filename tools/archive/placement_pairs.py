@@ -1,6 +1,6 @@
 """measurement aid: emission-only launch time for every (node_obs allocation, adj allocation) pair."""
 import os, sys, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import fair_marl_amd as fm
 cfg = fm.EnvConfig(num_agents=32, num_landmarks=32, num_obstacles=8)
 n, dev, K = 65536, 'cuda:0', 6
