@@ -676,8 +676,8 @@ __device__ __forceinline__ double2 agent_force_pairs(const Params &p, char *lds,
     }
     return make_double2(Fx, Fy);
 }
-// three mixed_stats side by side (the fairness scalar's vector and the two info planes' vectors): the same operations per
-// vector, one pass -- the three dependent chains overlap instead of following each other
+// three mixed_stats side by side (the fairness scalar's vector and the two info planes' vectors) in one pass -- the three dependent
+// chains overlap instead of following each other
 __device__ __forceinline__ void mixed_stats3(const double *f1, const double *s1, int sp1, const double *f2, const double *s2, int sp2,
                                              const double *f3, const double *s3, int sp3, int n, double &m1, double &sd1, double &m2,
                                              double &sd2, double &m3, double &sd3) {
@@ -685,13 +685,16 @@ __device__ __forceinline__ void mixed_stats3(const double *f1, const double *s1,
     for (int j = 0; j < n; ++j) {
         a1 += (j < sp1) ? f1[j] : s1[j]; a2 += (j < sp2) ? f2[j] : s2[j]; a3 += (j < sp3) ? f3[j] : s3[j];
     }
-    m1 = a1 / n; m2 = a2 / n; m3 = a3 / n;
+    // (all three feed float32 OUTPUTS only -- the fairness column of obs, the reward's fairness term, the info planes: a reciprocal
+    // instead of the correctly rounded divisions, the short square root: an ulp or two in float64, on the chain a small batch waits for)
+    const double rn = rcp_small((double)n);
+    m1 = a1 * rn; m2 = a2 * rn; m3 = a3 * rn;
     double q1 = 0.0, q2 = 0.0, q3 = 0.0;
     for (int j = 0; j < n; ++j) {
         const double d1 = ((j < sp1) ? f1[j] : s1[j]) - m1, d2 = ((j < sp2) ? f2[j] : s2[j]) - m2, d3 = ((j < sp3) ? f3[j] : s3[j]) - m3;
         q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
     }
-    sd1 = sqrt(q1 / n); sd2 = sqrt(q2 / n); sd3 = sqrt(q3 / n);
+    sd1 = sqrt_pos(q1 * rn); sd2 = sqrt_pos(q2 * rn); sd3 = sqrt_pos(q3 * rn);
 }
 
 // core.py:338-356 integrate_state: updates x, v, pd
