@@ -580,7 +580,7 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
             if (a == 0 && N >= 3 && (occ & PN) == PN && occ != full) { fast = true; break; }
         }
         tw.words()[2] = occ;
-        ((uint32_t *)tw.vdual())[N + 2] = fast ? 1u : 0u;   // (N >= 3: the table has N doubles = 2 N words)
+        if (N >= 3) ((uint32_t *)tw.vdual())[N + 2] = fast ? 1u : 0u;   // (the table has N doubles = 2 N words: room for word N + 2 from three agents on; `fast` is never set below)
     }
     wave_sync();
     if (active && i >= 1 && N >= 3 && ((const uint32_t *)t.vdual())[N + 2] != 0 && !FMARL_SKIP(p, 128)) {
@@ -672,8 +672,8 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
                 // ff:477-499: the same vector with this agent's own entry fresh -- one entry replaced (its path length for the frozen
                 // value, if it is still under way), else unchanged
                 double dm = m, ds = sd, unused;
-                if (!base) travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i + 1, dm, ds, unused);
-                else if (open) replaced_entry_stats(m, m2, N, Dg_old, pd, dm, ds);
+                if (!base || (open && !replaced_entry_stats(m, m2, N, Dg_old, pd, dm, ds)))
+                    travelled_stats(s_stat, s_stat + N, *t.openmask(), N, i + 1, dm, ds, unused);
                 const size_t plane = (size_t)p.n_envs * N;
                 float *inf = o.info + g;
                 inf[FMARL_INFO_DIST_TO_GOAL * plane] = (float)left;

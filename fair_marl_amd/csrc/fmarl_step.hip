@@ -454,12 +454,15 @@ __device__ __forceinline__ void mixed_stats_m2(const double *fresh, const double
 }
 // The statistics of a vector that differs from one with known (mean, M2) in ONE entry, `was` -> `now` (Welford's update for a
 // replaced sample).  For OUTPUT-only statistics -- the info planes' mean / std after the agent's own entry went from its stale to its
-// fresh value: float32 outputs compared at 1e-5 -- instead of two more passes over the vector (float64: error ~1e-15).
-__device__ __forceinline__ void replaced_entry_stats(double mean, double m2, int n, double was, double now, double &mean2, double &sd2) {
+// fresh value: float32 outputs compared at 1e-5 -- instead of two more passes over the vector (float64: error ~1e-15 of the OLD M2).
+// -> false when the update cancels (the new vector is constant, or nearly: its M2 is rounding noise of the old one -- and a standard
+// deviation of 1e-8 instead of exactly 0 shows in mean / (std + 1e-4) at 1e-4): the caller then takes the two passes.
+__device__ __forceinline__ bool replaced_entry_stats(double mean, double m2, int n, double was, double now, double &mean2, double &sd2) {
     const double d = now - was;
     mean2 = mean + d * rcp_small((double)n);
     const double q = m2 + d * ((now - mean2) + (was - mean));
     sd2 = sqrt_pos(fmax(q, 0.0) * rcp_small((double)n));
+    return q > 1e-10 * (m2 + d * d) || d == 0.0;
 }
 
 // First half of World.step (core.py:250-274) for agent i of one env: action force (core.py:277-298 with the
@@ -926,8 +929,8 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
             // Field-major records: info[k][env][agent], every store is lane-contiguous.
             if (!p.scan_stats && !info_stats_done) {
                 // (:600-602) the fairness scalar's vector with this agent's own entry fresh: one entry replaced
-                if (base_stats) replaced_entry_stats(m, base_m2, p.N, Dg_old, Dg_new, dm, ds);
-                else mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
+                if (!base_stats || !replaced_entry_stats(m, base_m2, p.N, Dg_old, Dg_new, dm, ds))
+                    mixed_stats(s_stat + 2 * p.N, s_stat + p.N, p.N, i + 1, dm, ds);
                 mixed_stats(s_stat + 4 * p.N, s_stat + 3 * p.N, p.N, i + 1, tm, ts);
             }
             const size_t plane = (size_t)p.n_envs * p.N;
