@@ -1112,6 +1112,50 @@ def test_info_planes_can_be_skipped_per_step(kw):
         assert np.array_equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize('case', range(int(os.environ.get('FMARL_SPAN_FUZZ_CASES', '90'))))
+def test_random_small_configs_span_equals_steps(case):
+    """The span kernels (state carried in registers across the steps: step_span_kernel, its small-batch form, formation_span_kernel,
+    fairnav_span_kernel -- where envs end their episodes inside the launch) on ragged shapes and knobs like the fuzz test above: two
+    and a half episodes from a tape as fmarl_step_span, every step into its own slot, against the same steps one launch each --
+    outputs of every step, infos of the last, the whole state: bit for bit."""
+    rs = np.random.RandomState(5000 + case)
+    kind = case % 3   # 0 navigation_graph, 1 nav_fairassign_fairrew_formation_graph, 2 fair_graph_formation
+    N = int(rs.randint(2 if kind == 1 else 1, 12)); O = int(rs.randint(0, 5)); W = int(rs.randint(0, 3)); n = int(rs.choice([1, 3, 40, 130]))
+    ep = int(rs.choice([2, 5, 9]))
+    kw = dict(num_agents=N, num_obstacles=O, episode_length=ep, max_speed=None if case % 5 == 4 else float(rs.choice([0.7, 2.0])),
+              min_dist_thresh=float(rs.choice([0.05, 0.3, 0.6])), goal_rew=float(rs.choice([5, 2.5])), collision_rew=float(rs.choice([5, 1.0])))
+    if kind == 2:
+        cfg = fm.EnvConfig(scenario_name='fair_graph_formation', num_landmarks=int(rs.randint(1, 3)), **kw)
+    elif kind == 1:
+        cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_landmarks=N, num_walls=W,
+                           min_obs_dist=float(rs.choice([0.5, 0.25, 1.2])), **kw)
+    else:
+        cfg = fm.EnvConfig(num_landmarks=N, num_walls=W, **kw)
+    E, D, F = cfg.E, cfg.obs_dim, cfg.node_feat
+    hint = int(rs.choice([0, 0, 2, 5]))
+    a = fm.RolloutEngine(cfg, n, device=DEV, seed=300 + case, envs_per_workgroup=hint)
+    b = fm.RolloutEngine(cfg, n, device=DEV, seed=300 + case, envs_per_workgroup=hint)
+    gen = torch.Generator(device=DEV); gen.manual_seed(case)
+    a.reset(); b.reset()
+    if case % 2:   # start the span in the middle of an episode
+        act = torch.randint(0, 5, (n, N), device=DEV, generator=gen, dtype=torch.int32)
+        a.step(act); b.step(act)
+    T = 2 * ep + ep // 2 + 1
+    tape = torch.randint(0, 5, (T, n, N), device=DEV, generator=gen, dtype=torch.int32)
+    z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=DEV)  # noqa: E731
+    big = dict(obs=z(T, n, N, D), node_obs=z(T, n, N, E, F), adj=z(T, n, E, E), reward=z(T, n, N), done=z(T, n, N, dt=torch.uint8))
+    b.use_outputs(b.new_output_set(obs=big['obs'][0], node_obs=big['node_obs'][0], adj_env=big['adj'][0], reward=big['reward'][0], done=big['done'][0]))
+    b.step_span(tape, strides={k: v[0].numel() for k, v in big.items()})
+    for t in range(T):
+        r = a.step(tape[t])
+        for k, x in zip(('obs', 'node_obs', 'adj', 'reward', 'done'), (r[0], r[2], a.adj_env, r[4], r[5])):
+            assert torch.equal(big[k][t], x), 'case %d %s step %d %s' % (case, cfg, t, k)
+    assert torch.equal(a.info, b.info)   # (stride 0: the last step's infos)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), 'case %d %s state %s' % (case, cfg, k)
+
+
 @pytest.mark.parametrize('geom', [0, 3, 'full'])
 @pytest.mark.parametrize('kw', SHARD_CASES + [dict(num_agents=32, num_landmarks=32, num_obstacles=8, episode_length=7),
                                               dict(num_agents=10, num_landmarks=10, num_obstacles=3, episode_length=7)],
