@@ -800,8 +800,9 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         goal = s_pos[p.N + match];
         integrate_agent(p, F, x, v, pd);
     }
+    FMARL_TICK(1);   // physics
     __syncthreads();   // every lane has finished reading the old positions
-    FMARL_TICK(1);   // physics, barrier
+    FMARL_TICK(8);   // ... the wait at its barrier
 
     double dg = 0, Tr_new = 0;
     bool will_reset = false;
@@ -821,8 +822,9 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
         will_reset = auto_reset && step >= p.episode_length;          // env_wrappers.py:859-864
         if (i == 0) *(int *)(base + p.lds_flag) = will_reset ? 1 : 0;
     }
+    FMARL_TICK(2);   // agent rows of the emission tables, statistics inputs
     __syncthreads();
-    FMARL_TICK(2);   // agent rows of the emission tables, statistics inputs, barrier
+    FMARL_TICK(9);   // ... the wait at their barrier
     if constexpr (SMALL) {
         if (tid >= 64) {   // waves 1 .. 3: the emission (pos / agentf / ego / posf / wall / flag are final since the barrier above)
             emit_graph_waves(p, o, lds, env0, nenv);
@@ -1018,6 +1020,7 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     // emission only reads pos / agentf / wall / flag, all final since the barrier above
 #ifdef FMARL_MEASURE
     if (!SMALL && !FMARL_SKIP(p, 32)) {   // emit_graph with clocks between its parts (odd workgroups write adj first)
+        if (!p.vec_node) { __syncthreads(); FMARL_TICK(10); }   // generic rows: how long the waves wait for each other at the emission's first barrier (an extra one here, which takes the wait)
         const bool adj_first = (blockIdx.x & 1) != 0;
         if (adj_first) emit_adj(p, o, lds, env0, 0, nenv, threadIdx.x, kThreads);
         FMARL_TICK(6);   // adj (odd workgroups)

@@ -12,8 +12,9 @@ import bench  # noqa: E402
 import fair_marl_amd as fm  # noqa: E402
 from fair_marl_amd import _lib  # noqa: E402
 
-NAMES_NAV = ['loads+tables+barrier', 'physics+barrier', 'agent rows+barrier', 'scan statistics', 'stats+hits+reward+stores', 'node_obs',
-             'adj (odd workgroups: first)', 'adj (even workgroups: last)']
+NAMES_NAV = ['loads+tables+barrier', 'physics', 'agent rows', 'scan statistics', 'stats+hits+reward+stores', 'node_obs',
+             'adj (odd workgroups: first)', 'adj (even workgroups: last)', 'wait at the barrier behind the physics', 'wait at the barrier behind the agent rows',
+             'wait at the emission\'s first barrier (generic rows)']
 NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'reward+state+info (before the walk)',
               'obs+occupancy state+record', 'node rows', 'in-kernel reset of the ended envs: the rest', 'adj', 'in-kernel reset: the barrier that finds ended envs + the pre-draw of their Philox blocks',
               'in-kernel reset: the placement (first lane of an ended env)']
