@@ -17,7 +17,8 @@ the max over ranks of the time of exactly K steps bracketed by barrier + device 
 With N > 1 each rank owns 65 536 envs (weak scaling) and every step's trajectory record
 (obs, reward, done) is gathered to rank 0 over RCCL inside the timed region.
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how roofline / cpu_baseline are built.
+Rank 0 prints ONE compact JSON line on stdout (<= 6 000 bytes: compact_line) and writes the full record -- the prose, the tables,
+every secondary entry -- to bench_detail.json and stderr; see DESIGN.md "Measurement" for how roofline / cpu_baseline are built.
 """
 import argparse
 import json
@@ -49,6 +50,11 @@ CONFIGS = {   # workload: a format string, filled with the number of envs the ru
     'fnav': dict(workload='nav_fairassign_fairrew_formation_graph, 3 agents + 3 obstacles (E=9), %d envs per GPU',
                  env=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3,
                           num_obstacles=3, goal_rew=30.0, collision_rew=30.0), n_envs=65536, cpu_envs=32, cpu_episodes=4),
+    # the same scenario at the size BASELINE.md section 2 times the reference at (N = 10: 855 agent-steps/s on one core): 64 x N > 192 lanes,
+    # so fairnav_span_kernel<256>, and the per-step re-assignment grows with N (nav_fairassign_fairrew_formation_graph.py:704-721)
+    'fnav10': dict(workload='nav_fairassign_fairrew_formation_graph, 10 agents + 10 goals + 3 obstacles (E=23), %d envs per GPU',
+                   env=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=10, num_landmarks=10,
+                            num_obstacles=3, goal_rew=30.0, collision_rew=30.0), n_envs=65536, cpu_envs=16, cpu_episodes=3),
     # the reference's own experiment scale (10 agents): odd E, so the generic (row-per-lane) emission path
     'n10': dict(workload='navigation_graph, 10 agents + 3 obstacles (E=23), %d envs per GPU',
                 env=dict(num_agents=10, num_landmarks=10, num_obstacles=3), n_envs=65536, cpu_envs=64, cpu_episodes=3),
@@ -59,11 +65,12 @@ CONFIGS = {   # workload: a format string, filled with the number of envs the ru
 KERNEL_NAMES = {'fair_graph_formation': 'formation_kernel<true>', 'nav_fairassign_fairrew_formation_graph': 'fairnav_kernel<true>'}
 # every BASELINE config that fits one GPU besides the headline one, timed after the headline region (same process, fresh
 # engines) and reported under `secondary`: (config, launch mode)
-SECONDARY = (('cfg3', 'eager'), ('cfg3', 'span'), ('cfg3', 'span5'), ('cfg3', 'span-same'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'),
+SECONDARY = (('cfg3', 'eager'), ('cfg3', 'pipeline2'), ('cfg3', 'span'), ('cfg3', 'span5'), ('cfg3', 'span-same'), ('cfg2', 'span'), ('cfg2', 'graph'), ('cfg2', 'eager'),
              ('cfg4', 'eager'), ('cfg4', 'span'), ('cfg4', 'pipeline2'), ('fnav', 'eager'), ('fnav', 'span'), ('fnav', 'pipeline2'), ('fnav', 'steady'), ('fnav', 'steady-span'),
+             ('fnav10', 'eager'), ('fnav10', 'span'),
              ('n10', 'eager'), ('n10', 'span'), ('n10', 'pipeline2span'))
 # nav_fairassign_fairrew_formation_graph where a training run is: a threshold at which goals are reached, so that episodes end
-# env by env, and enough untimed steps for the envs' episode phases to be uniform (mode 'steady'; tools/archive/fnav_steady.py)
+# env by env, and enough untimed steps for the envs' episode phases to be uniform (mode 'steady'; round 5: tools/archive/fnav_steady.py, in the history up to 28d23e2)
 STEADY = dict(min_dist_thresh=0.5, pre_steps=600)
 
 
@@ -220,7 +227,7 @@ SPAN_TUNE_STALL = 0.02
 # the secondary configs other than the headline's run in child processes of their own, started before this process touches the GPU,
 # smallest footprint first: what an entry measures then does not depend on what ran before it (profiles/r4_notes.md section 18: behind
 # the headline's 205 GB ring `n10 eager` read 0.206-0.273 ms per step, in a fresh process 0.2112-0.2119)
-SECONDARY_CHILD_ORDER = ('cfg2', 'fnav', 'cfg4', 'n10')
+SECONDARY_CHILD_ORDER = ('cfg2', 'fnav', 'cfg4', 'fnav10', 'n10')
 
 
 def _small_batch(cfg, eng):
@@ -267,7 +274,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     steps, warmup = max(ep, steps // ep * ep), (warmup + ep - 1) // ep * ep
     if mode.startswith('pipeline'):
         spans = mode.endswith('span')
-        return secondary_pipeline(name, int(mode[len('pipeline'):].replace('span', '')), device, steps, warmup, spans, slots)
+        return secondary_pipeline(name, int(mode[len('pipeline'):].replace('span', '')), device, steps, warmup, spans, slots, arena=arena)
     same = mode == 'span-same'
     run_len = int(mode[4:]) if mode.startswith('span') and mode[4:].isdigit() else 0
     rmode = 'span' if mode.startswith('span') or mode == 'steady-span' else ('eager' if mode == 'steady' else mode)
@@ -367,7 +374,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     return out
 
 
-def secondary_pipeline(name, k, device, steps, warmup, spans=False, slots='ring'):
+def secondary_pipeline(name, k, device, steps, warmup, spans=False, slots='ring', arena=None):
     """The same envs as k sub-batches on k streams (fair_marl_amd.PipelinedRollout; bit-identical results): the tail of one
     sub-batch's launch overlaps the head of another's.  What a random-action rollout -- actions known ahead -- or an
     alternating sampler gets out of the chip for the compute-heavy scenarios; with ``spans`` every sub-batch runs its steps as
@@ -377,7 +384,8 @@ def secondary_pipeline(name, k, device, steps, warmup, spans=False, slots='ring'
     cfg = fm.EnvConfig(**spec['env'])
     n, ep = spec['n_envs'], cfg.episode_length
     pipe = fm.PipelinedRollout(cfg, n, k=k, device=device, seed=1, tune_placement=0)
-    rings = pipe.new_rings(ep) if _use_ring(cfg, n, slots, device) else None
+    # (`arena`: the headline's ring -- every sub-batch writes its envs' part of the same (T, n, ...) time slots)
+    rings = pipe.new_rings(ep, like=arena) if arena is not None else (pipe.new_rings(ep) if _use_ring(cfg, n, slots, device) else None)
     g = torch.Generator(device=device)
     g.manual_seed(2000)
     tape = torch.randint(0, 5, (ep, n, cfg.N), device=device, generator=g, dtype=torch.int32)
@@ -404,7 +412,8 @@ def secondary_pipeline(name, k, device, steps, warmup, spans=False, slots='ring'
     out = dict(config=name, mode='pipeline%d%s' % (k, 'span' if spans else ''), workload=spec['workload'] % n,
                launch='%d sub-batches of %d envs on their own streams, each %s' % (k, n // k, 'running its steps as spans (fmarl_step_span)'
                                                                                    if spans else 'one fmarl_step call per step'),
-               slots=('every step its own time slot of an episode-long ring per sub-batch' if rings is not None else 'one output set per sub-batch, rewritten every step'),
+               slots=('every step its own time slot of the whole batch\'s episode-long ring (a sub-batch writes its envs\' part of a slot)' if arena is not None else
+                      'every step its own time slot of an episode-long ring per sub-batch' if rings is not None else 'one output set per sub-batch, rewritten every step'),
                value=n * cfg.N * steps / elapsed, unit='agent-steps/s', steps=steps, warmup=warmup,
                ms_per_step=elapsed / steps * 1e3, kernel=KERNEL_NAMES.get(cfg.scenario_name, 'step_span_kernel + step_end_kernel' if spans else 'step_kernel / step_end_kernel'),
                kernel_avg_ms=float(np.sum(kernel_ms)) / sum(b[0] - a[0] for a, b in zip(c0, c1)), kernel_launches=len(kernel_ms), frac=job / HBM_PEAK_GBS,
@@ -488,7 +497,10 @@ def run_secondary_children(headline):
         if name == headline or not any(n == name for n, _ in SECONDARY):
             continue
         try:
-            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--secondary-child', name], capture_output=True, text=True, timeout=300)
+            # (a child runs all modes of its config: 60 s per entry + 600 untimed steps for the steady ones, on top of 120 s of start-up)
+            entries = sum(1 for n, _ in SECONDARY if n == name)
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--secondary-child', name], capture_output=True, text=True,
+                                 timeout=120 + 60 * entries)
             lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
             if res.returncode != 0 or len(lines) != 1:
                 raise RuntimeError('exit code %d: %s' % (res.returncode, res.stderr[-400:]))
@@ -539,6 +551,91 @@ def launch_plan(launch, pipeline, scenario_name, gather, span_steps, episode_len
     return launch, max(1, min(steps, episode_length))
 
 
+# ---- the line the driver parses -------------------------------------------------------------------------------------------------
+# stdout carries ONE compact JSON line (<= COMPACT_LIMIT bytes: round 5's 21 KB line was more than the driver's parser took, its record
+# came back `parsed: null`).  Scalars and one-word modes only; the prose (what a launch mode is, how a figure was taken), the store
+# streams' table, the span-tuning table, the per-rank rows and the full `secondary` entries go to bench_detail.json beside this
+# file (--detail PATH) and, as one line behind DETAIL_PREFIX, to stderr.
+COMPACT_LIMIT = 6000
+DETAIL_PREFIX = 'bench.py detail: '
+_TOP_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'n_ranks_seen', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+             'vs_baseline', 'dtype', 'data')
+_CONFIG_KEYS = ('workload', 'n_envs_per_gpu', 'n_agents', 'n_entities', 'episode_length', 'auto_resets_timed', 'launch_mode', 'span_steps',
+                'slots', 'reset', 'exchange')
+_ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_avg_ms', 'kernel_launches', 'kernel_steps_per_launch',
+                  'store_ceiling_ms', 'frac_of_box_ceiling', 'frac_bytes_moved', 'slots')
+SECONDARY_FIELDS = ('config', 'mode', 'ms_per_step', 'frac')
+
+
+def _sig(v, digits=6):
+    """Floats to `digits` significant digits (the line is read by people and a parser, neither needs 17), containers element-wise."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float('%.*g' % (digits, v)) if np.isfinite(v) else None
+    if isinstance(v, (np.floating, np.integer)):
+        return _sig(v.item(), digits)
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return str(v)
+
+
+def compact_line(full, detail_name='bench_detail.json'):
+    """The one stdout line: the contract's keys, `config` as shapes + one-word modes, `roofline` as scalars, `cpu_baseline`,
+    `reference_cpu`, `secondary` as [config, mode, ms_per_step, frac] rows, and for N > 1 the scalars a scaling figure needs to explain
+    itself (multi_gpu, scaling_base).  Everything else is in the detail file.  Raises if the line would exceed COMPACT_LIMIT."""
+    c = {k: full[k] for k in _TOP_KEYS if k in full}
+    c['config'] = {k: full['config'][k] for k in _CONFIG_KEYS if k in full['config']}
+    c['roofline'] = {k: full['roofline'][k] for k in _ROOFLINE_KEYS if k in full['roofline']}
+    if 'cpu_baseline' in full:
+        c['cpu_baseline'] = {k: full['cpu_baseline'][k] for k in ('value', 'unit', 'cores', 'kind', 'sample')}
+    if 'reference_cpu' in full:
+        c['reference_cpu'] = {k: full['reference_cpu'][k] for k in ('value', 'unit', 'cores', 'source')}
+    if 'secondary' in full:
+        c['secondary_fields'] = list(SECONDARY_FIELDS)
+        c['secondary'] = [[_sig(e[k], 5) for k in SECONDARY_FIELDS] for e in full['secondary']]
+    if full.get('child_errors'):
+        c['child_errors'] = sorted(full['child_errors'])
+    m = full.get('multi_gpu')
+    if m is not None:
+        cm = {'per_rank_ms_per_step': _sig(m['per_rank_ms_per_step'], 5),
+              'host_blocked_ms_per_step_max': max(m['gather_wait_ms']['host_blocked_per_step']),
+              'stream_stalled_ms_per_step_max': max(m['gather_wait_ms']['stream_stalled_per_step']),
+              'bytes_received_by_rank0_per_step': m['bytes_received_by_rank0_per_step'], 'rank0_receive_GBps': m['rank0_receive_GBps'],
+              'collectives_timed': m.get('collectives_timed'), 'warmup_steps_actually_run': m.get('warmup_steps_actually_run')}
+        if 'span_tuning' in m:
+            st = m['span_tuning']
+            cm['span_tuning'] = {'chosen': st['chosen'], 'admissible': st['admissible'], 'stall_limit': st['stall_limit'],
+                                 'fields': ['span_steps', 'ms_per_step', 'stall_frac'],
+                                 'candidates': [[r['span_steps'], _sig(r['ms_per_step'], 5), _sig(r['stall_frac'], 3)] for r in st['candidates']]}
+        if 'ideal_vs_n1_headline' in m:
+            cm['ideal_vs_n1_headline'] = m['ideal_vs_n1_headline']
+            cm['n1_headline_mode_ms_per_step'] = m['n1_headline_mode']['ms_per_step']
+        if 'learner_rebuild' in m:
+            cm['learner_rebuild_ms_per_step'] = m['learner_rebuild']['ms_per_step']
+        c['multi_gpu'] = cm
+    if 'scaling_base' in full:
+        c['scaling_base'] = {k: full['scaling_base'][k] for k in ('value_per_gpu', 'unit', 'ms_per_step', 'efficiency')}
+    c['detail'] = detail_name
+    line = json.dumps(_sig(c), separators=(',', ':'), allow_nan=False)
+    if len(line.encode()) > COMPACT_LIMIT:
+        raise ValueError('bench.py: the result line is %d bytes, more than COMPACT_LIMIT = %d' % (len(line.encode()), COMPACT_LIMIT))
+    return line
+
+
+def write_detail(full, path):
+    """The full record: to `path` (best effort: the tree may be read-only) and as one line to stderr."""
+    text = json.dumps(full, default=lambda o: o.item() if isinstance(o, (np.floating, np.integer)) else str(o))
+    try:
+        with open(path, 'w') as f:
+            f.write(text + '\n')
+    except OSError as exc:
+        print('bench.py: could not write %s (%s); the detail follows on stderr only' % (path, exc), file=sys.stderr)
+    print(DETAIL_PREFIX + text, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -575,6 +672,8 @@ def main():
     ap.add_argument('--rccl-selftest', action='store_true', help='N=1: open an RCCL process group of ONE rank and run the step / '
                     'episode gathers through it inside the timed loop (the nccl code path on a one-GPU box); implies --record-path')
     ap.add_argument('--no-secondary', action='store_true', help='N=1: skip the other BASELINE configs after the headline region')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'bench_detail.json'), help='where the full record goes (prose, tables, per-rank rows, '
+                    'the full secondary entries); stdout carries the compact line only')
     ap.add_argument('--secondary-child', default=None, choices=sorted(CONFIGS), help=argparse.SUPPRESS)   # (internal: run_secondary_children)
     ap.add_argument('--no-span-tuning', action='store_true', help='N > 1: runs of GATHER_SPAN_STEPS steps instead of choosing the run length '
                     'during the warm-up (SPAN_TUNE_CANDIDATES)')
@@ -879,7 +978,10 @@ def main():
             first += n_tune
         pick = pick_span_length(table)
         span_len[0] = span_steps = pick['span_steps']
-        span_tuning = {'candidates': table, 'chosen': span_steps, 'runs_per_candidate': SPAN_TUNE_RUNS, 'rule': pick_span_length.__doc__}
+        span_tuning = {'candidates': table, 'chosen': span_steps, 'runs_per_candidate': SPAN_TUNE_RUNS, 'rule': pick_span_length.__doc__,
+                       # how many candidates passed the stall rule (0: the rule's fallback branch chose -- the lowest time per step of all)
+                       'admissible': sum(1 for r in table if r['stall_frac'] < SPAN_TUNE_STALL), 'stall_limit': SPAN_TUNE_STALL,
+                       'steps_run': sum(SPAN_TUNE_RUNS * r['span_steps'] for r in table)}
         pad = (W - first) % ep      # back to the episode phase the region would have started at without the tuning pass
         run_spans(first, pad, taper=False)
         first += pad
@@ -1066,13 +1168,19 @@ def main():
                        'n_entities': cfg.E, 'episode_length': ep, 'auto_resets_timed': resets,
                        'arithmetic': 'f64 state, contact forces and statistics; f32 outputs (obs, node_obs, adj, reward, info)',
                        'launch_mode': launch, 'launch': launch_text, 'span_steps': (min(ep, span_steps) if launch == 'span' else None),
-                       'slots': ('ring: every step writes its own time slot of an episode-long ring of (%d, n, ...) arrays (%.1f GB): the trajectory '
-                                 'exists afterwards, every byte is written once per pass' % (ep, ring_bytes / 1e9) if slots == 'ring'
-                                 else 'same: every step overwrites one output set'),
-                       'reset': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
-                                 else 'next episode staged on a side stream, committed and observed by the launch that ends the episode'
-                                      ' (%d of %d episode ends folded)' % (folded, cb[1] - ca[1] + cb[2] - ca[2])),
-                       'exchange': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
+                       # one word each in the compact line; the sentences behind them under *_text in the detail
+                       'slots': slots,
+                       'slots_text': ('ring: every step writes its own time slot of an episode-long ring of (%d, n, ...) arrays (%.1f GB): the trajectory '
+                                      'exists afterwards, every byte is written once per pass' % (ep, ring_bytes / 1e9) if slots == 'ring'
+                                      else 'same: every step overwrites one output set'),
+                       'reset': 'synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph' else 'staged',
+                       'reset_text': ('synchronous' if args.sync_reset or cfg.scenario_name != 'navigation_graph'
+                                      else 'next episode staged on a side stream, committed and observed by the launch that ends the episode'
+                                           ' (%d of %d episode ends folded)' % (folded, cb[1] - ca[1] + cb[2] - ca[2])),
+                       'exchange': ('none' if not gather else
+                                    (('rccl' + ('-selftest' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
+                                      else ('records-only' if world == 1 else 'gloo')) + '-gather-per-' + ('run' if sg is not None else 'step'))),
+                       'exchange_text': (('RCCL' + (' (process group of one rank: self-test)' if world == 1 else '') if args.backend == 'nccl' and dist.is_initialized()
                                      else ('record writes only, no process group' if world == 1 else 'gloo (rehearsal)')) + ' ' + exchange_text
                                     + ((' + %d B per env with EVERY step (goals, landmarks, obstacles, walls: this scenario\'s episodes end env by env, '
                                         'so the record is re-packed and gathered whenever an env may have been reset)' if fnav_sc else
@@ -1124,6 +1232,10 @@ def main():
                 'bytes_gathered_per_step': rec_bytes * world, 'bytes_received_by_rank0_per_step': recv_bytes,
                 'rank0_receive_GBps': recv_bytes / (elapsed / K) / 1e9,
                 'collectives': ('one per run of steps (%d in the timed region)' % (chunk[0] - chunk_start) if sg is not None else 'one per step'),
+                'collectives_timed': (chunk[0] - chunk_start) if sg is not None else K,
+                # every untimed step before the timed region: --warmup, the run-length tuning passes, the scaling_base passes and their
+                # pads back to the episode phase (with --warmup 5 and the tuner on: 5 + 112 + ...), so `warmup` is not mistaken for it
+                'warmup_steps_actually_run': first,
                 'episode_record_bytes_per_rank': 4 * episode_words_of(cfg) * n_envs if episodes else 0,
                 'episode_record_gathers_per_step': (1.0 if fnav_sc and sg is None else 1.0 / ep) if episodes else 0.0}
             if rebuild_ranks:
@@ -1181,6 +1293,8 @@ def main():
                                 % ('under a profiler no child process may be started' if under_profiler else child_errors.get(name, 'child failed')))
                 out['secondary'].append(e)
             out['secondary_wall_s'] = time.perf_counter() - t_sec + child_wall
+            if child_errors:   # configs whose child process failed or timed out (their entries then ran in this process: ADVICE round 5)
+                out['child_errors'] = child_errors
             for e in out['secondary']:   # the other slot mode of the headline config, over 300 steps
                 if e['config'] == args.config and e['mode'] == 'span-same':
                     out['roofline']['frac_same_slot'] = e['frac']
@@ -1188,7 +1302,9 @@ def main():
                 if e['config'] == args.config and e['mode'] == 'span':
                     out['roofline']['frac_distinct_slots_300_steps'] = e['frac']
         sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + '\n').encode())
+        line = compact_line(out, os.path.basename(args.detail))
+        write_detail(out, args.detail)
+        os.write(result_fd, (line + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# FMARL_LIB: measurement aid (tools/mkvariant.sh, tools/archive/abrun.sh) -- another build of the SAME sources / C-ABI, e.g. a
+# FMARL_LIB: measurement aid (tools/mkvariant.sh, tools/ab_lib.sh) -- another build of the SAME sources / C-ABI, e.g. a
 # -DFMARL_MEASURE build or an experiment's variant, selected per process instead of overwriting the shipped library
 LIB_PATH = os.environ.get('FMARL_LIB') or os.path.join(HERE, 'csrc', 'libfmarl.so')
 

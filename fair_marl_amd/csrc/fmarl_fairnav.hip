@@ -661,7 +661,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_kerne
 // registers across a whole step -- shapes, eight output pointers, nine strides -- they spill twice as many registers.
 struct FairnavSpanArgs { Params p; FmarlOutputs o; SpanStrides s; const int32_t *action_idx; const float *action_vec; int T, auto_reset; };
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_span_kernel(FairnavSpanArgs) {
+__global__ __launch_bounds__(THREADS, 3) void fairnav_span_kernel(FairnavSpanArgs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     FairnavCarry c = {};
     for (int t = 0;; ++t) {

@@ -304,6 +304,26 @@ __global__ __launch_bounds__(256) void store_stream_kernel(float4 *dst, size_t n
     }
 }
 
+// fmarl_ring_alloc's check of an array allocated after another one was freed: a KERNEL's fill read back by a kernel (the faults seen on
+// re-used address ranges passed a fill / read-back through the copy engines and lost a kernel's writes).  Word i gets a pattern of i;
+// the second launch counts the words that do not hold it and zeroes the array.
+__global__ __launch_bounds__(256) void ring_fill_kernel(uint4 *dst, size_t n16, uint32_t salt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint32_t w = (uint32_t)i * 2654435761u ^ salt;
+        dst[i] = make_uint4(w, ~w, w + 1u, salt);
+    }
+}
+__global__ __launch_bounds__(256) void ring_check_kernel(uint4 *dst, size_t n16, uint32_t salt, unsigned long long *bad) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint32_t w = (uint32_t)i * 2654435761u ^ salt;
+        const uint4 v = dst[i];
+        mine += (v.x != w) + (v.y != ~w) + (v.z != w + 1u) + (v.w != salt);
+        dst[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
 // test hook (fmarl_poison_lds): every workgroup writes 0xFF bytes over all the LDS it was given
 __global__ __launch_bounds__(256) void poison_lds_kernel(int words) {
     extern __shared__ __attribute__((aligned(16))) char lds[];

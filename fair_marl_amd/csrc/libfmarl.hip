@@ -230,7 +230,8 @@ void launch_place(Handle *h, const Params &p, int mode, const uint8_t *mask, hip
 // on what the host knew about the staged data when it was captured, so a captured staging always clears the validity flags
 // first and leaves the host's own `stage_dirty` as it was (nothing ran).
 // nav_fairassign_fairrew_formation_graph kernels: the instantiation for the handle's workgroup size (TH = 192 or 256 threads)
-#define FMARL_FNAV(h, kernel, grid, lds, st, ...) FMARL_FNAV_T((h)->threads, kernel, grid, lds, st, __VA_ARGS__)
+// (the per-step, reset-observation and rebuild kernels always run kThreads wide: only the span kernel has a three-wave form)
+#define FMARL_FNAV(h, kernel, grid, lds, st, ...) do { constexpr int TH = kThreads; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } while (0)
 #define FMARL_FNAV_T(threads, kernel, grid, lds, st, ...)                                               \
     do {                                                                                                \
         if ((threads) == 192) { constexpr int TH = 192; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
@@ -401,7 +402,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         off = align16(o2);
         // Tables nobody reads once the emission starts: a region of their own behind all envs' blocks, which the waves' emission
         // windows alias (13.5 KB that used to sit beside the envs' tables: 36 -> 58 envs per workgroup in the shipped FA+FR
-        // configuration, and the launch time falls with the number of workgroups: tools/archive/epb_sweep.py fnav)
+        // configuration, and the launch time falls with the number of workgroups: an envs-per-workgroup sweep of round 3, tools/archive/epb_sweep.py in the history up to 28d23e2)
         int d = 0;
         p.lds_stat = d;    d += 5 * p.N * 8;        // [pd_new | Dg_old | Dg_new | Tr_old | Tr_new] x N
         p.n_D = d;         d += p.N * p.L * 8;
@@ -528,8 +529,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        for (const void *f : {(const void *)fairnav_rebuild_kernel<192>, (const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 192>,
-                              (const void *)fairnav_kernel<true, 256>, (const void *)fairnav_kernel<false, 192>, (const void *)fairnav_kernel<false, 256>,
+        for (const void *f : {(const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 256>, (const void *)fairnav_kernel<false, 256>,
                               (const void *)fairnav_span_kernel<192>, (const void *)fairnav_span_kernel<256>})
             if (e2 == hipSuccess) e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
@@ -795,7 +795,10 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
         // lockstep go through fmarl_step.  The third scenario's episodes end env by env and its step resets them itself: all
         // its steps are one launch (fairnav_span_kernel: the state through global memory between the steps).
         int k = 0;
-        if (sc == FMARL_SCENARIO_FAIRNAV) k = n_steps - t;
+        // (its span carries the step counter in 15 bits and the two collision counts in 16 each -- FairnavCarry: episodes too long for
+        // that go out one launch per step, the state through global memory, same results)
+        if (sc == FMARL_SCENARIO_FAIRNAV)
+            k = (h->cfg.episode_length < 32768 && (long long)(h->cfg.num_agents - 1) * h->cfg.episode_length <= 65535) ? n_steps - t : 0;
         else if (h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;
         if (k > n_steps - t) k = n_steps - t;
         FmarlOutputs o = *outs;
@@ -920,6 +923,7 @@ struct RingAlloc {
 };
 std::mutex g_ring_mutex;
 uint64_t g_ring_reserved = 0, g_ring_live = 0, g_ring_ranges = 0, g_ring_live_ranges = 0, g_ring_refused = 0;
+uint64_t g_ring_frees = 0, g_ring_checked = 0, g_ring_check_failed = 0;   // arrays freed; arrays checked by a kernel's fill; of them failed
 uint64_t ring_reserve_cap() {
     static const uint64_t cap = [] {
         const char *e = getenv("FMARL_RING_RESERVE_CAP_GB");
@@ -929,15 +933,53 @@ uint64_t ring_reserve_cap() {
     return cap;
 }
 
-void ring_release(RingAlloc *r) {
+void ring_release(RingAlloc *r, bool was_handed_out = true) {
     if (!r) return;
+    // no launch may still write here: the library waits for the device itself rather than trust every caller to have done so (a
+    // destructor that runs during somebody's stream capture cannot synchronise: the error is dropped, the pieces go back anyway)
+    if (r->mapped && hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    if (r->ptr && r->mapped == 0) {
+        // a range that never carried a mapping (a piece could not be created: out of memory) has no translations anywhere: it goes back
+        // to the runtime and off the books -- failed attempts (retries with fewer slots) must not eat the reserve cap
+        (void)hipMemAddressFree(r->ptr, r->total);
+        for (auto h : r->handles) (void)hipMemRelease(h);
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        g_ring_reserved -= r->total; g_ring_live -= r->total; --g_ring_ranges; --g_ring_live_ranges;
+        delete r;
+        return;
+    }
     for (size_t k = 0; r->ptr && k < r->mapped; ++k) (void)hipMemUnmap((char *)r->ptr + k * r->piece, r->piece);   // (piece by piece, as they were mapped)
     for (auto h : r->handles) (void)hipMemRelease(h);
     if (r->ptr) {   // the range stays reserved, idle from here on
         std::lock_guard<std::mutex> lock(g_ring_mutex);
         g_ring_live -= r->total; --g_ring_live_ranges;
+        if (was_handed_out) ++g_ring_frees;
     }
     delete r;
+}
+
+// An array allocated after another one of this process was freed -- the only condition either fault was ever seen under (re-reserved
+// ranges: round 4; kept ranges with fresh pieces: round 5; tools/vmm_fault_repro.cpp shows both on the bare HIP calls) -- is checked
+// before it is handed out: a kernel fills it with a pattern of the word index, a second kernel reads it back, counts the words that
+// do not hold it and leaves zeroes.  Two passes over the array (205 GB: 60 ms), never for a process's first arrays.
+// -> number of wrong 32-bit words, or -1 when the check itself could not run.
+long long ring_kernel_check(void *ptr, size_t total) {
+    unsigned long long *bad = nullptr, host = 0;
+    if (hipMalloc((void **)&bad, sizeof(*bad)) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    const size_t n16 = total / 16;
+    const uint32_t salt = 0x9e3779b9u ^ (uint32_t)(uintptr_t)ptr ^ (uint32_t)((uintptr_t)ptr >> 32);
+    hipError_t e = hipMemset(bad, 0, sizeof(*bad));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fmarl::ring_fill_kernel, dim3(4096), dim3(256), 0, (hipStream_t)0, (uint4 *)ptr, n16, salt);
+        e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fmarl::ring_check_kernel, dim3(4096), dim3(256), 0, (hipStream_t)0, (uint4 *)ptr, n16, salt, bad);
+        e = hipMemcpy(&host, bad, sizeof(host), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(bad);
+    if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (long long)host;
 }
 }  // namespace
 
@@ -1022,8 +1064,31 @@ int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **ba
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();   // (not left behind for the caller's next HIP call to trip over)
-        ring_release(r);           // unmaps what was mapped, releases every piece; the range stays reserved (and counted)
-        return fail(FMARL_EHIP, "fmarl_ring_alloc: %s", hipGetErrorString(e));
+        const hipError_t why = e;
+        ring_release(r, false);    // unmaps what was mapped, releases every piece; a range that carried a mapping stays reserved (and counted)
+        return fail(FMARL_EHIP, "fmarl_ring_alloc: %s", hipGetErrorString(why));
+    }
+    bool check;
+    {
+        std::lock_guard<std::mutex> lock(g_ring_mutex);
+        check = g_ring_frees > 0;
+    }
+    if (const char *v = getenv("FMARL_RING_VERIFY")) check = v[0] == '1' ? true : (v[0] == '0' ? false : check);   // 1: always, 0: never
+    if (check) {
+        const long long bad = ring_kernel_check(ptr, total);
+        {
+            std::lock_guard<std::mutex> lock(g_ring_mutex);
+            ++g_ring_checked;
+            if (bad != 0) ++g_ring_check_failed;
+        }
+        if (bad != 0) {
+            fprintf(stderr, "libfmarl: fmarl_ring_alloc: an array of %zu bytes allocated after an earlier one was freed did not hold a kernel's fill "
+                            "(%lld wrong words); refused -- allocate plainly\n", total, bad);
+            ring_release(r, false);
+            char words[32];
+            snprintf(words, sizeof(words), "%lld", bad);
+            return fail(FMARL_EHIP, "fmarl_ring_alloc: the array did not hold a kernel's fill (%s wrong words): allocate plainly", words);
+        }
     }
     *base = ptr; *cookie = r;
     return FMARL_OK;
@@ -1035,11 +1100,11 @@ int fmarl_ring_free(void *cookie) {
     return FMARL_OK;
 }
 
-int fmarl_ring_stats(uint64_t out[6]) {
+int fmarl_ring_stats(uint64_t out[8]) {
     if (!out) return fail(FMARL_EINVAL, "fmarl_ring_stats: null argument");
     std::lock_guard<std::mutex> lock(g_ring_mutex);
     out[0] = g_ring_reserved; out[1] = g_ring_reserved - g_ring_live; out[2] = g_ring_ranges; out[3] = g_ring_ranges - g_ring_live_ranges;
-    out[4] = ring_reserve_cap(); out[5] = g_ring_refused;
+    out[4] = ring_reserve_cap(); out[5] = g_ring_refused; out[6] = g_ring_checked; out[7] = g_ring_check_failed;
     return FMARL_OK;
 }
 

@@ -743,12 +743,7 @@ class _SpreadBlock(object):
         cookie, self._cookie = self._cookie, None
         if cookie is None or not cookie.value:
             return
-        try:
-            torch.cuda.synchronize(self._device)   # no launch may still write here
-        except Exception as e:   # (e.g. destroyed while some stream captures): the pieces are returned anyway, and it is said
-            import logging
-            logging.getLogger('fair_marl_amd').warning('time-slot array freed without a device synchronize: %s', e)
-        try:
+        try:   # (fmarl_ring_free waits for the device itself before it unmaps)
             if self._lib.fmarl_ring_free(cookie):
                 raise RuntimeError(self._lib.fmarl_last_error().decode())
         except Exception as e:
@@ -767,16 +762,9 @@ def alloc_time_slots(lib, device, shape, spread=None, zero=False, single=False):
         spread = False
     if (T >= 2 or single) and (spread or (spread is None and slot_bytes >= (64 << 20))):
         try:
+            # (an array allocated after an earlier one of the process was freed has been filled and read back by kernels inside
+            # fmarl_ring_alloc -- include/fmarl.h; one that failed raised MemoryError above and the allocation below is a plain one)
             t = torch.as_tensor(_SpreadBlock(lib, device, shape, slot_bytes, T), device=device)
-            if os.environ.get('FMARL_RING_VERIFY') == '1':
-                # opt-in: a KERNEL's fill read back by a kernel (the fault that re-used address ranges showed -- include/fmarl.h
-                # fmarl_ring_alloc -- passed a fill / read-back through the copy engines and lost a kernel's writes); costs two
-                # passes over the array
-                t.fill_(1.25)
-                if bool((t != 1.25).any()):
-                    del t
-                    raise MemoryError('fmarl_ring_alloc: the array did not hold a kernel\'s fill (FMARL_RING_VERIFY)')
-                zero = True
             if zero:
                 t.zero_()
             return t, True
@@ -803,9 +791,14 @@ class OutputRing(object):
     ``spread`` (default: on for node_obs / adj arrays whose slots are 64 MiB and more): the slots stay virtually contiguous --
     ``node_obs[t]`` is an ordinary contiguous tensor -- but their physical memory is interleaved in pieces over the whole array
     (``fmarl_ring_alloc``): MI355X writes ONE 8 GB region at 5.7-6.0 TB/s and the same bytes spread over 160 GB at 6.8-7.1, so a
-    launch that fills a single slot (``step``: a policy in the loop) runs at the rate a whole rollout gets."""
+    launch that fills a single slot (``step``: a policy in the loop) runs at the rate a whole rollout gets.
 
-    def __init__(self, engine, slots, like=None, spread=None):
+    ``env_range`` = (first env, count) together with ``like``: this ring is the time slots of a SUB-BATCH of the other ring's envs
+    (``PipelinedRollout.new_rings(like=...)``) -- every array is the other ring's, cut along the env axis (slot t of the sub-batch
+    is a contiguous block inside slot t of the whole batch; the step-to-step stride is the whole batch's), except the info
+    planes, whose (14, n, N) layout puts the env axis second: those are this ring's own."""
+
+    def __init__(self, engine, slots, like=None, spread=None, env_range=None):
         eng, cfg = engine, engine.cfg
         n, N, E, D, F = eng.n_envs, cfg.N, cfg.E, cfg.obs_dim, cfg.node_feat
         self.engine, self.slots = eng, int(slots)
@@ -816,9 +809,16 @@ class OutputRing(object):
 
         self.spread = []   # names of the arrays whose physical memory is interleaved
 
-        def mk(*shape, dtype=torch.float32, name=None):
+        if env_range is not None and (like is None or env_range[1] != eng.n_envs):
+            raise ValueError('OutputRing(env_range=...): needs `like`, and a range of the engine\'s %d envs' % eng.n_envs)
+
+        def mk(*shape, dtype=torch.float32, name=None, own=False):
             old = next(taken, None)
+            if own and env_range is not None:
+                return torch.empty(*shape, dtype=dtype, device=eng.device)
             if like is not None:
+                if old is not None and env_range is not None:
+                    old = old[:, env_range[0]:env_range[0] + env_range[1]]
                 if old is None or tuple(old.shape) != tuple(shape) or old.dtype != dtype or old.device != eng.device:
                     raise ValueError('OutputRing(like=...): the other ring has no %s array of shape %s' % (dtype, (shape,)))
                 if name in getattr(like, 'spread', ()):
@@ -839,14 +839,14 @@ class OutputRing(object):
             self.done = mk(T, n, N, dtype=torch.uint8)
             self.node_obs = mk(T, n, N, E, F, name='node_obs') if eng.emit_graph else skip()
             self.adj_env = mk(T, n, E, E, name='adj') if eng.emit_graph else skip()
-            self.info_planes = mk(T, _lib.INFO_WIDTH, n, N) if eng.emit_info else skip()
+            self.info_planes = mk(T, _lib.INFO_WIDTH, n, N, own=True) if eng.emit_info else skip()
             self.edge_nnz = mk(T, n, dtype=torch.int32) if eng.count_edges else skip()
             self.graph_record = mk(T, n, N, eng.step_record_words, dtype=torch.int32) if eng.emit_graph_record else skip()
         pick = lambda a, t: a[t] if a is not None else None  # noqa: E731
         self.sets = [eng.new_output_set(obs=self.obs[t], reward=self.reward[t], done=self.done[t], node_obs=pick(self.node_obs, t),
                                         adj_env=pick(self.adj_env, t), info_planes=pick(self.info_planes, t),
                                         edge_nnz=pick(self.edge_nnz, t), graph_record=pick(self.graph_record, t)) for t in range(T)]
-        per = lambda a: int(a[0].numel()) if a is not None else 0  # noqa: E731
+        per = lambda a: int(a.stride(0)) if a is not None else 0  # noqa: E731  (elements from a slot to the next: a sub-batch's view keeps the batch's)
         self.strides = dict(obs=per(self.obs), node_obs=per(self.node_obs), adj=per(self.adj_env), reward=per(self.reward), done=per(self.done),
                             info=per(self.info_planes), edge_nnz=per(self.edge_nnz), graph_record=per(self.graph_record))
 

@@ -85,10 +85,17 @@ class PipelinedRollout:
             e.rollout(action_tapes[j], mode=mode, ring=rings[j] if rings is not None else None)
         self._each(one)
 
-    def new_rings(self, slots):
-        """One ``OutputRing`` of ``slots`` time slots per sub-batch."""
+    def new_rings(self, slots, like=None):
+        """One ``OutputRing`` of ``slots`` time slots per sub-batch.  ``like``: a ring of the WHOLE batch (an engine of n_envs envs
+        made it) -- sub-batch j's slots are then its envs' part of that ring's slots, so the trajectory of the whole batch ends up
+        in one set of (T, n_envs, ...) arrays whichever way it was stepped."""
         from .engine import OutputRing
-        return [OutputRing(e, slots) for e in self.engines]
+        if like is None:
+            return [OutputRing(e, slots) for e in self.engines]
+        if like.slots != slots or like.engine.n_envs != self.n_envs:
+            raise ValueError('new_rings(like=...): the other ring has %d slots of %d envs, wanted %d of %d'
+                             % (like.slots, like.engine.n_envs, slots, self.n_envs))
+        return [OutputRing(e, slots, like=like, env_range=(j * self.n_sub, self.n_sub)) for j, e in enumerate(self.engines)]
 
     def split_tape(self, action_tape):
         """(T, n_envs, N) -> k contiguous (T, n_envs / k, N) tapes, sub-batch j holding the envs [j n_envs / k, (j + 1) n_envs / k)."""

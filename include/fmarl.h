@@ -314,7 +314,7 @@ int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, i
  * contiguous, but their PHYSICAL memory is interleaved: the array is backed by slots * slot_bytes / piece_bytes physical pieces
  * (hipMemCreate), and virtual piece j of slot t is mapped to physical piece j * slots + t -- every slot is spread evenly over the
  * whole allocation.  Why: MI355X takes a store stream at 5.7-6.0 TB/s when its target is one contiguous 8 GB region and at 6.8-7.1
- * TB/s when the same bytes are spread over 160 GB, even in pieces of 32 MiB (tools/archive/spread_probe.hip, profiles/r4_notes.md) -- a
+ * TB/s when the same bytes are spread over 160 GB, even in pieces of 32 MiB (profiles/r4_spread_probe.txt, profiles/r4_notes.md) -- a
  * launch that writes ONE time slot (a policy in the loop: fmarl_step) gets the rate of the whole ring.  piece_bytes = 0: the
  * library's choice (<= 16 MiB, a divisor of slot_bytes); otherwise a multiple of the allocation granularity that divides
  * slot_bytes.  FMARL_EINVAL when the slot size has no such divisor, FMARL_EHIP when the device has no virtual memory management:
@@ -322,15 +322,20 @@ int fmarl_insert_masks(const uint8_t *done, float *masks, float *active_masks, i
  * fmarl_ring_free returns the physical memory; the array's virtual address range stays reserved, idle, for the life of the process:
  * on this stack the GPU holds on to translations of unmapped addresses, whether the range goes back to the runtime and is reserved
  * again (round 4) or stays with the process and gets fresh pieces mapped into it (round 5: tried, same fault) -- an address that
- * has carried a mapping is never used again (tools/vmm_reuse_probe.py).  The reservations are
- * counted and capped (8 TiB per process; FMARL_RING_RESERVE_CAP_GB overrides): past the cap FMARL_EINVAL -- allocate plainly.
+ * has carried a mapping is never used again (tools/vmm_fault_repro.cpp shows both faults on the bare HIP calls).  The reservations
+ * are counted and capped (8 TiB per process; FMARL_RING_RESERVE_CAP_GB overrides): past the cap FMARL_EINVAL -- allocate plainly.
+ * An array allocated AFTER an earlier one of the process was freed (the only condition a fault was ever seen under) is checked before
+ * it is handed out: a kernel fills it, a kernel reads it back and leaves zeroes; if a word is wrong the array is released, the event
+ * logged to stderr and FMARL_EHIP returned -- allocate plainly (FMARL_RING_VERIFY=1 checks every array, =0 none).  fmarl_ring_free
+ * waits for the device itself (hipDeviceSynchronize) before it unmaps.
  * Access is granted to the allocating device; with FMARL_RING_PEER_ACCESS=1 in the environment also to every device that has peer
  * access to it (hipMalloc memory is peer-accessible once peer access is enabled, an array of pieces only for the devices named). */
 int fmarl_ring_alloc(size_t slot_bytes, int slots, size_t piece_bytes, void **base, void **cookie);
 int fmarl_ring_free(void *cookie);
 /* The allocator's books: out[0] bytes of address space reserved so far, [1] of them idle (ranges of freed arrays), [2] ranges
- * reserved, [3] of them idle, [4] the cap on [0] in bytes, [5] requests refused at the cap. */
-int fmarl_ring_stats(uint64_t out[6]);
+ * reserved, [3] of them idle, [4] the cap on [0] in bytes, [5] requests refused at the cap, [6] arrays checked by a kernel's fill
+ * before they were handed out, [7] of them refused because they did not hold it. */
+int fmarl_ring_stats(uint64_t out[8]);
 
 /* --- pieces exported on their own -------------------------------------------------------- */
 

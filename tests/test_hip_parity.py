@@ -299,6 +299,29 @@ def _run_ranks(script_args, world=2, timeout=600):
     return res.stdout
 
 
+def _bench_records(out):
+    """(the compact stdout line, the full detail record) of a bench.py run whose stdout and stderr were captured together: exactly one
+    line starts with '{' -- the one the driver parses, at most bench.COMPACT_LIMIT bytes of strict JSON -- and exactly one carries the
+    detail behind bench.DETAIL_PREFIX; the two agree wherever both hold a key."""
+    import json
+    import bench
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-4000:]
+    assert len(lines[0].encode()) <= bench.COMPACT_LIMIT, len(lines[0])
+    c = json.loads(lines[0], parse_constant=lambda k: pytest.fail('non-strict JSON constant %s' % k))
+    det = [l for l in out.splitlines() if l.startswith(bench.DETAIL_PREFIX)]
+    assert len(det) == 1, out[-4000:]
+    d = json.loads(det[0][len(bench.DETAIL_PREFIX):])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        assert c[key] == (pytest.approx(d[key], rel=1e-5) if isinstance(d[key], float) else d[key]), key
+    for sect, keys in (('config', bench._CONFIG_KEYS), ('roofline', bench._ROOFLINE_KEYS)):
+        assert set(c[sect]) == set(keys)
+        for key in keys:
+            assert c[sect][key] == (pytest.approx(d[sect][key], rel=1e-5) if isinstance(d[sect][key], float) else d[sect][key]), (sect, key)
+    assert all(' ' not in str(c['config'][k]) for k in ('launch_mode', 'slots', 'reset', 'exchange'))
+    return c, d
+
+
 def test_two_ranks_gather_reproduces_the_unsharded_rollout():
     """The N > 1 path of bench.py with real processes on the GPU: two ranks step their shards, rank 0 gathers the
     step and episode records (gloo: RCCL needs one GPU per rank) and rebuilds node_obs / adj; everything must equal
@@ -316,7 +339,7 @@ def test_two_ranks_gather_reproduces_the_unsharded_rollout():
 
 @pytest.mark.parametrize('world,extra', [(2, []), (4, ['--learner-rebuild', '2']), (2, ['--launch', 'step']),
                                          (3, ['--span-steps', '25', '--learner-rebuild', '1']), (2, ['--launch', 'step', '--learner-rebuild', '1'])])
-def test_bench_multi_rank_rehearsal(world, extra):
+def test_bench_multi_rank_rehearsal(world, extra, tmp_path):
     """bench.py's own multi-rank loops with ranks sharing the GPU over gloo -- runs of steps as spans, their records gathered with ONE
     collective per run (the default for every N: the launch mode does not depend on the number of GPUs; with a gather the runs are
     GATHER_SPAN_STEPS long), whole-episode runs (--span-steps 25) and --launch step: one gather per step -- record rotation, gathers
@@ -324,17 +347,19 @@ def test_bench_multi_rank_rehearsal(world, extra):
     own time per step, what each waited for the exchange, what rank 0 receives, the same steps without the exchange
     (scaling_base) and -- with --learner-rebuild -- what it costs rank 0 to turn peers' gathered steps back into node_obs / adj
     inside the timed loop."""
-    import json
     import bench
     out = _run_ranks([os.path.join(os.path.dirname(HERE), 'bench.py'), '--gpus', str(world), '--backend', 'gloo', '--n-envs', '512',
-                      '--steps', '30', '--warmup', '5'] + extra, world=world)
-    lines = [l for l in out.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, out[-4000:]
-    d = json.loads(lines[0])
+                      '--steps', '30', '--warmup', '5', '--detail', str(tmp_path / 'detail.json')] + extra, world=world)
+    c, d = _bench_records(out)       # c: the line the driver parses; d: the full record
     span = 'step' not in extra
     whole = '--span-steps' in extra
-    assert d['n_gpus'] == world and d['steps'] == 30 and d['scaling'] == 'weak' and 'gather' in d['config']['exchange']
-    assert d['config']['launch_mode'] == ('span' if span else 'step') and d['config']['slots'].startswith('ring')
+    assert d['n_gpus'] == world and d['steps'] == 30 and d['scaling'] == 'weak'
+    assert d['config']['exchange'] == 'gloo-gather-per-' + ('run' if span else 'step') and 'gather' in d['config']['exchange_text']
+    assert d['config']['launch_mode'] == ('span' if span else 'step') and d['config']['slots'] == 'ring' and d['config']['slots_text'].startswith('ring')
+    # the compact line's N > 1 block: what a scaling figure needs to explain itself, as scalars (VERDICT round 5, items 1 and 8)
+    cm = c['multi_gpu']
+    assert len(cm['per_rank_ms_per_step']) == world and c['scaling_base']['efficiency'] == pytest.approx(d['scaling_base']['efficiency'], rel=1e-5)
+    assert cm['warmup_steps_actually_run'] == d['multi_gpu']['warmup_steps_actually_run'] and c['detail'] == 'detail.json'
     assert d['value'] == pytest.approx(world * 512 * 32 * 30 / (d['ms_per_step'] * 30e-3), rel=1e-6)
     assert 'cpu_baseline' not in d and d['n_ranks_seen'] == world
     # the timed steps start at episode phase 5: warm-up [0, 5), (runs of steps without --span-steps: the tuning passes, then back to phase
@@ -350,6 +375,11 @@ def test_bench_multi_rank_rehearsal(world, extra):
             assert [r['span_steps'] for r in st['candidates']] == list(bench.SPAN_TUNE_CANDIDATES) and st['chosen'] == L
             assert L == bench.pick_span_length(st['candidates'])['span_steps']
             assert all(r['ms_per_step'] > 0 and r['stall_frac'] >= 0 for r in st['candidates'])
+            assert st['admissible'] == sum(1 for r in st['candidates'] if r['stall_frac'] < bench.SPAN_TUNE_STALL) == cm['span_tuning']['admissible']
+            assert cm['span_tuning']['chosen'] == L and [r[0] for r in cm['span_tuning']['candidates']] == list(bench.SPAN_TUNE_CANDIDATES)
+            # the untimed steps before the region: warm-up 5, the tuning passes (4 runs per candidate), back to phase 5, then twice (30 + 20)
+            tuned = sum(bench.SPAN_TUNE_RUNS * k for k in bench.SPAN_TUNE_CANDIDATES)
+            assert st['steps_run'] == tuned and m['warmup_steps_actually_run'] == 5 + tuned + (-tuned) % 25 + 100
         runs = bench.span_schedule(5, 30, 25, L, True)
         assert sum(runs) == 30 and runs[-1] == 1
         # a run that reaches the episode end (phase 24) leaves its last step to the episode-ending launch; a run of one step is a step launch
@@ -365,6 +395,7 @@ def test_bench_multi_rank_rehearsal(world, extra):
     else:
         assert d['roofline']['kernel_launches'] == 30 and d['roofline']['kernel_steps_per_launch'] == 1.0
         assert 'span_tuning' not in d['multi_gpu'] and 'ideal_vs_n1_headline' not in d['multi_gpu']
+        assert d['multi_gpu']['warmup_steps_actually_run'] == 5 + 30 + 20 and 'span_tuning' not in cm
     assert '512 envs per GPU' in d['config']['workload'] and d['roofline']['traffic'] is None   # --n-envs: no replayed 65 536-env counters
     assert 'secondary' not in d and d['config']['auto_resets_timed'] == 1
     m = d['multi_gpu']
@@ -385,7 +416,7 @@ def test_bench_multi_rank_rehearsal(world, extra):
         assert 'learner_rebuild' not in m
 
 
-def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus():
+def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus(tmp_path):
     """The driver's command (--steps 20 --warmup 5) at one rank and at two (gloo ranks sharing this box's GPU): the same launch
     mode, the same kernel, time slots on both sides -- a scaling figure compares like with like."""
     import json
@@ -393,11 +424,12 @@ def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus():
     import sys
     root = os.path.dirname(HERE)
     res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--n-envs', '1024',
-                          '--no-cpu-baseline'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=root)
+                          '--no-cpu-baseline', '--detail', str(tmp_path / 'one.json')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=root)
     assert res.returncode == 0, res.stdout[-4000:]
-    one = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][0])
-    out = _run_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--n-envs', '1024', '--steps', '20', '--warmup', '5'], world=2)
-    two = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+    _, one = _bench_records(res.stdout)
+    out = _run_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--n-envs', '1024', '--steps', '20', '--warmup', '5',
+                      '--detail', str(tmp_path / 'two.json')], world=2)
+    _, two = _bench_records(out)
     assert one['config']['launch_mode'] == two['config']['launch_mode'] == 'span'
     assert one['roofline']['kernel'] == two['roofline']['kernel'] == 'step_span_kernel'
     assert one['roofline']['slots'] == two['roofline']['slots'] == 'ring'
@@ -407,7 +439,7 @@ def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus():
     assert two['multi_gpu']['span_tuning']['chosen'] == two['config']['span_steps'] and two['multi_gpu']['ideal_vs_n1_headline'] > 0
 
 
-def test_bench_exchange_through_rccl_with_one_rank():
+def test_bench_exchange_through_rccl_with_one_rank(tmp_path):
     """The nccl (= RCCL) branch of sharding.py / bench.py on the one GPU of this box: a process group of ONE rank, every
     step's record and every episode record gathered through RCCL inside the timed loop, all_reduce for the timing."""
     import json
@@ -415,13 +447,13 @@ def test_bench_exchange_through_rccl_with_one_rank():
     import sys
     root = os.path.dirname(HERE)
     res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--rccl-selftest', '--n-envs', '2048', '--steps', '60',
-                          '--warmup', '10', '--no-cpu-baseline'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                          '--warmup', '10', '--no-cpu-baseline', '--detail', str(tmp_path / 'd.json')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                          timeout=600, cwd=root)
     assert res.returncode == 0, res.stdout[-4000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
-    assert len(lines) == 1, res.stdout[-4000:]
-    d = json.loads(lines[0])
-    assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1 and d['config']['exchange'].startswith('RCCL (process group of one rank')
+    c, d = _bench_records(res.stdout)
+    assert json.load(open(str(tmp_path / 'd.json'))) == d and c['reference_cpu']['value'] == 1662.0
+    assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1 and d['config']['exchange'] == 'rccl-selftest-gather-per-step'
+    assert d['config']['exchange_text'].startswith('RCCL (process group of one rank')
     assert d['roofline']['traffic'] is None and d['roofline']['traffic_source'] is None and '2048 envs' in d['config']['workload']
     assert d['reference_cpu']['value'] == 1662.0
     assert d['multi_gpu']['bytes_received_by_rank0_per_step'] == 0 and d['multi_gpu']['bytes_gathered_per_step'] == 2048 * 32 * 33
@@ -590,6 +622,40 @@ def test_pipelined_sub_batches_reproduce_the_single_engine(kw, k):
     assert torch.equal(pipe.gather('obs'), whole.obs)
     with pytest.raises(ValueError):
         fm.PipelinedRollout(cfg, 97, k=2, device=DEV)
+
+
+@pytest.mark.parametrize('kw', SHARD_CASES, ids=lambda kw: kw.get('scenario_name', 'navigation_graph'))
+@pytest.mark.parametrize('mode', ['eager', 'span'])
+def test_pipelined_sub_batches_fill_the_whole_batchs_time_slots(kw, mode):
+    """``PipelinedRollout.new_rings(like=ring)``: the sub-batches write their envs' part of the WHOLE batch's (T, n, ...) time slots
+    (``OutputRing(env_range=...)``: the arrays cut along the env axis, the step-to-step stride the whole batch's) -- one launch per
+    sub-batch and step, or as spans -- and every slot of a two-episode rollout equals what ONE engine over all envs wrote, bit for bit
+    (bench.py's (cfg3, pipeline2) entry on the headline's arrays)."""
+    cfg = fm.EnvConfig(**dict(kw, episode_length=6))
+    n, N, T = 128, cfg.N, 12
+    whole = fm.RolloutEngine(cfg, n, device=DEV, seed=31)
+    ring_w = fm.OutputRing(whole, T)
+    other = fm.RolloutEngine(cfg, n, device=DEV, seed=31)
+    ring_p = fm.OutputRing(other, T)
+    for a in (ring_p.obs, ring_p.reward, ring_p.node_obs, ring_p.adj_env):
+        a.fill_(float('nan'))
+    pipe = fm.PipelinedRollout(cfg, n, k=2, device=DEV, seed=31)
+    rings = pipe.new_rings(T, like=ring_p)
+    assert rings[1].node_obs.data_ptr() == ring_p.node_obs[0, n // 2].data_ptr() and rings[0].strides['node_obs'] == ring_p.strides['node_obs']
+    assert rings[0].strides['obs'] == n * N * cfg.obs_dim and rings[0].info_planes.shape == (T, 14, n // 2, N)
+    g = torch.Generator(device=DEV); g.manual_seed(12)
+    tape = torch.randint(0, 5, (T, n, N), device=DEV, generator=g, dtype=torch.int32)
+    whole.reset(); pipe.reset()
+    whole.rollout(tape, mode=mode, ring=ring_w)
+    pipe.rollout(pipe.split_tape(tape), mode=mode, rings=rings)
+    pipe.synchronize(); torch.cuda.synchronize()
+    for name in ('obs', 'reward', 'done', 'node_obs', 'adj_env'):
+        assert torch.equal(getattr(ring_w, name), getattr(ring_p, name)), name
+    assert torch.equal(ring_w.info_planes, torch.cat([r.info_planes for r in rings], dim=2))
+    with pytest.raises(ValueError):
+        pipe.new_rings(T - 1, like=ring_p)
+    with pytest.raises(ValueError):
+        fm.OutputRing(pipe.engines[0], T, env_range=(0, n // 2))
 
 
 def test_index_math_beyond_2_to_the_32_elements():
@@ -1887,9 +1953,13 @@ def test_time_slots_after_a_freed_array_keep_what_is_written():
     import time
     from fair_marl_amd import _lib
     from fair_marl_amd.engine import alloc_time_slots
+    import ctypes as C
     lib = _lib.load()
     shapes = [(2, 32768, 10, 16, 12), (2, 32768, 3, 9, 13), (2, 32768, 10, 16, 12), (2, 32768, 3, 9, 13), (2, 32768, 6, 16, 11),
               (2, 32768, 10, 16, 12), (2, 32768, 6, 16, 11)]
+    stats = (C.c_uint64 * 8)()
+    assert lib.fmarl_ring_stats(stats) == 0
+    checked0, failed0 = int(stats[6]), int(stats[7])
     for k, shape in enumerate(shapes):
         t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
         assert interleaved
@@ -1902,8 +1972,11 @@ def test_time_slots_after_a_freed_array_keep_what_is_written():
         assert int((flat.cpu() != float(k + 1)).sum()) == 0, 'array %d copied to the host' % k
         assert int((flat != float(k + 1)).sum()) == 0, 'array %d after the copy' % k
         del t, flat
-        gc.collect()
-        torch.cuda.synchronize()
+        gc.collect()   # (no synchronize here: fmarl_ring_free waits for the device itself)
+    # every array that followed a freed one was filled and read back by kernels before it was handed out (automatic: VERDICT round 5, 6 b),
+    # and none was refused
+    assert lib.fmarl_ring_stats(stats) == 0
+    assert int(stats[6]) - checked0 >= len(shapes) - 1 and int(stats[7]) == failed0
 
 
 def test_time_slot_allocator_keeps_books_and_a_cap():
@@ -1920,7 +1993,7 @@ def test_time_slot_allocator_keeps_books_and_a_cap():
     lib = _lib.load()
     gc.collect()
     torch.cuda.synchronize()
-    stats = (C.c_uint64 * 6)()
+    stats = (C.c_uint64 * 8)()
 
     def read():
         assert lib.fmarl_ring_stats(stats) == 0
@@ -1942,10 +2015,16 @@ def test_time_slot_allocator_keeps_books_and_a_cap():
         torch.cuda.synchronize()
         a = read()
         assert a[1] - b[1] == (k + 1) * nbytes and a[3] - b[3] == k + 1
-    os.environ['FMARL_RING_VERIFY'] = '1'   # (the opt-in kernel fill / read-back of a fresh array)
+    # the kernel fill / read-back of an array that follows a freed one leaves zeroes and is counted; FMARL_RING_VERIFY=0 switches it off
+    c0 = read()
+    t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
+    c1 = read()
+    assert interleaved and int((t != 0).sum()) == 0 and c1[6] == c0[6] + 1 and c1[7] == c0[7]
+    del t
+    os.environ['FMARL_RING_VERIFY'] = '0'
     try:
         t, interleaved = alloc_time_slots(lib, DEV, shape, spread=True)
-        assert interleaved and int((t != 0).sum()) == 0
+        assert interleaved and read()[6] == c1[6]
         del t
     finally:
         del os.environ['FMARL_RING_VERIFY']
@@ -1955,7 +2034,7 @@ def test_time_slot_allocator_keeps_books_and_a_cap():
             "a, ia = alloc_time_slots(lib, dev, shape, spread=None); del a; torch.cuda.synchronize()\n"
             "b, ib = alloc_time_slots(lib, dev, shape, spread=None)   # past the cap of 0.3 GiB: a plain allocation\n"
             "b.fill_(2.0); ok = int((b != 2.0).sum()) == 0\n"
-            "s = (C.c_uint64 * 6)(); lib.fmarl_ring_stats(s)\n"
+            "s = (C.c_uint64 * 8)(); lib.fmarl_ring_stats(s)\n"
             "try:\n    alloc_time_slots(lib, dev, shape, spread=True); raised = False\nexcept MemoryError as e:\n    raised = 'FMARL_RING_RESERVE_CAP_GB' in str(e)\n"
             "print('RESULT', ia, ib, ok, int(s[5]), raised)\n")
     env = dict(os.environ, FMARL_RING_RESERVE_CAP_GB='0.3', PYTHONPATH=os.path.dirname(HERE))
