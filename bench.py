@@ -345,6 +345,11 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
         span_text = ('fmarl_step_span: the %d steps of the tape as ONE launch (%d envs per workgroup); episodes end env by env and the step '
                      'resets them itself; the state stays in registers between the steps (three waves per workgroup)' % (ep, eng.envs_per_workgroup))
     steps_per_launch = (c1[0] - c0[0]) / max(1, len(kernel_ms))
+    if rmode == 'span' and steps_per_launch <= 1.0:
+        # fmarl_step_span launches per step where a span form does not pay (nav_fairassign_fairrew_formation_graph beyond five agents:
+        # profiles/r6_fnav10_summary.md): say which kernel ran
+        kern = KERNEL_NAMES.get(cfg.scenario_name, kern)
+        span_text += '; at this shape the library launches per step inside fmarl_step_span'
     epw = eng.envs_per_workgroup
     ring_bytes = ring.nbytes if ring is not None else 0
     # (on the pages the kernel wrote: the ring's node_obs slots, else the engine's node_obs)

@@ -95,6 +95,7 @@ _SIGS = {
     'fmarl_launch_geometry': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'fmarl_poison_lds': (C.c_int, [C.c_void_p, C.c_void_p]),
     'fmarl_insert_masks': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    'fmarl_store_pattern': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
     'fmarl_ring_alloc': (C.c_int, [C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'fmarl_ring_free': (C.c_int, [C.c_void_p]),
     'fmarl_ring_stats': (C.c_int, [C.POINTER(C.c_uint64)]),

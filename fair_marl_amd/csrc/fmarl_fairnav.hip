@@ -188,22 +188,25 @@ __device__ __forceinline__ int lexifair_upto3(const double *D, int L, int N, int
     return (int)((codes >> (6 * best + 2 * (lane < 3 ? lane : 0))) & 3ull);
 }
 
+// `reset_match`: the assignment of the envs that were reset inside this step (marked in words()[2]), written straight into the state
+// (goal_match of the workgroup's first env): nothing in the step reads it -- no table, no barrier behind it.
 template <int G, int THREADS>
-__device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, bool only_flagged) {
+__device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, int *reset_match) {
     const int group = threadIdx.x / G, ngroups = THREADS / G, lane = threadIdx.x % G;
     for (int el = group; el < nenv; el += ngroups) {
         const FairNavLds t(p, lds, el);
-        if (only_flagged && t.skip()) continue;   // (group-uniform)
+        if (reset_match && t.words()[2] == 0) continue;   // (group-uniform)
+        int *out = reset_match ? reset_match + (size_t)el * p.N : t.match();
         if (G == 4 && p.N <= 3) {
             const int mc = lexifair_upto3<G>(t.D(), p.L, p.N, lane);
-            if (lane < p.N) t.match()[lane] = mc;
+            if (lane < p.N) out[lane] = mc;
             continue;
         }
         double c[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) c[j] = (lane < p.N && j < p.N) ? t.D()[lane * p.L + j] : 0.0;
         const int mc = lexifair_group<G>(c, p.N);
-        if (lane < p.N) t.match()[lane] = mc;
+        if (lane < p.N) out[lane] = mc;
     }
 }
 
@@ -285,6 +288,107 @@ struct PlacedEnvLds {
         return hit;
     }
 };
+
+// The in-kernel reset's placement by TEAMS of lanes (round 6).  One lane per ended env walked the reference's rejection sampling
+// alone -- every distance test a dependent LDS round trip, 8 900 cycles per placement at three agents while the other 191 lanes of
+// the workgroup waited at the barrier (profiles/r5_ticks_fnav_steady.txt).  Here every ended env gets a team of 16 (32, 64) lanes, all
+// of them idle in this phase anyway: lane j of the team HOLDS entity j (placement order: obstacles, agents, goals) in registers.  The
+// sequence stays the reference's -- one candidate per Philox block, in stream order, accepted or rejected before the next one is
+// looked at, so the stream consumption and every decision are the sequential walk's, bit for bit -- but a candidate's tests run side
+// by side: each lane tests the candidate against the entity it holds (the threshold of its kind), one ballot says whether any hit,
+// and the lane of the slot being filled takes the candidate.  A trip of the loop is a dozen vector instructions and a ballot; the
+// next block's LDS read is issued a trip ahead.  Which team takes which env comes from the envs' flags (ballots every wave takes for
+// itself: no worklist, no extra barrier).  Entities beyond 64 per env: the one-lane walk (place_env).
+__device__ __forceinline__ double u_lin(double lo, double hi, double a) { return lo + (hi - lo) * a; }   // PhiloxStream::uniform's expression
+template <int THREADS>
+__device__ __forceinline__ void fairnav_place_teams(const Params &p, char *lds, int env0, int nenv, int n_pre) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int O = p.O, N = p.N, L = p.L, W = p.W, slots = O + N + L;
+    const int ts_log = slots <= 16 ? 4 : (slots <= 32 ? 5 : 6), TS = 1 << ts_log;
+    const int j = tid & (TS - 1), team = tid >> ts_log, nteams = THREADS >> ts_log;
+    const uint64_t tmask = TS == 64 ? ~0ull : ((1ull << TS) - 1ull);
+    const int tshift = lane & ~(TS - 1);
+    // the ended envs (flag 0: fairnav_pass), every wave for itself
+    const uint64_t m0 = __ballot(lane < nenv && !FairNavLds(p, lds, lane).skip());
+    const uint64_t m1 = nenv > 64 ? __ballot(lane + 64 < nenv && !FairNavLds(p, lds, lane + 64).skip()) : 0ull;
+    const int c0 = __popcll(m0), n_ended = c0 + __popcll(m1);
+    const double ws = p.world_size;
+    const double thr = 1.05 * (kEntitySize + kEntitySize), thr_goal = 1.2 * (kEntitySize + kEntitySize);   // nf:643
+    const double thr_obs = 2.0 * (kEntitySize + kEntitySize);                                              // nf:592-613
+    for (int first = 0; first < n_ended; first += nteams) {
+        const int kth = first + team;
+        if (kth >= n_ended) continue;   // (team-uniform; the ballots below only count the lanes that are here)
+        uint64_t m = kth < c0 ? m0 : m1;
+        for (int q = kth < c0 ? kth : kth - c0; q > 0; --q) m &= m - 1;
+        const int el = (kth < c0 ? 0 : 64) + __ffsll((unsigned long long)m) - 1;
+        const FairNavLds te(p, lds, el);
+        const int env = env0 + el, epi = *te.episode();
+        const uint32_t genv = (uint32_t)(p.env_offset + env);
+        // the first blocks of the env's stream: lane j of the team draws block j into the env's part of the second LDS region (its
+        // tables there are dead by now); the team's lanes share a wave, so a wavefront-scope fence is all that orders write and reads
+        double *pre = te.predraw();
+        const int n_team = n_pre < TS ? n_pre : TS;
+        double a, b;
+        if (j < n_team) {
+            philox_block(p.seed, (uint32_t)j, genv, (uint32_t)epi, a, b);
+            pre[2 * j] = a; pre[2 * j + 1] = b;
+        }
+        wave_sync();
+        auto block = [&](int idx, double &a, double &b) {
+            if (idx < n_team) { a = pre[2 * idx]; b = pre[2 * idx + 1]; }
+            else philox_block(p.seed, (uint32_t)idx, genv, (uint32_t)epi, a, b);
+        };
+        block(0, a, b);
+        const double wlen = u_lin(0.2, 0.8, a) * p.world_size / 4;   // nf:239-241
+        double2 mine = make_double2(0.0, 0.0);
+        if (j < O) {   // nf:271-275, every obstacle by its own lane
+            block(1 + j, a, b);
+            mine = make_double2(0.8 * u_lin(-ws / 2, ws / 2, a), 0.8 * u_lin(-ws / 2, ws / 2, b));
+        }
+        block(1 + O, a, b);
+        const double wall_position = u_lin(0.2, 0.9, a);   // :288, drawn even without walls
+        double axis0 = 0.0, axis1 = 0.0;   // :294-324 (W <= 2; scalars, not arrays: a run-time index would put them in scratch memory)
+        int orient0 = 0, orient1 = 0;
+        if (W > 0) { block(2 + O, a, b); orient0 = a < 0.5 ? 0 : 1; axis0 = wall_position * ws / 2; }
+        if (W > 1) { block(3 + O, a, b); orient1 = a < 0.5 ? 0 : 1; axis1 = -wall_position * ws / 2; }
+        int idx = 2 + O + W, e = O, tries = 0, fails = 0;
+        double an, bn;
+        block(idx, a, b);
+        block(idx + 1, an, bn);
+        while (e < slots) {   // :389-457 agents, :472-535 goals
+            const bool goal = e >= O + N;
+            double2 x = make_double2(u_lin(-ws / 2, ws / 2, a), u_lin(-ws / 2, ws / 2, b));
+            if (goal) x = make_double2(0.8 * x.x, 0.8 * x.y);
+            const bool relevant = j < O || (j >= (goal ? O + N : O) && j < e);
+            bool hit = relevant && closer_than(mine, x, j < O ? thr_obs : (goal ? thr_goal : thr));
+            if (W > 0) hit |= wall_box_hit_pad15(x, axis0, -wlen, wlen, orient0);
+            if (W > 1) hit |= wall_box_hit_pad15(x, axis1, -wlen, wlen, orient1);
+            const bool bad = ((__ballot(hit) >> tshift) & tmask) != 0;
+            ++tries;
+            if (!bad || tries >= kMaxTries) {
+                fails += bad ? 1 : 0;
+                if (j == e) mine = x;
+                ++e; tries = 0;
+            }
+            ++idx;
+            a = an; b = bn;
+            block(idx + 1, an, bn);
+        }
+        // every lane stores the entity it holds: into the env's float64 table (what the re-seated lanes read) and into the state
+        if (j < O) { te.pos()[N + L + j] = mine; p.obstacle_pos[(size_t)env * O + j] = mine; }
+        else if (j < O + N) te.pos()[j - O] = mine;   // (into the state by the agent's own lane when it re-seats: behind its terminal step's store)
+        else if (j < slots) { te.pos()[N + (j - O - N)] = mine; p.landmark_pos[(size_t)env * L + (j - O - N)] = mine; }
+        if (j == 0) {
+            p.wall_length[env] = wlen;
+            const size_t g = (size_t)env * W;
+            if (W > 0) { p.wall_orient[g] = orient0; p.wall_axis[g] = axis0; p.wall_e0[g] = -wlen; p.wall_e1[g] = wlen; }
+            if (W > 1) { p.wall_orient[g + 1] = orient1; p.wall_axis[g + 1] = axis1; p.wall_e0[g + 1] = -wlen; p.wall_e1[g + 1] = wlen; }
+            p.place_fails[env] = fails;
+            p.episode[env] = epi + 1;
+            *te.episode() = epi + 1;
+        }
+    }
+}
 
 // One pass over the workgroup's envs.
 //   STEP = true : one env step (MultiAgentGraphEnv.step, environment.py:816-877).  Envs whose agents are all done (stop-on-goal
@@ -372,10 +476,10 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICK(2);   // distance table
     if (STEP && !FMARL_SKIP(p, 64)) {
         // reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721)
-        if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, false);
-        else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, false);
-        else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, false);
-        else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, false);
+        if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, nullptr);
+        else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, nullptr);
+        else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, nullptr);
+        else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, nullptr);
     } else if (active) {
         t.match()[i] = p.goal_match[g];
     }
@@ -449,7 +553,8 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             } else {
                 p.agent_pos[g] = x; p.agent_vel[g] = vout; p.p_dist[g] = pd; p.status[g] = (int8_t)status;
                 p.dists_to_goal[g] = Dg_new; p.times_required[g] = Tr_new; p.dist_left[g] = left; p.goal_reached[g] = (int8_t)gr;
-                p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac; p.goal_match[g] = t.match()[i];
+                p.num_obst_coll[g] = noc; p.num_agent_coll[g] = nac;
+                if (!ended) p.goal_match[g] = t.match()[i];   // (an env that is reset below: the new episode's assignment, by the lanes that solve it)
                 if (i == 0) p.cur_step[env] = step;
             }
             if (o.reward) o.reward[g] = (float)rew;
@@ -481,7 +586,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
         // state stores and table reads above from the placement's stores to the same fields and its writes to the tables.)
         // (flag: marks the envs the pre-draw and the restricted assignment below work on; written here so that the barrier that
         // decides whether any env ended also publishes it -- nothing between the previous barrier and this point reads the flags)
-        if (in_range && i == 0 && auto_reset) *t.flag() = ended ? 0 : 1;
+        if (in_range && i == 0 && auto_reset) { *t.flag() = ended ? 0 : 1; t.words()[2] = ended ? 1 : 0; }
         if (__syncthreads_or(ended)) {
             if (in_range && i == 0) p.reset_flag[env] = ended ? 1 : 0;
             // The placement is the reference's sequential rejection sampling on the env's own Philox stream, by ONE lane per ended
@@ -489,24 +594,30 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             // with episodes ending at all phases (profiles/r4_ticks_fnav_steady.txt).  The blocks are counter-based, so the first
             // p.n_pre of them are drawn here by all lanes side by side (one block each) into the env's part of the second LDS
             // region (its tables there are dead by now); the placing lane then only reads them and runs the distance tests.
+            // (Round 6: where teams place -- fairnav_place_teams -- a team draws its env's blocks itself and the workgroup's pre-draw pass
+            // with its barrier is gone; the lanes of a team share a wave, LDS keeps a wave's accesses in order.)
             const int n_pre = p.n_pre;
-            for (int task = tid; task < nenv * n_pre; task += THREADS) {
-                const int e_l = task / n_pre, b = task - e_l * n_pre;
-                const FairNavLds te(p, lds, e_l);
-                if (te.skip()) continue;
-                double u0, u1;
-                philox_block(p.seed, (uint32_t)b, (uint32_t)(p.env_offset + env0 + e_l), (uint32_t)*te.episode(), u0, u1);
-                te.predraw()[2 * b] = u0; te.predraw()[2 * b + 1] = u1;
+            const bool teams = p.O + N + L <= 64;
+            if (!teams) {
+                for (int task = tid; task < nenv * n_pre; task += THREADS) {
+                    const int e_l = task / n_pre, b = task - e_l * n_pre;
+                    const FairNavLds te(p, lds, e_l);
+                    if (te.skip()) continue;
+                    double u0, u1;
+                    philox_block(p.seed, (uint32_t)b, (uint32_t)(p.env_offset + env0 + e_l), (uint32_t)*te.episode(), u0, u1);
+                    te.predraw()[2 * b] = u0; te.predraw()[2 * b + 1] = u1;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            FMARL_TICK(11);   // (measure builds) the barrier that found ended envs, the pre-draw
-            if (in_range && i == 0 && ended) {
+            FMARL_TICK(11);   // (measure builds) the barrier that found ended envs (+ the pre-draw pass of the one-lane walk)
+            if (teams) fairnav_place_teams<THREADS>(p, lds, env0, nenv, n_pre);   // a team of lanes per ended env
+            else if (in_range && i == 0 && ended) {   // more than 64 entities: the first lane of the env walks alone
                 PlacedEnvLds pl{t.pos(), p, env};
                 const int epi = *t.episode();
                 place_env(p, pl, kResetAuto, env, kPlaceEntities, epi, t.predraw(), n_pre);
                 *t.episode() = epi + 1;
             }
-            FMARL_TICK(12);   // (measure builds) the placement itself, by the first lane of every ended env
+            FMARL_TICK(12);   // (measure builds) the placement itself
             __threadfence_block();   // (walls: the static entities of the placed envs are re-read from the state below)
             __syncthreads();
             if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
@@ -525,7 +636,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                     c.bits = fairnav_pack(0.0, 0, -1.0, 0); c.hits = 0;
                 }
                 else {   // (a span's inner step: the last step of the launch stores these from the registers)
-                    p.agent_vel[g] = make_double2(0.0, 0.0); p.p_dist[g] = 0.0; p.status[g] = 0;
+                    p.agent_pos[g] = nx; p.agent_vel[g] = make_double2(0.0, 0.0); p.p_dist[g] = 0.0; p.status[g] = 0;
                     p.times_required[g] = -1.0; p.dists_to_goal[g] = -1.0; p.dist_left[g] = -1.0; p.goal_reached[g] = -1;
                     p.num_obst_coll[g] = 0; p.num_agent_coll[g] = 0; p.goal_occ[g] = 0.0; p.goal_history[g] = -1;
                     if (i == 0) p.cur_step[env] = 0;
@@ -544,15 +655,14 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             // the assignment of the new episode (nf:469): nothing in this step reads it (the walk, the observation and the rows do not
             // know the assignment; every step assigns afresh inside reward(agent 0)) -- it is state, and inside a span the last step
             // of the launch stores its own: skipped there, with its barrier
-            if (!keep) {
-                if (!FMARL_SKIP(p, 64)) {
-                    if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, true);
-                    else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, true);
-                    else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, true);
-                    else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, true);
-                }
-                __syncthreads();
-                if (ended) p.goal_match[g] = t.match()[i];
+            // (round 6: straight into the state by the lanes that solve it -- no table entry, no barrier, no store by the env's own lanes
+            // behind one; the envs it is for are marked in words()[2], the flags go back to "every env emits" at once)
+            if (!keep && !FMARL_SKIP(p, 64)) {
+                int *gm = p.goal_match + (size_t)env0 * N;
+                if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, gm);
+                else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, gm);
+                else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, gm);
+                else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, gm);
             }
             if (in_range && i == 0) *t.flag() = 0;   // every env emits (read again behind the walk's barriers)
         } else if (in_range && i == 0) *t.flag() = 0;    // (no env of the workgroup ended)
@@ -660,9 +770,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_kerne
 // All arguments are one struct, re-read from the argument block inside the time loop (span_params_reloaded): held in scalar
 // registers across a whole step -- shapes, eight output pointers, nine strides -- they spill twice as many registers.
 struct FairnavSpanArgs { Params p; FmarlOutputs o; SpanStrides s; const int32_t *action_idx; const float *action_vec; int T, auto_reset; };
+// Shapes with more than 192 agent lanes per workgroup (N >= 4) run 256 threads wide, and there the carry does not pay: at three
+// workgroups per CU (168 registers, what the carry needs) the 10-agent shape took 0.775 ms per step against 0.634 for one launch per
+// step at four (profiles/r6_fnav10_summary.md) -- its step is bound by the assignment and the sequential walk, which want the fourth
+// workgroup's waves, not by the state's 100 bytes per agent.  So <256> sends the state through global memory between the steps (every
+// field is read back by the lane -- or, the env's counters, by the workgroup -- that stored it, behind the barrier) at four per CU.
+#ifndef FMARL_FNAV256_CARRY
+#define FMARL_FNAV256_CARRY 0
+#endif
+#ifndef FMARL_FNAV256_BLOCKS
+#define FMARL_FNAV256_BLOCKS (FMARL_FNAV256_CARRY ? 3 : 4)
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 3) void fairnav_span_kernel(FairnavSpanArgs) {
+__global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : FMARL_FNAV256_BLOCKS) void fairnav_span_kernel(FairnavSpanArgs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool kCarry = THREADS == 192 || FMARL_FNAV256_CARRY;
     FairnavCarry c = {};
     for (int t = 0;; ++t) {
         const FairnavSpanArgs &a = span_params_reloaded<FairnavSpanArgs>();
@@ -670,8 +792,8 @@ __global__ __launch_bounds__(THREADS, 3) void fairnav_span_kernel(FairnavSpanArg
         const FmarlOutputs ot = span_outputs(a.o, a.s, t);
         fairnav_pass<true, THREADS>(a.p, ot, lds, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
                                     a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset, c,
-                                    (t > 0 ? 1 : 0) | (t < a.T - 1 ? 2 : 0));
-        __syncthreads();   // the next step overwrites the LDS tables the emission read
+                                    kCarry ? ((t > 0 ? 1 : 0) | (t < a.T - 1 ? 2 : 0)) : 0);
+        __syncthreads();   // the next step overwrites the LDS tables the emission read (and, without the carry, reads the state this one stored)
     }
 }
 

@@ -304,6 +304,39 @@ __global__ __launch_bounds__(256) void store_stream_kernel(float4 *dst, size_t n
     }
 }
 
+// fmarl_store_pattern: the store stream of the GENERIC emission path (row shapes whose width is not a multiple of 16 bytes: 10 agents,
+// E = 23 -> 1 012-byte ego rows) with everything but the stores removed.  A workgroup owns group (b * order) mod groups of every time
+// slot: `node_group` contiguous bytes of node rows, which its four waves write window by window -- `window` bytes (64 rows) at 4-byte
+// aligned starts, as aligned 16-byte chunks per lane plus up to three dwords at either end, flush_rows' shape -- and `adj_group`
+// contiguous bytes of adjacency words, each wave a contiguous quarter, one dword per lane and store (emit_adj_generic's shape); odd
+// workgroups write the adjacency first (emit_graph).  The workgroup walks the slots in order, as a span kernel walks its steps.
+__global__ __launch_bounds__(256) void store_pattern_kernel(char *node, char *adj, size_t node_group, size_t adj_group, uint32_t groups, uint32_t slots,
+                                                            size_t node_slot, size_t adj_slot, uint32_t window, uint32_t order) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t g = (uint32_t)(((uint64_t)blockIdx.x * order) % groups);
+    const bool adj_first = (blockIdx.x & 1) != 0;
+    for (uint32_t t = 0; t < slots; ++t) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((pass == 0) == adj_first) {   // adjacency words
+                const size_t off = (size_t)g * adj_group, size = off < adj_slot ? (adj_slot - off < adj_group ? adj_slot - off : adj_group) : 0;
+                const uint32_t words = (uint32_t)(size >> 2), per = (words + 3) / 4, w0 = wave * per < words ? wave * per : words, w1 = w0 + per < words ? w0 + per : words;
+                float *d = (float *)(adj + (size_t)t * adj_slot + off);
+                for (uint32_t k = w0 + lane; k < w1; k += 64) d[k] = (float)k;
+            } else {                          // node rows, a window per wave and round
+                const size_t off = (size_t)g * node_group, size = off < node_slot ? (node_slot - off < node_group ? node_slot - off : node_group) : 0;
+                char *base = node + (size_t)t * node_slot + off;
+                for (size_t w = (size_t)wave * window; w < size; w += (size_t)4 * window) {
+                    char *start = base + w, *end = base + (w + window < size ? w + window : size);
+                    char *a0 = (char *)(((uintptr_t)start + 15) & ~(uintptr_t)15), *a1 = (char *)((uintptr_t)end & ~(uintptr_t)15);
+                    for (char *q = a0 + lane * 16; q < a1; q += 64 * 16) *(float4 *)q = make_float4(1.f, 2.f, 3.f, (float)lane);
+                    if (lane < 3) { char *q = start + lane * 4; if (q < (a0 < end ? a0 : end)) *(float *)q = 4.f; }
+                    else if (lane < 6) { char *q = (a1 > a0 ? a1 : a0) + (lane - 3) * 4; if (q < end) *(float *)q = 5.f; }
+                }
+            }
+        }
+    }
+}
+
 // fmarl_ring_alloc's check of an array allocated after another one was freed: a KERNEL's fill read back by a kernel (the faults seen on
 // re-used address ranges passed a fill / read-back through the copy engines and lost a kernel's writes).  Word i gets a pattern of i;
 // the second launch counts the words that do not hold it and zeroes the array.

@@ -451,6 +451,20 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         // small batches: spread over the 256 CUs (>= 512 workgroups) rather than fill every lane of a few
         int e2 = p.n_envs / 512; epb = e2 < 1 ? 1 : (e2 < epb ? e2 : epb);
     }
+    if (!form && !fnav && cfg->envs_per_workgroup == 0 && (p.n_envs + epb - 1) / epb >= 512) {
+        // navigation_graph rows of generic shape (E F not a multiple of 4): a workgroup's node rows leave as windows of 64 rows -- 2 816 bytes
+        // = 44 lines at F = 11 -- so when the workgroup's region starts on a 64-byte boundary, every window does.  The store pattern alone
+        // then runs 13 % faster (fmarl_store_pattern, 10 agents: 0.158 -> 0.137 ms per step), the kernel 3-5 % (spans 0.195 -> 0.189, one
+        // launch per step 0.201 -> 0.191 at 24 instead of 25 envs per workgroup: profiles/r6_n10_tcc.md).  The largest env count whose
+        // node bytes are a multiple of 64, if it gives up at most a tenth of the lanes.
+        const long long env_node = 4LL * p.N * p.E * p.F;
+        if ((p.E * p.F) % 4 != 0) {
+            long long a = 64, b = env_node % 64;
+            while (b) { const long long r = a % b; a = b; b = r; }
+            const int g = (int)(64 / a), aligned = epb / g * g;
+            if (aligned >= 1 && aligned * 10 >= epb * 9) epb = aligned;
+        }
+    }
 #ifdef FMARL_MEASURE
     if (const char *e = getenv("FMARL_EPB")) { const int v = atoi(e); if (v >= 1 && v <= epb) epb = v; }   // envs per workgroup (experiments)
 #endif
@@ -465,7 +479,9 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // hold no agent) -- 168 vector registers per lane at four workgroups per CU instead of 128 (fmarl_fairnav.hip FairnavCarry)
     // -- for the span kernel only, which carries the state: one launch per step measured 4 % slower on three waves (the emission is
     // shared by fewer waves) and has no carry to fit
-    h->span_threads = (fnav && epb * p.N <= 192) ? 192 : h->threads;
+    // (only where the third wave is at least half full: with two waves of agents or little more -- 13 envs x 10 agents -- the three-wave form measured
+    // 23 % SLOWER than one launch per step, 0.776 against 0.631 ms per step, every phase of the step alike: profiles/r6_fnav10_summary.md)
+    h->span_threads = (fnav && epb * p.N <= 192 && epb * p.N >= 160) ? 192 : h->threads;
     h->small_ok = false;   // (decided below, once the emission shapes are known)
     p.lds_stage = align16(epb * p.lds_env_bytes);
     if (form) {   // the second region: epw envs per wave, the wave's part = its emission window
@@ -797,8 +813,11 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
         int k = 0;
         // (its span carries the step counter in 15 bits and the two collision counts in 16 each -- FairnavCarry: episodes too long for
         // that go out one launch per step, the state through global memory, same results)
+        // Nor do more than five agents: the step is then bound by the assignment and the sequential walk, whose waves want every register
+        // and the chip's lockstep -- measured per step at 65 536 envs, one launch per step / the span: N = 3 0.0531 / 0.0440 ms, 4 0.0979 /
+        // 0.0976, 5 0.1597 / 0.1522, 6 0.2143 / 0.2357, 8 0.3773 / 0.3838, 10 0.634 / 0.668 (profiles/r6_fnav10_summary.md).
         if (sc == FMARL_SCENARIO_FAIRNAV)
-            k = (h->cfg.episode_length < 32768 && (long long)(h->cfg.num_agents - 1) * h->cfg.episode_length <= 65535) ? n_steps - t : 0;
+            k = (h->cfg.num_agents <= 5 && h->cfg.episode_length < 32768 && (long long)(h->cfg.num_agents - 1) * h->cfg.episode_length <= 65535) ? n_steps - t : 0;
         else if (h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;
         if (k > n_steps - t) k = n_steps - t;
         FmarlOutputs o = *outs;
@@ -899,6 +918,24 @@ int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, i
     else if (shape == 2) hipLaunchKernelGGL(fmarl::store_stream_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
     else if (shape == 3) hipLaunchKernelGGL(fmarl::store_stream_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
     else hipLaunchKernelGGL(fmarl::store_stream_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, (float4 *)dst, n16, (uint32_t)c16, (uint32_t)chunks, (uint32_t)order);
+    HIP_OK(hipGetLastError());
+    return FMARL_OK;
+}
+
+int fmarl_store_pattern(void *node, void *adj, size_t node_group_bytes, size_t adj_group_bytes, int groups, int slots, size_t node_slot_bytes,
+                        size_t adj_slot_bytes, int window_bytes, int order, void *stream) {
+    if (!node || !adj || groups < 1 || slots < 1 || window_bytes < 64 || (window_bytes & 3) || (node_group_bytes & 3) || (adj_group_bytes & 3) ||
+        (node_slot_bytes & 3) || (adj_slot_bytes & 3) || order < 1 || (((uintptr_t)node | (uintptr_t)adj) & 3))
+        return fail(FMARL_EINVAL, "fmarl_store_pattern: bad argument (sizes are multiples of 4 bytes, window_bytes >= 64)");
+    if ((size_t)groups * node_group_bytes < node_slot_bytes || (size_t)groups * adj_group_bytes < adj_slot_bytes)
+        return fail(FMARL_EINVAL, "fmarl_store_pattern: the groups do not cover a slot");
+    {
+        size_t a = (size_t)groups, b = (size_t)order % (size_t)groups;
+        while (b) { const size_t r = a % b; a = b; b = r; }
+        if (groups > 1 && a != 1) return fail(FMARL_EINVAL, "fmarl_store_pattern: order must be coprime with the number of groups");
+    }
+    hipLaunchKernelGGL(fmarl::store_pattern_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, (char *)node, (char *)adj, node_group_bytes,
+                       adj_group_bytes, (uint32_t)groups, (uint32_t)slots, node_slot_bytes, adj_slot_bytes, (uint32_t)window_bytes, (uint32_t)order);
     HIP_OK(hipGetLastError());
     return FMARL_OK;
 }

@@ -304,6 +304,15 @@ int fmarl_poison_lds(void *handle, void *stream);
  * (which has no device path); takes no handle. */
 int fmarl_store_stream(void *dst, size_t bytes, int shape, size_t chunk_bytes, int order, int persist, void *stream);
 
+/* Measurement aid, as fmarl_store_stream: the store stream of the GENERIC emission path -- node rows whose width is not a multiple of
+ * 16 bytes (10 agents, E = 23: 1 012-byte ego rows) leave a wave as windows of `window_bytes` (64 rows) at 4-byte aligned starts,
+ * aligned 16-byte chunks per lane plus up to three dwords at either end, and the adjacency as one dword per lane and store -- with
+ * everything but the stores removed.  Workgroup b owns group (b * order) mod groups of every time slot: node_group_bytes of node[] and
+ * adj_group_bytes of adj[] (the last group of a slot is cut at node_slot_bytes / adj_slot_bytes), and walks the `slots` slots in order
+ * like a span launch.  Its time per slot is the ceiling of a step kernel that writes in this pattern.  Takes no handle. */
+int fmarl_store_pattern(void *node, void *adj, size_t node_group_bytes, size_t adj_group_bytes, int groups, int slots, size_t node_slot_bytes,
+                        size_t adj_slot_bytes, int window_bytes, int order, void *stream);
+
 /* The masks of the runner's insert (onpolicy/runner/shared/graph_mpe_runner.py:444-465) for `rows` env-steps of num_agents agents each:
  * done u8 (rows, N) -> masks f32 (rows, N): 0 where the agent is done; active_masks f32 (rows, N): 0 where the agent is done but
  * its env is not.  One launch (DeviceRolloutBuffer.insert_step / insert_span). */

@@ -452,7 +452,7 @@ def test_bench_exchange_through_rccl_with_one_rank(tmp_path):
     assert res.returncode == 0, res.stdout[-4000:]
     c, d = _bench_records(res.stdout)
     assert json.load(open(str(tmp_path / 'd.json'))) == d and c['reference_cpu']['value'] == 1662.0
-    assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1 and d['config']['exchange'] == 'rccl-selftest-gather-per-step'
+    assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1 and d['config']['exchange'] == 'rccl-selftest-gather-per-run'
     assert d['config']['exchange_text'].startswith('RCCL (process group of one rank')
     assert d['roofline']['traffic'] is None and d['roofline']['traffic_source'] is None and '2048 envs' in d['config']['workload']
     assert d['reference_cpu']['value'] == 1662.0
@@ -1902,7 +1902,9 @@ def test_time_slots_with_interleaved_physical_memory():
     free1, total1 = torch.cuda.mem_get_info()
     with pytest.raises(MemoryError):
         alloc_time_slots(lib, torch.device(DEV), (2, (total1 // 4 // (1 << 20) * (1 << 20)) * 3 // 4), spread=True)   # 2 x 0.75 x the device
-    assert abs(torch.cuda.mem_get_info()[0] - free1) < 64 * (1 << 20)
+    # nothing leaked (the free figure may GROW: handing the never-mapped range back lets the runtime return a cached 64 MiB block of its own;
+    # four failed attempts in a row in a fresh process leave it unchanged: tools/jobs/r6_oom_probe.py)
+    assert free1 - torch.cuda.mem_get_info()[0] < 64 * (1 << 20)
     assert float(torch.ones(4, device=DEV).sum()) == 4.0
     t2, inter2 = alloc_time_slots(lib, torch.device(DEV), (4, 1000, 3), spread=None)       # small slots: plain
     assert not inter2

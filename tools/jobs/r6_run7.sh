@@ -1,0 +1,6 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r6g; mkdir -p $O
+for rep in 1 2; do for v in ship nc3 fc3 fc4; do L=fair_marl_amd/csrc/libfmarl.so; [ $v != ship ] && L=fair_marl_amd/csrc/variants/libfmarl_$v.so; echo "== $v" >> $O/ab_fnav10.txt; FMARL_LIB=$PWD/$L timeout -k 10 200 python tools/fnav_lines.py fnav10 eager,span 1 2>&1 | grep -v libdrm >> $O/ab_fnav10.txt; done; done
+cat $O/ab_fnav10.txt

@@ -56,13 +56,13 @@ def main():
     assert lib.fmarl_measure_ticks(out, waves) == 0
     tot = sum(out[:14])
     print('%s: %d waves, %.0f cycles per wave' % (name, waves, tot / waves))
-    for k, nm in enumerate(NAMES_FNAV if name == 'fnav' else (NAMES if name == 'cfg4' else NAMES_NAV)):
+    for k, nm in enumerate(NAMES_FNAV if name.startswith('fnav') else (NAMES if name == 'cfg4' else NAMES_NAV)):
         print('  %-26s %8.0f cycles  %5.1f %%' % (nm, out[k] / waves, 100 * out[k] / tot))
     import numpy as np
     rows = np.zeros((waves, 16), dtype=np.uint32)
     lib.fmarl_measure_rows.argtypes = [C.c_void_p, C.c_int]
     assert lib.fmarl_measure_rows(rows.ctypes.data, waves) == 0
-    if name not in ('fnav', 'cfg4') and eng.envs_per_workgroup * cfg.N <= 64:   # small batches (step_body SMALL): wave 0 = the agents, waves 1 .. 3 = the emission
+    if name not in ('fnav', 'fnav10', 'cfg4') and eng.envs_per_workgroup * cfg.N <= 64:   # small batches (step_body SMALL): wave 0 = the agents, waves 1 .. 3 = the emission
         for label, sel in (('wave 0 of a workgroup (agents)', rows[0::4]), ('waves 1 .. 3 (emission)', np.concatenate([rows[1::4], rows[2::4], rows[3::4]]))):
             print('%s: %.0f cycles per wave' % (label, sel[:, :14].sum() / len(sel)))
             for k, nm in enumerate(NAMES_NAV):
