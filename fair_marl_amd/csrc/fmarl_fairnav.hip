@@ -300,10 +300,10 @@ struct PlacedEnvLds {
 // next block's LDS read is issued a trip ahead.  Which team takes which env comes from the envs' flags (ballots every wave takes for
 // itself: no worklist, no extra barrier).  Entities beyond 64 per env: the one-lane walk (place_env).
 __device__ __forceinline__ double u_lin(double lo, double hi, double a) { return lo + (hi - lo) * a; }   // PhiloxStream::uniform's expression
-template <int THREADS>
+template <int THREADS, int NL>
 __device__ __forceinline__ void fairnav_place_teams(const Params &p, char *lds, int env0, int nenv, int n_pre) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int O = p.O, N = p.N, L = p.L, W = p.W, slots = O + N + L;
+    const int O = NL ? 3 : p.O, N = NL ? NL : p.N, L = NL ? NL : p.L, W = NL ? 0 : p.W, slots = O + N + L;
     const int ts_log = slots <= 16 ? 4 : (slots <= 32 ? 5 : 6), TS = 1 << ts_log;
     const int j = tid & (TS - 1), team = tid >> ts_log, nteams = THREADS >> ts_log;
     const uint64_t tmask = TS == 64 ? ~0ull : ((1ull << TS) - 1ull);
@@ -417,11 +417,15 @@ __device__ __forceinline__ uint32_t fairnav_pack(double status, int hist, double
     return (status != 0.0 ? 1u : 0u) | ((uint32_t)(hist + 1) & 0xffu) << 1 | ((uint32_t)((int)gr + 1) & 0xffu) << 9 | (uint32_t)step << 17;
 }
 
-template <bool STEP, int THREADS>
+//   NL            0, or 3: the shipped FA / FA+FR configuration's shape -- 3 agents, 3 goals, 3 obstacles, no wall -- as compile-time
+//                 constants.  The pass is a chain of short loops over agents / goals / partners whose bodies start with an LDS read:
+//                 with run-time bounds every trip waits for its own read; with the bounds known the loops unroll and a loop's reads
+//                 leave together (round 6: one launch per step 0.0527 -> 0.0483 ms, the span 0.0431 -> 0.0403, 65 536 envs).
+template <bool STEP, int THREADS, int NL = 0>
 __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs &o, char *lds, const int32_t *action_idx,
                                              const float *action_vec, int auto_reset, FairnavCarry &c, const int carry) {
     FMARL_TICKS_BEGIN
-    const int tid = threadIdx.x, N = p.N, L = p.L;
+    const int tid = threadIdx.x, N = NL ? NL : p.N, L = NL ? NL : p.L, O = NL ? 3 : p.O, W = NL ? 0 : p.W;
     const int env0 = env_block(p) * p.epb;
     const int nenv = min(p.epb, p.n_envs - env0);
     const int el = tid / N, i = tid - el * N;
@@ -460,7 +464,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     if (!arrives) load_statics_range(p, lds, env0, 0, nenv, tid, THREADS);
     __syncthreads();
     FMARL_TICK(0);   // state loads, entity tables, barrier
-    if (STEP && active) world_step_agent(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
+    if (STEP && active) world_step_agent<NL, NL ? 3 : 0, 0>(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
     __syncthreads();   // every lane has finished reading the old positions
     FMARL_TICK(1);   // physics
     if (active) t.pos()[i] = x;
@@ -529,10 +533,10 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             for (int j = 0; j < N; ++j)
                 if (j != i && closer_than(x, t.pos()[j], 1.05 * (kEntitySize + kEntitySize))) ++ag_hits;
             bool ob_hit = false;
-            for (int k = 0; k < p.O; ++k)
+            for (int k = 0; k < O; ++k)
                 ob_hit |= closer_than(t.pos()[N + L + k], x, 2.0 * (kEntitySize + kEntitySize));
             const double *wl = t.wall();
-            for (int w = 0; w < p.W; ++w)
+            for (int w = 0; w < W; ++w)
                 ob_hit |= wall_box_hit_pad15(x, wl[w * 4], wl[w * 4 + 1], wl[w * 4 + 2], (int)wl[w * 4 + 3]);
             double rew = 0.0;
             if (dgoal < p.thr) { if (newly) rew += p.goal_rew; }
@@ -597,7 +601,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             // (Round 6: where teams place -- fairnav_place_teams -- a team draws its env's blocks itself and the workgroup's pre-draw pass
             // with its barrier is gone; the lanes of a team share a wave, LDS keeps a wave's accesses in order.)
             const int n_pre = p.n_pre;
-            const bool teams = p.O + N + L <= 64;
+            const bool teams = O + N + L <= 64;
             if (!teams) {
                 for (int task = tid; task < nenv * n_pre; task += THREADS) {
                     const int e_l = task / n_pre, b = task - e_l * n_pre;
@@ -610,7 +614,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
                 __syncthreads();
             }
             FMARL_TICK(11);   // (measure builds) the barrier that found ended envs (+ the pre-draw pass of the one-lane walk)
-            if (teams) fairnav_place_teams<THREADS>(p, lds, env0, nenv, n_pre);   // a team of lanes per ended env
+            if (teams) fairnav_place_teams<THREADS, NL>(p, lds, env0, nenv, n_pre);   // a team of lanes per ended env
             else if (in_range && i == 0 && ended) {   // more than 64 entities: the first lane of the env walks alone
                 PlacedEnvLds pl{t.pos(), p, env};
                 const int epi = *t.episode();
@@ -621,8 +625,8 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             __threadfence_block();   // (walls: the static entities of the placed envs are re-read from the state below)
             __syncthreads();
             if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
-                if (p.W == 0) {   // the placement left the new landmarks / obstacles in the env's float64 table: their f32 copies from there
-                    for (int k = i; k < L + p.O; k += N) { const double2 e = t.pos()[N + k]; t.posf()[N + k] = make_float2((float)e.x, (float)e.y); }
+                if (W == 0) {   // the placement left the new landmarks / obstacles in the env's float64 table: their f32 copies from there
+                    for (int k = i; k < L + O; k += N) { const double2 e = t.pos()[N + k]; t.posf()[N + k] = make_float2((float)e.x, (float)e.y); }
                 } else load_statics_range(p, lds, env0, el, el + 1, i, N);   // (+ the wall tables: a round trip through global memory)
                 const double2 nx = t.pos()[i];   // (the placement wrote the env's float64 table)
                 t.occ()[i] = 0.0; t.hist()[i] = -1;
@@ -672,9 +676,16 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     // ---- the sequential part: occupancy / history walk in agent order
     ObsGoal og;
     og.goal = -1; og.second = 0; og.g_occ = og.g_hist = og.second_occ = 0.0;
+    // Three barriers per agent (round 6; four before): the clear that graph_observation(a) asks for (nf:1278) is applied by the lane that
+    // runs the NEXT event, just before it -- nobody looks at the occupancy in between -- and the last one behind the loop.
     for (int a = 0; a < (FMARL_SKIP(p, 128) ? 0 : N); ++a) {
-        if (active && i == a)
+        if (active && i == a) {
+            if (t.words()[0] != N) {   // graph_observation(a - 1) found no free goal: the clear itself, once, and the marker back to "nobody"
+                for (int k = 0; k < L; ++k) t.occ()[k] = 0.0;
+                t.words()[0] = N;
+            }
             og = obs_event(t.D() + i * L, t.minprox(), t.occ(), t.hist(), L, i, p.thr, p.min_obs_dist);
+        }
         __syncthreads();
         // graph_observation(a): row of entity i on the snapshot (nf:1255-1283)
         bool far = false, free_empty = true;
@@ -702,13 +713,14 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             else { r.code = (int8_t)cc; r.occ = 0.f; r.hist = t.hist()[cc]; }   // after the clear every goal is free
             t.rows()[a * N + i] = r;
         }
-        __syncthreads();
-        if (active && free_empty && t.words()[0] == i) {   // the clear itself (nf:1278), once per graph_observation
+        __syncthreads();   // (the rows above read the occupancy and the marker: the next event's lane changes both)
+    }
+    if (!FMARL_SKIP(p, 128)) {
+        if (active && i == 0 && t.words()[0] != N) {   // the last graph_observation's clear
             for (int k = 0; k < L; ++k) t.occ()[k] = 0.0;
+            t.words()[0] = N;
         }
         __syncthreads();
-        if (active && i == 0) t.words()[0] = N;
-        // (the next iteration's first barrier orders this reset before the next atomicMin)
     }
     FMARL_TICK(5);   // walk
 
@@ -750,7 +762,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICKS_END;
 }
 
-template <bool STEP, int THREADS>
+template <bool STEP, int THREADS, int NL>
 __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                                  const float *action_vec, int auto_reset) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_kerne
     // all being loaded at the top and spilled into vector lanes: 144 -> 30 spilled scalar registers, 0.0575 -> 0.0555 ms per launch
     // at 65 536 x 3 (-5 % with episodes ending at all phases, profiles/r4_notes.md)
     FairnavCarry c;
-    fairnav_pass<STEP, THREADS>(span_params_reloaded(), o, lds, action_idx, action_vec, auto_reset, c, 0);
+    fairnav_pass<STEP, THREADS, NL>(span_params_reloaded(), o, lds, action_idx, action_vec, auto_reset, c, 0);
 }
 
 // fmarl_step_span for nav_fairassign_fairrew_formation_graph: T steps of the workgroup's own envs in one launch, episode ends
@@ -781,7 +793,7 @@ struct FairnavSpanArgs { Params p; FmarlOutputs o; SpanStrides s; const int32_t 
 #ifndef FMARL_FNAV256_BLOCKS
 #define FMARL_FNAV256_BLOCKS (FMARL_FNAV256_CARRY ? 3 : 4)
 #endif
-template <int THREADS>
+template <int THREADS, int NL>
 __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : FMARL_FNAV256_BLOCKS) void fairnav_span_kernel(FairnavSpanArgs) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool kCarry = THREADS == 192 || FMARL_FNAV256_CARRY;
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : FMARL_FNAV256_BLOCKS)
         const FairnavSpanArgs &a = span_params_reloaded<FairnavSpanArgs>();
         if (t >= a.T) break;
         const FmarlOutputs ot = span_outputs(a.o, a.s, t);
-        fairnav_pass<true, THREADS>(a.p, ot, lds, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
+        fairnav_pass<true, THREADS, NL>(a.p, ot, lds, a.action_idx ? a.action_idx + (size_t)t * a.s.actions : nullptr,
                                     a.action_vec ? a.action_vec + (size_t)t * a.s.actions : nullptr, a.auto_reset, c,
                                     kCarry ? ((t > 0 ? 1 : 0) | (t < a.T - 1 ? 2 : 0)) : 0);
         __syncthreads();   // the next step overwrites the LDS tables the emission read (and, without the carry, reads the state this one stored)

@@ -706,10 +706,17 @@ __device__ __forceinline__ void formation_body(const Params &p, const FmarlOutpu
 #ifndef FMARL_FORM_MIN_BLOCKS
 #define FMARL_FORM_MIN_BLOCKS 1
 #endif
-template <bool STEP>
+// SH = 1: BASELINE config 4's shape -- 10 agents, 1 landmark, 3 obstacles, the scenario's 2 walls -- as compile-time constants (fmarl_step.hip
+// shape_const's reasoning); 0 = the run-time values.
+template <int SH>
+__device__ __forceinline__ void formation_shape_const(Params &q) {
+    if constexpr (SH == 1) { q.N = 10; q.L = 1; q.O = 3; q.W = 2; q.E = 16; }
+}
+template <bool STEP, int SH>
 __global__ __launch_bounds__(kThreads, FMARL_FORM_MIN_BLOCKS) void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                              const float *action_vec, int auto_reset) {
     FormCarry c;
+    formation_shape_const<SH>(p);
     formation_body<STEP>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
@@ -720,11 +727,14 @@ __global__ __launch_bounds__(kThreads, FMARL_FORM_MIN_BLOCKS) void formation_ker
 #ifndef FMARL_FORM_SPAN_BLOCKS
 #define FMARL_FORM_SPAN_BLOCKS 4
 #endif
+template <int SH>
 __global__ __launch_bounds__(kThreads, FMARL_FORM_SPAN_BLOCKS) void formation_span_kernel(Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx,
                                                                      const float *action_vec, int T) {
     FormCarry c = {};
     for (int t = 0; t < T; ++t) {
         const Params &q = span_params_reloaded();   // == p
+        // (the shape's counts: the argument block is re-read where it is used, so they are told to the compiler rather than written over a copy)
+        if constexpr (SH == 1) __builtin_assume(q.N == 10 && q.L == 1 && q.O == 3 && q.W == 2 && q.E == 16);
         const FmarlOutputs ot = span_outputs(o, s, t);
 #ifdef FMARL_FORM_NO_CARRY   // (A/B builds: the state through global memory every step, as before round 4)
         formation_body<true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr,

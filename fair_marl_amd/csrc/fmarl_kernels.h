@@ -5,10 +5,10 @@
 namespace fmarl {
 
 // fmarl_step.hip
-__global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
-                            int auto_reset);
-__global__ void step_end_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
-                                int auto_reset);
+template <int SH> __global__ void step_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
+                                              int auto_reset);
+template <int SH> __global__ void step_end_kernel(Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec,
+                                                  int auto_reset);
 __device__ void emit_graph(const Params &p, const FmarlOutputs &o, char *lds, int env0, int nenv);
 __device__ void load_statics(const Params &p, char *lds, int env0, int nenv);
 __device__ void load_statics_range(const Params &p, char *lds, int env0, int el_begin, int el_end, int thr, int nthr);
@@ -23,13 +23,13 @@ __global__ void cost_matrix_kernel(const double2 *agent_pos, const double2 *goal
                                    int n_envs, int N, int L);
 
 // fmarl_formation.hip
-template <bool STEP> __global__ void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+template <bool STEP, int SH> __global__ void formation_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                      const float *action_vec, int auto_reset);
 
 __global__ void formation_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec, const uint32_t *step_rec, int n_envs);
 
 // fmarl_fairnav.hip
-template <bool STEP, int THREADS> __global__ void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
+template <bool STEP, int THREADS, int NL> __global__ void fairnav_kernel(Params p, FmarlOutputs o, const int32_t *action_idx,
                                                                 const float *action_vec, int auto_reset);
 
 template <int THREADS> __global__ void fairnav_rebuild_kernel(Params p, FmarlOutputs o, const uint32_t *ep_rec, const uint32_t *step_rec, int n_envs);

@@ -469,9 +469,13 @@ __device__ __forceinline__ bool replaced_entry_stats(double mean, double m2, int
 // decode of environment.py:265-311) + entity and wall collision forces (core.py:301-335, :370-462) out of
 // the LDS entity table (positions of the PREVIOUS step).  Only the position is needed here, so callers
 // can leave velocity / path length in memory until integrate_agent (fewer live registers across the pair loop).
-__device__ __forceinline__ double2 agent_force(const Params &p, const char *base, int i, size_t g,
+// CN / CO / CW: the numbers of agents (= landmarks), obstacles and walls as compile-time constants (CN = 0: the run-time ones) -- the
+// partner loops then unroll and their LDS reads leave together instead of one per trip (kernels whose launch is one wave's chain)
+template <int CN = 0, int CO = 0, int CW = 0>
+__device__ __forceinline__ double2 agent_force(const Params &p_, const char *base, int i, size_t g,
                                                const int32_t *action_idx, const float *action_vec,
                                                const double2 x, bool agent_forces = true, int a_pre = -1) {
+    const struct { int N, L, O, W, lds_pos, lds_wall, ablate; } p = {CN ? CN : p_.N, CN ? CN : p_.L, CN ? CO : p_.O, CN ? CW : p_.W, p_.lds_pos, p_.lds_wall, p_.ablate};
     const double2 *s_pos = (const double2 *)(base + p.lds_pos);
     double ux, uy;
     if (action_idx) {
@@ -714,10 +718,11 @@ __device__ __forceinline__ void integrate_agent(const Params &p, const double2 F
 }
 
 // World.step for agent i: both halves.
+template <int CN = 0, int CO = 0, int CW = 0>
 __device__ __forceinline__ void world_step_agent(const Params &p, const char *base, int i, size_t g,
                                                  const int32_t *action_idx, const float *action_vec,
                                                  double2 &x, double2 &v, double &pd, bool agent_forces = true, int a_pre = -1) {
-    const double2 F = agent_force(p, base, i, g, action_idx, action_vec, x, agent_forces, a_pre);
+    const double2 F = agent_force<CN, CO, CW>(p, base, i, g, action_idx, action_vec, x, agent_forces, a_pre);
     integrate_agent(p, F, x, v, pd);
 }
 
@@ -1043,15 +1048,36 @@ __device__ __forceinline__ void step_body(const Params &p, const FmarlOutputs &o
     FMARL_TICKS_END;
 }
 
+// Shapes as compile-time constants (round 6).  The step is a chain of short loops over agents / partners / entities whose bodies start
+// with an LDS read; with run-time bounds every trip waits for its own read, with the bounds known the loops unroll and their reads
+// leave together.  SH picks a row of kNavShapes -- the shapes BASELINE.json and the reference's own scripts name -- and shape_const
+// writes its counts over the kernel's copy of the argument block, from where constant propagation carries them through the inlined
+// step body; SH = 0 (any other shape, or FMARL_GENERIC_SHAPES=1) leaves the run-time values.  Same arithmetic in the same order.
+struct NavShape { int N, O, W; };
+// (32 agents + 8 obstacles -- BASELINE config 3 -- was tried and is not in the table: its launch is a store stream, the unrolled partner
+// loops cost registers -- one launch per step 1.39 -> 1.42 ms, the span kernel 288 bytes of scratch: profiles/r6_shapes.md)
+constexpr NavShape kNavShapes[] = {{0, 0, 0}, {3, 3, 0}, {10, 3, 0}};   // (num_landmarks == num_agents in this scenario)
+template <int SH>
+__device__ __forceinline__ void shape_const(Params &q) {
+    if constexpr (SH != 0) {
+        q.N = kNavShapes[SH].N; q.L = kNavShapes[SH].N; q.O = kNavShapes[SH].O; q.W = kNavShapes[SH].W;
+        q.E = 2 * kNavShapes[SH].N + kNavShapes[SH].O + kNavShapes[SH].W;
+    }
+}
+
+template <int SH>
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_kernel(
     Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
     StepCarry c;
+    shape_const<SH>(p);
     step_body<false>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
+template <int SH>
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
     Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
     StepCarry c;
+    shape_const<SH>(p);
     step_body<true>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
@@ -1063,24 +1089,24 @@ __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_end_kernel(
 // the step body's own barriers are all the ordering the steps need (a step's first LDS writes come two barriers after its
 // start, by when every wave has left the previous step's emission).
 // one launch per step of a small batch (step_body SMALL)
+template <int SH>
 __global__ __launch_bounds__(kThreads, kStepWavesPerSimd) void step_small_kernel(
     Params p, FmarlOutputs o, const int32_t *action_idx, const float *action_vec, int auto_reset) {
     StepCarry c;
+    shape_const<SH>(p);
     step_body<false, true>(p, o, action_idx, action_vec, auto_reset, c, 0);
 }
 
 #ifndef FMARL_SPAN_BLOCKS
 #define FMARL_SPAN_BLOCKS 3
 #endif
+template <int SH>
 __global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_kernel(
     Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, const float *action_vec, int T) {
     StepCarry c = {};
     for (int t = 0; t < T; ++t) {
-#ifdef FMARL_SPAN_RELOADED   // (A/B builds: the argument block re-read where it is used -- 172 -> 22 spilled scalar registers, 157 -> 145 VGPRs)
-        const Params &q = span_params_reloaded();
-#else
-        const Params q = span_params(p);
-#endif
+        Params q = span_params(p);
+        shape_const<SH>(q);
         const FmarlOutputs ot = span_outputs(o, s, t);
         step_body<false>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr, action_vec ? action_vec + (size_t)t * s.actions : nullptr,
                          0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0));
@@ -1089,11 +1115,13 @@ __global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_kernel(
 
 // the span of a small batch (step_body SMALL): between the steps the emission waves wait at the next step's first barrier, which is
 // also what keeps the next step's table writes behind their reads
+template <int SH>
 __global__ __launch_bounds__(kThreads, FMARL_SPAN_BLOCKS) void step_span_small_kernel(
     Params p, FmarlOutputs o, SpanStrides s, const int32_t *action_idx, const float *action_vec, int T) {
     StepCarry c = {};
     for (int t = 0; t < T; ++t) {
-        const Params q = span_params(p);
+        Params q = span_params(p);
+        shape_const<SH>(q);
         const FmarlOutputs ot = span_outputs(o, s, t);
         step_body<false, true>(q, ot, action_idx ? action_idx + (size_t)t * s.actions : nullptr, action_vec ? action_vec + (size_t)t * s.actions : nullptr,
                                0, c, (t > 0 ? 1 : 0) | (t < T - 1 ? 2 : 0), (action_idx && t < T - 1) ? action_idx + (size_t)(t + 1) * s.actions : nullptr);

@@ -230,12 +230,53 @@ void launch_place(Handle *h, const Params &p, int mode, const uint8_t *mask, hip
 // on what the host knew about the staged data when it was captured, so a captured staging always clears the validity flags
 // first and leaves the host's own `stage_dirty` as it was (nothing ran).
 // nav_fairassign_fairrew_formation_graph kernels: the instantiation for the handle's workgroup size (TH = 192 or 256 threads)
+// navigation_graph: the step kernels' instances with the shape as compile-time constants (fmarl_step.hip kNavShapes; 0 = the generic ones).
+// The small-batch kernels exist for shape 1 (BASELINE config 2), the full-batch ones for shape 2 (the reference's own 10-agent scale);
+// FMARL_GENERIC_SHAPES=1 in the environment switches every scenario's shape instances off (A/B, escape hatch).
+static bool generic_shapes() { static const bool g = [] { const char *e = getenv("FMARL_GENERIC_SHAPES"); return e && e[0] == '1'; }(); return g; }
+static inline int nav_shape(const FmarlConfig *c) {
+    if (generic_shapes() || c->scenario != FMARL_SCENARIO_NAVIGATION_GRAPH) return 0;
+    for (int k = 1; k < (int)(sizeof(fmarl::kNavShapes) / sizeof(fmarl::kNavShapes[0])); ++k)
+        if (c->num_agents == fmarl::kNavShapes[k].N && c->num_landmarks == c->num_agents && c->num_obstacles == fmarl::kNavShapes[k].O &&
+            c->num_walls == fmarl::kNavShapes[k].W) return k;
+    return 0;
+}
+#define FMARL_NAV_SMALL(h, kernel, grid, threads, lds, st, ...)                                                         \
+    do {                                                                                                                \
+        if (nav_shape(&(h)->cfg) == 1) { constexpr int SH = 1; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); } \
+        else { constexpr int SH = 0; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }                    \
+    } while (0)
+#define FMARL_NAV_FULL(h, kernel, grid, threads, lds, st, ...)                                                          \
+    do {                                                                                                                \
+        if (nav_shape(&(h)->cfg) == 2) { constexpr int SH = 2; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); } \
+        else { constexpr int SH = 0; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }                    \
+    } while (0)
+// fair_graph_formation in BASELINE config 4's shape (fmarl_formation.hip formation_shape_const)
+static inline bool form_shape1(const FmarlConfig *c) { return !generic_shapes() && c->num_agents == 10 && c->num_landmarks == 1 && c->num_obstacles == 3 && c->num_walls == 2; }
+#define FMARL_FORM(h, kernel, grid, threads, lds, st, ...)                                                              \
+    do {                                                                                                                \
+        if (form_shape1(&(h)->cfg)) { constexpr int SH = 1; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }    \
+        else { constexpr int SH = 0; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }                    \
+    } while (0)
+// nav_fairassign_fairrew_formation_graph in the shape of the shipped FA / FA+FR weights (3 agents, 3 goals, 3 obstacles, no wall): the step
+// kernels' NL = 3 instances hold these counts as compile-time constants
+static inline bool fnav_shape3(const FmarlConfig *c) { return !generic_shapes() && c->num_agents == 3 && c->num_landmarks == 3 && c->num_obstacles == 3 && c->num_walls == 0; }
 // (the per-step, reset-observation and rebuild kernels always run kThreads wide: only the span kernel has a three-wave form)
 #define FMARL_FNAV(h, kernel, grid, lds, st, ...) do { constexpr int TH = kThreads; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } while (0)
-#define FMARL_FNAV_T(threads, kernel, grid, lds, st, ...)                                               \
+// the step kernels also exist with the agent / goal count as a compile-time constant (NL = 3: the shipped FA / FA+FR configuration; 0 = any)
+#define FMARL_FNAV_NL(h, kernel, grid, lds, st, ...)                                                    \
     do {                                                                                                \
-        if ((threads) == 192) { constexpr int TH = 192; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
-        else { constexpr int TH = 256; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); }                    \
+        constexpr int TH = kThreads;                                                                    \
+        if (fnav_shape3(&(h)->cfg)) { constexpr int NL = 3; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
+        else { constexpr int NL = 0; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); }  \
+    } while (0)
+#define FMARL_FNAV_T(h, threads, kernel, grid, lds, st, ...)                                            \
+    do {                                                                                                \
+        const bool nl3_ = fnav_shape3(&(h)->cfg);                                                                         \
+        if ((threads) == 192 && nl3_) { constexpr int TH = 192, NL = 3; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
+        else if ((threads) == 192) { constexpr int TH = 192, NL = 0; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
+        else if (nl3_) { constexpr int TH = 256, NL = 3; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); }             \
+        else { constexpr int TH = 256, NL = 0; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); }                     \
     } while (0)
 
 int launch_stage(Handle *h, void *state, hipStream_t st) {
@@ -279,10 +320,10 @@ int launch_reset(Handle *h, void *state, int mode, const uint8_t *mask, const Fm
     }
     if (outs && (outs->obs || outs->node_obs || outs->adj)) {
         if (form)
-            hipLaunchKernelGGL(formation_kernel<false>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs,
+            hipLaunchKernelGGL((formation_kernel<false, 0>), dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs,
                                (const int32_t *)nullptr, (const float *)nullptr, 0);
         else if (p.scenario == FMARL_SCENARIO_FAIRNAV)
-            FMARL_FNAV(h, (fairnav_kernel<false, TH>), dim3(h->grid), h->lds_bytes, st, p, *outs, (const int32_t *)nullptr, (const float *)nullptr, 0);
+            FMARL_FNAV(h, (fairnav_kernel<false, TH, 0>), dim3(h->grid), h->lds_bytes, st, p, *outs, (const int32_t *)nullptr, (const float *)nullptr, 0);
         else
             hipLaunchKernelGGL(reset_emit_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs);
     } else if ((form || p.scenario == FMARL_SCENARIO_FAIRNAV) && mode != kResetInit) {
@@ -534,19 +575,22 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         if (!ok) { delete h; return fail(FMARL_EINVAL, "fmarl_create: shape too large (entity count beyond the index arithmetic of the emission)"); }
     }
     if (h->lds_bytes > 64 * 1024) {
-        hipError_t e1 = hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_end_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_span_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)step_span_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_span_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        hipError_t e1 = hipSuccess;
+        for (const void *f : {(const void *)step_kernel<0>, (const void *)step_kernel<2>, (const void *)step_end_kernel<0>,
+                              (const void *)step_end_kernel<2>, (const void *)step_span_kernel<0>, (const void *)step_span_kernel<2>,
+                              (const void *)step_small_kernel<0>, (const void *)step_small_kernel<1>,
+                              (const void *)step_span_small_kernel<0>, (const void *)step_span_small_kernel<1>})
+            if (e1 == hipSuccess) e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        for (const void *f : {(const void *)formation_span_kernel<0>, (const void *)formation_span_kernel<1>, (const void *)formation_kernel<true, 1>})
+            if (e1 == hipSuccess) e1 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         hipError_t e2 = hipFuncSetAttribute((const void *)reset_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)rebuild_graph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        for (const void *f : {(const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 256>, (const void *)fairnav_kernel<false, 256>,
-                              (const void *)fairnav_span_kernel<192>, (const void *)fairnav_span_kernel<256>})
+        for (const void *f : {(const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 256, 0>, (const void *)fairnav_kernel<true, 256, 3>,
+                              (const void *)fairnav_kernel<false, 256, 0>, (const void *)fairnav_span_kernel<192, 0>, (const void *)fairnav_span_kernel<192, 3>,
+                              (const void *)fairnav_span_kernel<256, 0>, (const void *)fairnav_span_kernel<256, 3>})
             if (e2 == hipSuccess) e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e1 != hipSuccess || e2 != hipSuccess) { delete h; return fail(FMARL_EHIP, "fmarl_create: cannot raise dynamic LDS limit"); }
     }
@@ -682,8 +726,8 @@ int fmarl_init_state(void *handle, void *state, void *stream) {
         Params q = bind(h, state);
         q.n_envs = 0;
         FmarlOutputs none = {};
-        hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(kThreads), h->lds_bytes, st, q, none, (const int32_t *)nullptr,
-                           (const float *)nullptr, 0);
+        FMARL_NAV_FULL(h, step_end_kernel<SH>, dim3(1), dim3(kThreads), h->lds_bytes, st, q, none, (const int32_t *)nullptr,
+                       (const float *)nullptr, 0);
         HIP_OK(hipGetLastError());
     }
     h->lockstep = !h->captured && h->cfg.scenario != FMARL_SCENARIO_FAIRNAV;   // fairnav episodes end early, env by env
@@ -754,17 +798,17 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
     const bool prof = h->ev && h->ev_n < h->ev_cap && !h->cap_id && cs == hipStreamCaptureStatusNone;
     if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
     if (p.scenario == FMARL_SCENARIO_FAIRNAV)
-        FMARL_FNAV(h, (fairnav_kernel<true, TH>), dim3(h->grid), h->lds_bytes, st, p, *outs, action_idx, action_vec, auto_reset ? 1 : 0);
+        FMARL_FNAV_NL(h, (fairnav_kernel<true, TH, NL>), dim3(h->grid), h->lds_bytes, st, p, *outs, action_idx, action_vec, auto_reset ? 1 : 0);
     else if (p.scenario == FMARL_SCENARIO_FORMATION)
-        hipLaunchKernelGGL(formation_kernel<true>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs, action_idx,
-                           action_vec, auto_reset ? 1 : 0);
+        FMARL_FORM(h, (formation_kernel<true, SH>), dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs, action_idx,
+                   action_vec, auto_reset ? 1 : 0);
     else if (fold)
-        hipLaunchKernelGGL(step_end_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec, 1);
+        FMARL_NAV_FULL(h, step_end_kernel<SH>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec, 1);
     else if (h->small_ok && !outs->edge_nnz)
-        hipLaunchKernelGGL(step_small_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
-                           auto_reset ? 1 : 0);
+        FMARL_NAV_SMALL(h, step_small_kernel<SH>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
+                        auto_reset ? 1 : 0);
     else
-        hipLaunchKernelGGL(step_kernel, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
+        FMARL_NAV_FULL(h, step_kernel<SH>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
                            auto_reset ? 1 : 0);
     if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = 1; ++h->ev_n; }
     HIP_OK(hipGetLastError());
@@ -844,13 +888,13 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
             const bool prof = h->ev && h->ev_n < h->ev_cap;
             if (prof) HIP_OK(hipEventRecord(h->ev[2 * h->ev_n], st));
             if (sc == FMARL_SCENARIO_FAIRNAV)
-                FMARL_FNAV_T(h->span_threads, (fairnav_span_kernel<TH>), dim3(h->grid), h->lds_bytes, st, FairnavSpanArgs{p, o, s, a, av, k, 1});
+                FMARL_FNAV_T(h, h->span_threads, (fairnav_span_kernel<TH, NL>), dim3(h->grid), h->lds_bytes, st, FairnavSpanArgs{p, o, s, a, av, k, 1});
             else if (sc == FMARL_SCENARIO_FORMATION)
-                hipLaunchKernelGGL(formation_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
+                FMARL_FORM(h, formation_span_kernel<SH>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             else if (h->small_ok && !o.edge_nnz)
-                hipLaunchKernelGGL(step_span_small_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
+                FMARL_NAV_SMALL(h, step_span_small_kernel<SH>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             else
-                hipLaunchKernelGGL(step_span_kernel, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
+                FMARL_NAV_FULL(h, step_span_kernel<SH>, dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, o, s, a, av, k);
             if (prof) { HIP_OK(hipEventRecord(h->ev[2 * h->ev_n + 1], st)); h->ev_steps[h->ev_n] = k; ++h->ev_n; }
             HIP_OK(hipGetLastError());
             if (h->lockstep) h->host_step += k;

@@ -459,22 +459,30 @@ def test_hot_kernels_keep_their_register_and_scratch_budget():
         return hits[0]
     # scratch = 0: besides its cost, a scratch load is a VMEM load on gfx9 -- its s_waitcnt vmcnt(0) also waits for every global
     # store issued before it (the generic node emission ran at 2/3 of its rate while 24 bytes of a row lived in scratch)
-    for part, max_vgpr, max_scratch, min_occ in (('11step_kernel', 96, 0, 5), ('16formation_kernelILb1', 120, 0, 4),
-                                                 ('14fairnav_kernelILb1ELi256', 128, 0, 4),
+    for part, max_vgpr, max_scratch, min_occ in (('11step_kernelILi0', 96, 0, 5), ('16formation_kernelILb1ELi0', 120, 0, 4), ('16formation_kernelILb1ELi1', 120, 0, 4),
+                                                 ('14fairnav_kernelILb1ELi256ELi0', 128, 0, 4),
+                                                 # ... and with the agent / goal count a compile-time 3 (the shipped FA / FA+FR configuration): unrolled loops, fewer registers
+                                                 ('14fairnav_kernelILb1ELi256ELi3', 104, 0, 4), ('19fairnav_span_kernelILi192ELi3', 152, 0, 3),
+                                                 ('19fairnav_span_kernelILi256ELi3', 120, 0, 4),
                                                  ('17reset_emit_kernel', 96, 0, 5),
-                                                 ('20rebuild_graph_kernel', 96, 0, 5), ('15step_end_kernel', 112, 0, 4),
+                                                 ('20rebuild_graph_kernel', 96, 0, 5), ('15step_end_kernelILi0', 112, 0, 4),
                                                  # the span kernels (the bench's default launch mode) and the learner-side gather: the latter once
                                                  # compiled to 179 VGPRs = two waves per SIMD for a copy kernel (profiles/archive/r3_notes.md)
-                                                 ('16step_span_kernel', 160, 0, 3), ('21formation_span_kernel', 128, 0, 4),
+                                                 ('16step_span_kernelILi0', 160, 0, 3), ('21formation_span_kernelILi0', 128, 0, 4),
+                                                 # BASELINE config 4's shape as compile-time constants: 72 bytes of scratch and still 5 % faster than the generic one
+                                                 # (0.218 -> 0.206 ms per step on one box, profiles/r6_shapes.md)
+                                                 ('21formation_span_kernelILi1', 128, 80, 4),
+                                                 ('11step_kernelILi2', 100, 0, 5), ('16step_span_kernelILi2', 168, 0, 3), ('17step_small_kernelILi1', 88, 0, 5),
+                                                 ('22step_span_small_kernelILi1', 168, 0, 3),
                                                  ('23minibatch_gather_kernel', 112, 0, 4),
                                                  # three waves per workgroup (64 envs x 3 agents: the shipped configuration): 168 registers at four
                                                  # workgroups per CU; six doubles of the carried state are spilled around the emission and reloaded at
                                                  # the top of the next step (loop depth 1, none of it inside the emission loops: profiles/r5_notes.md)
-                                                 ('19fairnav_span_kernelILi192', 168, 64, 3),
+                                                 ('19fairnav_span_kernelILi192ELi0', 168, 64, 3),
                                                  # the four-wave form (fewer than 160 or more than 192 agent lanes per workgroup: small geometries; only up
                                                  # to five agents -- beyond, fmarl_step_span launches per step): no carry, the state through global memory
                                                  # between the steps at four waves per SIMD (round 5: the carry at 128 registers, 236 bytes of scratch;
                                                  # the carry at 168 registers = three waves per SIMD measured 20 % slower, profiles/r6_fnav10_summary.md)
-                                                 ('19fairnav_span_kernelILi256', 128, 112, 4)):
+                                                 ('19fairnav_span_kernelILi256ELi0', 128, 112, 4)):
         vgpr, scratch, occ = find(part)
         assert vgpr <= max_vgpr and scratch <= max_scratch and occ >= min_occ, (part, vgpr, scratch, occ)

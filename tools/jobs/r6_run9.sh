@@ -1,0 +1,11 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r6j; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "fairnav or fnav or random_small or full_size" > $O/tests.log 2>&1; echo "tests rc=$?" >> $O/tests.log; tail -5 $O/tests.log
+grep -q "rc=0" $O/tests.log || exit 1
+M=$PWD/fair_marl_amd/csrc/variants/libfmarl_measure.so
+FMARL_LIB=$M timeout -k 10 200 python tools/phase_ticks.py fnav 0.5 600 2>&1 | grep -v libdrm > $O/ticks_fnav_steady.txt; cat $O/ticks_fnav_steady.txt
+for rep in 1 2; do for v in ship prev; do L=fair_marl_amd/csrc/libfmarl.so; [ $v != ship ] && L=fair_marl_amd/csrc/variants/libfmarl_$v.so; echo "== $v" >> $O/ab_fnav.txt; FMARL_LIB=$PWD/$L timeout -k 10 300 python tools/fnav_lines.py fnav eager,span,steady,steady-span 1 2>&1 | grep -v libdrm >> $O/ab_fnav.txt; done; done
+cat $O/ab_fnav.txt
+timeout -k 10 200 python tools/fnav_lines.py fnav10 eager,span 1 2>&1 | grep -v libdrm > $O/fnav10.txt; cat $O/fnav10.txt
