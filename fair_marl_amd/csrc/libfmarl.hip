@@ -260,6 +260,9 @@ static inline bool form_shape1(const FmarlConfig *c) { return !generic_shapes() 
     } while (0)
 // nav_fairassign_fairrew_formation_graph in the shape of the shipped FA / FA+FR weights (3 agents, 3 goals, 3 obstacles, no wall): the step
 // kernels' NL = 3 instances hold these counts as compile-time constants
+// (... and at the size BASELINE.md section 2 times the reference at: 10 agents, 10 goals, 3 obstacles -- the per-step kernel only: beyond five
+// agents fmarl_step_span launches per step)
+static inline bool fnav_shape10(const FmarlConfig *c) { return !generic_shapes() && c->num_agents == 10 && c->num_landmarks == 10 && c->num_obstacles == 3 && c->num_walls == 0; }
 static inline bool fnav_shape3(const FmarlConfig *c) { return !generic_shapes() && c->num_agents == 3 && c->num_landmarks == 3 && c->num_obstacles == 3 && c->num_walls == 0; }
 // (the per-step, reset-observation and rebuild kernels always run kThreads wide: only the span kernel has a three-wave form)
 #define FMARL_FNAV(h, kernel, grid, lds, st, ...) do { constexpr int TH = kThreads; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } while (0)
@@ -268,6 +271,7 @@ static inline bool fnav_shape3(const FmarlConfig *c) { return !generic_shapes() 
     do {                                                                                                \
         constexpr int TH = kThreads;                                                                    \
         if (fnav_shape3(&(h)->cfg)) { constexpr int NL = 3; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
+        else if (fnav_shape10(&(h)->cfg)) { constexpr int NL = 10; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); } \
         else { constexpr int NL = 0; hipLaunchKernelGGL(kernel, grid, dim3(TH), lds, st, __VA_ARGS__); }  \
     } while (0)
 #define FMARL_FNAV_T(h, threads, kernel, grid, lds, st, ...)                                            \
@@ -588,7 +592,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
         if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void *)formation_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void *)formation_rebuild_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);
-        for (const void *f : {(const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 256, 0>, (const void *)fairnav_kernel<true, 256, 3>,
+        for (const void *f : {(const void *)fairnav_rebuild_kernel<256>, (const void *)fairnav_kernel<true, 256, 0>, (const void *)fairnav_kernel<true, 256, 3>, (const void *)fairnav_kernel<true, 256, 10>,
                               (const void *)fairnav_kernel<false, 256, 0>, (const void *)fairnav_span_kernel<192, 0>, (const void *)fairnav_span_kernel<192, 3>,
                               (const void *)fairnav_span_kernel<256, 0>, (const void *)fairnav_span_kernel<256, 3>})
             if (e2 == hipSuccess) e2 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes);

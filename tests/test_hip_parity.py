@@ -658,6 +658,51 @@ def test_pipelined_sub_batches_fill_the_whole_batchs_time_slots(kw, mode):
         fm.OutputRing(pipe.engines[0], T, env_range=(0, n // 2))
 
 
+@pytest.mark.parametrize('case', ['nav3_small', 'nav10', 'form10', 'fnav3', 'fnav10'])
+def test_shape_instances_equal_the_generic_kernels(case):
+    """The step kernels exist a second time for the shapes BASELINE.json and the reference's scripts name, with the agent / obstacle / wall
+    counts as compile-time constants (unrolled loops whose LDS reads leave together: fmarl_step.hip shape_const, fairnav NL = 3,
+    formation_shape_const).  Same arithmetic in the same order: a rollout through them -- one launch per step and as spans, auto-resets
+    inside -- equals the generic kernels' (a child process with FMARL_GENERIC_SHAPES=1) in every output of every step and in the final
+    state, bit for bit (tests/shape_check.py)."""
+    import subprocess
+    import sys
+    import shape_check
+    mine = shape_check.digest(case)
+    env = dict(os.environ, FMARL_GENERIC_SHAPES='1')
+    res = subprocess.run([sys.executable, os.path.join(HERE, 'shape_check.py'), case], capture_output=True, text=True, timeout=600, env=env)
+    line = [l for l in res.stdout.splitlines() if l.startswith('DIGEST')]
+    assert res.returncode == 0 and line, res.stderr[-2000:]
+    assert line[0].split() == ['DIGEST', case, mine]
+
+
+@pytest.mark.parametrize('kw', [dict(num_agents=3, num_landmarks=3, episode_length=40000), dict(num_agents=7, num_landmarks=7, episode_length=9)],
+                         ids=['episode too long for the carried step counter', 'more than five agents'])
+def test_fairnav_span_falls_back_to_launches_per_step(kw):
+    """fmarl_step_span of nav_fairassign_fairrew_formation_graph launches per step where its span kernel must not or does not pay: the
+    carried state packs the step counter into 15 bits and the collision counts into 16 (an episode_length of 32 768 or
+    more would wrap them), and beyond five agents one launch per step is the faster form (profiles/r6_fnav10_summary.md).  Same results,
+    and the launch counters say what ran."""
+    cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_obstacles=2, min_dist_thresh=0.3, **kw)
+    n, T = 64, 12
+    a, b = fm.RolloutEngine(cfg, n, device=DEV, seed=3), fm.RolloutEngine(cfg, n, device=DEV, seed=3)
+    g = torch.Generator(device=DEV); g.manual_seed(4)
+    tape = torch.randint(0, 5, (T, n, cfg.N), device=DEV, generator=g, dtype=torch.int32)
+    a.reset(); b.reset()
+    a.profile_enable(T)
+    a.rollout(tape, mode='span')
+    for t in range(T):
+        b.step(tape[t])
+    torch.cuda.synchronize()
+    ms, steps = a.profile_read(with_steps=True)
+    assert len(ms) == T and all(k == 1 for k in steps)          # twelve launches of one step each, no span launch
+    for name in ('obs', 'reward', 'done', 'node_obs', 'adj_env'):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    sa, sb = a.get_state(), b.get_state()
+    for key in sa:
+        assert np.array_equal(sa[key], sb[key]), key
+
+
 def test_index_math_beyond_2_to_the_32_elements():
     """300 000 envs of the cfg 3 shape on one GPU: node_obs has 7.6e9 elements (> 2^32).  The first and the last
     envs must equal small engines placed at the same global env indices."""
