@@ -784,7 +784,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 192 ? 3 : 4) void fairnav_kerne
 struct FairnavSpanArgs { Params p; FmarlOutputs o; SpanStrides s; const int32_t *action_idx; const float *action_vec; int T, auto_reset; };
 // Shapes with more than 192 agent lanes per workgroup (N >= 4) run 256 threads wide, and there the carry does not pay: at three
 // workgroups per CU (168 registers, what the carry needs) the 10-agent shape took 0.775 ms per step against 0.634 for one launch per
-// step at four (profiles/r6_fnav10_summary.md) -- its step is bound by the assignment and the sequential walk, which want the fourth
+// step at four (profiles/r6_fnav_spans_by_n.txt) -- its step is bound by the assignment and the sequential walk, which want the fourth
 // workgroup's waves, not by the state's 100 bytes per agent.  So <256> sends the state through global memory between the steps (every
 // field is read back by the lane -- or, the env's counters, by the workgroup -- that stored it, behind the barrier) at four per CU.
 #ifndef FMARL_FNAV256_CARRY

@@ -525,7 +525,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     // -- for the span kernel only, which carries the state: one launch per step measured 4 % slower on three waves (the emission is
     // shared by fewer waves) and has no carry to fit
     // (only where the third wave is at least half full: with two waves of agents or little more -- 13 envs x 10 agents -- the three-wave form measured
-    // 23 % SLOWER than one launch per step, 0.776 against 0.631 ms per step, every phase of the step alike: profiles/r6_fnav10_summary.md)
+    // 23 % SLOWER than one launch per step, 0.776 against 0.631 ms per step, every phase of the step alike: profiles/r6_fnav_spans_by_n.txt)
     h->span_threads = (fnav && epb * p.N <= 192 && epb * p.N >= 160) ? 192 : h->threads;
     h->small_ok = false;   // (decided below, once the emission shapes are known)
     p.lds_stage = align16(epb * p.lds_env_bytes);
@@ -863,7 +863,7 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
         // that go out one launch per step, the state through global memory, same results)
         // Nor do more than five agents: the step is then bound by the assignment and the sequential walk, whose waves want every register
         // and the chip's lockstep -- measured per step at 65 536 envs, one launch per step / the span: N = 3 0.0531 / 0.0440 ms, 4 0.0979 /
-        // 0.0976, 5 0.1597 / 0.1522, 6 0.2143 / 0.2357, 8 0.3773 / 0.3838, 10 0.634 / 0.668 (profiles/r6_fnav10_summary.md).
+        // 0.0976, 5 0.1597 / 0.1522, 6 0.2143 / 0.2357, 8 0.3773 / 0.3838, 10 0.634 / 0.668 (profiles/r6_fnav_spans_by_n.txt).
         if (sc == FMARL_SCENARIO_FAIRNAV)
             k = (h->cfg.num_agents <= 5 && h->cfg.episode_length < 32768 && (long long)(h->cfg.num_agents - 1) * h->cfg.episode_length <= 65535) ? n_steps - t : 0;
         else if (h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;

@@ -1,0 +1,9 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+for c in cfg3 cfg4 n10 cfg2 fnav10; do
+  timeout -k 10 420 bash tools/profile.sh r6_$c $c > gpurun_out/r6_profile_$c.log 2>&1; echo "$c rc=$?"
+done
+timeout -k 10 420 bash tools/profile.sh r6_fnav fnav > gpurun_out/r6_profile_fnav.log 2>&1; echo "fnav rc=$?"
+PROF_ARGS="--launch span" timeout -k 10 420 bash tools/profile.sh r6s_fnav fnav > gpurun_out/r6_profile_fnav_span.log 2>&1; echo "fnav span rc=$?"
+ls gpurun_out

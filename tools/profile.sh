@@ -7,7 +7,7 @@ CFG=${2:-cfg3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-python bench.py --config $CFG --no-secondary $PROF_ARGS > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --config $CFG --no-secondary --detail $OUT/bench_detail.json $PROF_ARGS > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 200 --warmup 50 --no-cpu-baseline --no-secondary $PROF_ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 50 --warmup 25 --no-cpu-baseline --no-secondary $PROF_ARGS > $OUT/pmc_fetch.log 2>&1

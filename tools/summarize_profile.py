@@ -40,15 +40,18 @@ def counter_mean(path, kernel, counter):
     return float(np.mean(vals)), float(np.max(vals)), len(vals)
 
 
-bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])   # the compact stdout line
+# (round 6: the line is compact; the full record of the same run -- bench_detail.json, copied by tools/profile.sh -- holds the rest)
+detail = json.load(open(os.path.join(src, 'bench_detail.json'))) if os.path.exists(os.path.join(src, 'bench_detail.json')) else bench
+scen = 'fnav' if cfg.startswith('fnav') else cfg
 stats = one('trace/*/*kernel_stats.csv')
 shutil.copy(stats, os.path.join(dst, '%s_kernel_stats.csv' % stem))
 mode = bench['config'].get('launch_mode', 'step')
 small = 'small' in bench['roofline'].get('kernel', '')   # (small batches of navigation_graph run the step_small / step_span_small kernels)
 if mode == 'span':   # the dominant kernel is the span kernel (a launch = a run of steps)
-    kname = {'cfg4': 'formation_span_kernel', 'fnav': 'fairnav_span_kernel'}.get(cfg, 'step_span_small_kernel' if small else 'step_span_kernel')
+    kname = {'cfg4': 'formation_span_kernel', 'fnav': 'fairnav_span_kernel'}.get(scen, 'step_span_small_kernel' if small else 'step_span_kernel')
 else:
-    kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(cfg, ('step_small_kernel' if small else 'step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
+    kname = {'cfg4': 'formation_kernel<true>', 'fnav': 'fairnav_kernel<true>'}.get(scen, ('step_small_kernel' if small else 'step_kernel', 'step_end_kernel'))   # the step launch: 24 + 1 per episode
 f_mean, f_max, nf = counter_mean(one('pmc_fetch/*/*counter_collection.csv'), kname, 'FETCH_SIZE')
 w_mean, w_max, nw = counter_mean(one('pmc_write/*/*counter_collection.csv'), kname, 'WRITE_SIZE')
 traffic_mean = (2.0 * f_mean + w_mean) * 1024.0
@@ -70,12 +73,12 @@ with open(out, 'w') as f:
             '(kernel table); `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` in separate passes over '
             '`python3 bench.py --config %s --steps 50 --warmup 25 --no-cpu-baseline` (traffic); all with `--no-secondary` '
             '(the other configs of the default line run the same kernel names).\n\n' % (cfg, cfg, cfg))
-    f.write('## bench.py JSON line\n\n```json\n%s\n```\n\n' % json.dumps(bench, indent=1))
+    f.write('## bench.py JSON line (stdout; the full record of the run is bench_detail.json)\n\n```json\n%s\n```\n\n' % json.dumps(bench, indent=1))
     f.write('## rocprofv3 kernel stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n')
     for r in rows[:8]:
         f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'].split('(')[0][:60], r['Calls'], float(r['AverageNs']) / 1e3,
                                                        float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
-    rl = bench['roofline']
+    rl = detail['roofline']
     knames = kname if isinstance(kname, tuple) else (kname,)
     krows = [r for r in rows if any(is_kernel(r['Name'], k) for k in knames)]
     calls = sum(int(r['Calls']) for r in krows)
