@@ -624,6 +624,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
             FMARL_TICK(12);   // (measure builds) the placement itself
             __threadfence_block();   // (walls: the static entities of the placed envs are re-read from the state below)
             __syncthreads();
+            FMARL_TICK(13);   // (measure builds) the barrier behind the placement: a wave without a team waits here for the slowest one
             if (ended) {   // re-seat the env's lanes on the new episode (reset_world: nf:233-241, environment.py:882-898)
                 if (W == 0) {   // the placement left the new landmarks / obstacles in the env's float64 table: their f32 copies from there
                     for (int k = i; k < L + O; k += N) { const double2 e = t.pos()[N + k]; t.posf()[N + k] = make_float2((float)e.x, (float)e.y); }

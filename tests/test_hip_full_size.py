@@ -48,6 +48,21 @@ CASES = {
     'fnav': dict(mod=fnv, seed=34, stride=331,
                  kw=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=3, num_landmarks=3, num_obstacles=3,
                          goal_rew=30.0, collision_rew=30.0, min_dist_thresh=0.5)),
+    # the same scenario at two agents: more than 64 envs per workgroup -- the placement teams' second ballot word (fairnav_place_teams) --
+    # and 16-lane teams that hold 6 entities
+    'fnav2': dict(mod=fnv, seed=37, stride=499,
+                  kw=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=2, num_landmarks=2, num_obstacles=2,
+                          goal_rew=30.0, collision_rew=30.0, min_dist_thresh=0.5)),
+    # ... at ten agents (BASELINE.md section 2's N = 10 row, bench.py --config fnav10): the per-step kernel's 10-agent shape instance,
+    # 32-lane teams that hold 23 entities, fmarl_step_span launching per step
+    'fnav10': dict(mod=fnv, seed=38, stride=1511,
+                   kw=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=10, num_landmarks=10, num_obstacles=3,
+                           goal_rew=30.0, collision_rew=30.0)),   # (the default threshold: at larger ones ten agents reach the state in which the reference itself raises, nf:888-903)
+    # ... with walls: the teams draw the wall orientations, test the padded wall boxes and store the wall records; the re-seated lanes
+    # re-read the wall tables from the state
+    'fnavw': dict(mod=fnv, seed=39, stride=997, n=16384,
+                  kw=dict(scenario_name='nav_fairassign_fairrew_formation_graph', num_agents=4, num_landmarks=4, num_obstacles=2, num_walls=2,
+                          goal_rew=30.0, collision_rew=30.0, min_dist_thresh=0.45)),
 }
 
 
@@ -112,8 +127,11 @@ def test_full_batch_rollout_through_episode_ends_vs_oracle(case, epb_hint):
         ends += int(d.sum())
         early += int((d & ((t + 1) % T != 0)).sum())
     assert ends >= 2 * len(sample)
-    if case == 'fnav':
-        assert early > 50, early   # envs of one workgroup really ended at different steps
+    if case.startswith('fnav'):
+        if case != 'fnav10':   # (ten agents never all stop early at the default threshold: their envs end with the episode, all at once)
+            assert early > (50 if case == 'fnav' else 5), early   # envs of one workgroup really ended at different steps
+        if case == 'fnav2':
+            assert epb > 64, epb   # the second ballot word of the placement teams
     else:
         assert eng.phase == 2      # lockstep kept: the episode ends went through the folded / in-kernel path
     got = eng.get_state()
@@ -149,7 +167,7 @@ def test_full_batch_step_span_equals_step_by_step(case, epb_hint):
         a.step(tape[t])
     b.rollout(tape)                      # mode 'span' by default
     torch.cuda.synchronize()
-    assert b.launch_counts()[0] == T and a.phase == b.phase == (-1 if case == 'fnav' else 3)
+    assert b.launch_counts()[0] == T and a.phase == b.phase == (-1 if case.startswith('fnav') else 3)
     if case == 'fnav':
         assert int((a.field('episode') > a.field('episode').min()).sum()) > 100, 'envs must have ended episodes early, at different steps'
     for k in ('obs', 'node_obs', 'adj_env', 'reward', 'done', 'info'):

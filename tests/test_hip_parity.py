@@ -703,6 +703,32 @@ def test_fairnav_span_falls_back_to_launches_per_step(kw):
         assert np.array_equal(sa[key], sb[key]), key
 
 
+def test_store_pattern_writes_every_byte_of_its_groups_and_nothing_else():
+    """fmarl_store_pattern (the generic emission path's store pattern as a pure stream: tools/n10_pattern.py): windows at 4-byte aligned
+    starts as aligned 16-byte chunks + edge dwords, dword adjacency -- every word of every group of every slot is written exactly
+    where the pattern says, the last group of a slot is cut at the slot's size, and nothing outside the slots is touched."""
+    import ctypes as C
+    from fair_marl_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for node_group, adj_group, groups, slots, window in ((253000, 52900, 7, 3, 2816), (1188, 324, 5, 2, 64), (10120, 2116, 1, 1, 2816)):
+        node_slot, adj_slot = groups * node_group - 44 * 3, groups * adj_group - 4 * 5     # the last group is ragged
+        pad = 64
+        node = torch.full((slots * node_slot // 4 + 2 * pad,), float('nan'), device=DEV)
+        adj = torch.full((slots * adj_slot // 4 + 2 * pad,), float('nan'), device=DEV)
+        order = 1 if groups < 3 else next(o for o in range(groups // 2 + 1, 2 * groups) if np.gcd(o, groups) == 1)
+        rc = lib.fmarl_store_pattern(node[pad:].data_ptr(), adj[pad:].data_ptr(), node_group, adj_group, groups, slots, node_slot, adj_slot, window, order, st)
+        assert rc == 0, lib.fmarl_last_error()
+        torch.cuda.synchronize()
+        for t, n_in in ((node, slots * node_slot // 4), (adj, slots * adj_slot // 4)):
+            assert bool(torch.isnan(t[:pad]).all()) and bool(torch.isnan(t[pad + n_in:]).all())      # nothing before, nothing behind
+            assert not bool(torch.isnan(t[pad:pad + n_in]).any())                                     # every word inside
+    buf = torch.zeros(1024, device=DEV)
+    assert lib.fmarl_store_pattern(None, buf.data_ptr(), 64, 64, 1, 1, 64, 64, 64, 1, st) == 1
+    assert lib.fmarl_store_pattern(buf.data_ptr(), buf.data_ptr(), 64, 64, 4, 1, 256, 256, 64, 2, st) == 1 and b'coprime' in lib.fmarl_last_error()
+    assert lib.fmarl_store_pattern(buf.data_ptr(), buf.data_ptr(), 64, 64, 2, 1, 256, 64, 64, 1, st) == 1 and b'cover' in lib.fmarl_last_error()
+
+
 def test_index_math_beyond_2_to_the_32_elements():
     """300 000 envs of the cfg 3 shape on one GPU: node_obs has 7.6e9 elements (> 2^32).  The first and the last
     envs must equal small engines placed at the same global env indices."""

@@ -17,7 +17,7 @@ NAMES_NAV = ['loads+tables+barrier', 'physics', 'agent rows', 'scan statistics',
              'wait at the emission\'s first barrier (generic rows)']
 NAMES_FNAV = ['loads+tables+barrier', 'physics', 'distance table', 'assignment', 'status+bookkeeping', 'walk', 'reward+state+info (before the walk)',
               'obs+occupancy state+record', 'node rows', 'in-kernel reset of the ended envs: the rest', 'adj', 'in-kernel reset: the barrier that finds ended envs + the pre-draw of their Philox blocks',
-              'in-kernel reset: the placement (first lane of an ended env)']
+              'in-kernel reset: the placement (teams of lanes; round 5: the first lane of an ended env)', 'in-kernel reset: the barrier behind the placement']
 NAMES = ['loads+tables+barrier', 'physics', 'keys+ring+slots', 'agent x slot distances', 'occupancy', 'matchings', 'sets+walk',
          'obs+record', 'stats+hits+reward', 'state stores', 'info planes', 'node rows', 'adj']
 
