@@ -191,7 +191,7 @@ __device__ __forceinline__ int lexifair_upto3(const double *D, int L, int N, int
 // `reset_match`: the assignment of the envs that were reset inside this step (marked in words()[2]), written straight into the state
 // (goal_match of the workgroup's first env): nothing in the step reads it -- no table, no barrier behind it.
 template <int G, int THREADS>
-__device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, int *reset_match) {
+__device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds, int nenv, int *reset_match, bool warm = false) {
     const int group = threadIdx.x / G, ngroups = THREADS / G, lane = threadIdx.x % G;
     for (int el = group; el < nenv; el += ngroups) {
         const FairNavLds t(p, lds, el);
@@ -205,7 +205,9 @@ __device__ __forceinline__ void fairnav_assign_tasks(const Params &p, char *lds,
         double c[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) c[j] = (lane < p.N && j < p.N) ? t.D()[lane * p.L + j] : 0.0;
-        const int mc = lexifair_group<G>(c, p.N);
+        // `warm`: the step's re-assignment starts from the previous step's, which the env's match table holds (a launch that loaded the
+        // state loaded it too; inside a span the emission windows have been over it: the greedy start); so does a freshly placed env's first
+        const int mc = lexifair_group<G>(c, p.N, (warm && lane < p.N) ? t.match()[lane] : -1);
         if (lane < p.N) out[lane] = mc;
     }
 }
@@ -451,6 +453,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
         occ_i = p.goal_occ[g]; hist_i = p.goal_history[g];   // L == N
         step = p.cur_step[env] + (STEP ? 1 : 0);
         if (STEP && i == 0) *t.episode() = p.episode[env];
+        if (STEP && N > 3) t.match()[i] = p.goal_match[g];   // the previous step's assignment: where this step's solve starts (lexifair_group `warm`)
     }
     if (STEP && active && o.info) mtime = p.min_time[g];   // (constant over an episode: a cached load, issued here so that nothing waits for it)
     if (active) {
@@ -480,10 +483,10 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     FMARL_TICK(2);   // distance table
     if (STEP && !FMARL_SKIP(p, 64)) {
         // reward(agent 0)'s lexicographic-fair re-assignment on the new positions (nf:704-721)
-        if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, nullptr);
-        else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, nullptr);
-        else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, nullptr);
-        else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, nullptr);
+        if (N <= 4) fairnav_assign_tasks<4, THREADS>(p, lds, nenv, nullptr, !arrives);
+        else if (N <= 8) fairnav_assign_tasks<8, THREADS>(p, lds, nenv, nullptr, !arrives);
+        else if (N <= 16) fairnav_assign_tasks<16, THREADS>(p, lds, nenv, nullptr, !arrives);
+        else fairnav_assign_tasks<32, THREADS>(p, lds, nenv, nullptr, !arrives);
     } else if (active) {
         t.match()[i] = p.goal_match[g];
     }
