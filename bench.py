@@ -346,7 +346,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
                      'resets them itself; the state stays in registers between the steps (three waves per workgroup)' % (ep, eng.envs_per_workgroup))
     steps_per_launch = (c1[0] - c0[0]) / max(1, len(kernel_ms))
     if rmode == 'span' and steps_per_launch <= 1.0:
-        # fmarl_step_span launches per step where a span form does not pay (nav_fairassign_fairrew_formation_graph beyond five agents:
+        # fmarl_step_span launches per step where a span form does not pay (nav_fairassign_fairrew_formation_graph beyond three agents:
         # profiles/r6_fnav_spans_by_n.txt): say which kernel ran
         kern = KERNEL_NAMES.get(cfg.scenario_name, kern)
         span_text += '; at this shape the library launches per step inside fmarl_step_span'

@@ -861,11 +861,12 @@ int fmarl_step_span(void *handle, void *state, const int32_t *action_idx, const 
         int k = 0;
         // (its span carries the step counter in 15 bits and the two collision counts in 16 each -- FairnavCarry: episodes too long for
         // that go out one launch per step, the state through global memory, same results)
-        // Nor do more than five agents: the step is then bound by the assignment and the sequential walk, whose waves want every register
-        // and the chip's lockstep -- measured per step at 65 536 envs, one launch per step / the span: N = 3 0.0531 / 0.0440 ms, 4 0.0979 /
-        // 0.0976, 5 0.1597 / 0.1522, 6 0.2143 / 0.2357, 8 0.3773 / 0.3838, 10 0.634 / 0.668 (profiles/r6_fnav_spans_by_n.txt).
+        // Nor do more than three agents: the step is then bound by the assignment and the sequential walk, whose waves want every register,
+        // and only a launch per step can start its assignment from the previous step's (the span's emission windows run over the match
+        // table) -- measured per step at 65 536 envs, one launch per step / the span: N = 3 0.0483 / 0.0403 ms, 4 0.0961 / 0.1010,
+        // 5 0.1437 / 0.159, 6 0.2143 / 0.2357, 8 0.3773 / 0.3838, 10 0.634 / 0.668 (profiles/r6_fnav_spans_by_n.txt).
         if (sc == FMARL_SCENARIO_FAIRNAV)
-            k = (h->cfg.num_agents <= 5 && h->cfg.episode_length < 32768 && (long long)(h->cfg.num_agents - 1) * h->cfg.episode_length <= 65535) ? n_steps - t : 0;
+            k = (h->cfg.num_agents <= 3 && h->cfg.episode_length < 32768 && (long long)(h->cfg.num_agents - 1) * h->cfg.episode_length <= 65535) ? n_steps - t : 0;
         else if (h->lockstep) k = h->cfg.episode_length - 1 - h->host_step;
         if (k > n_steps - t) k = n_steps - t;
         FmarlOutputs o = *outs;

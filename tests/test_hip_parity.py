@@ -677,11 +677,11 @@ def test_shape_instances_equal_the_generic_kernels(case):
 
 
 @pytest.mark.parametrize('kw', [dict(num_agents=3, num_landmarks=3, episode_length=40000), dict(num_agents=7, num_landmarks=7, episode_length=9)],
-                         ids=['episode too long for the carried step counter', 'more than five agents'])
+                         ids=['episode too long for the carried step counter', 'more than three agents'])
 def test_fairnav_span_falls_back_to_launches_per_step(kw):
     """fmarl_step_span of nav_fairassign_fairrew_formation_graph launches per step where its span kernel must not or does not pay: the
     carried state packs the step counter into 15 bits and the collision counts into 16 (an episode_length of 32 768 or
-    more would wrap them), and beyond five agents one launch per step is the faster form (profiles/r6_fnav_spans_by_n.txt).  Same results,
+    more would wrap them), and beyond three agents one launch per step is the faster form (profiles/r6_fnav_spans_by_n.txt).  Same results,
     and the launch counters say what ran."""
     cfg = fm.EnvConfig(scenario_name='nav_fairassign_fairrew_formation_graph', num_obstacles=2, min_dist_thresh=0.3, **kw)
     n, T = 64, 12

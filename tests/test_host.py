@@ -480,7 +480,7 @@ def test_hot_kernels_keep_their_register_and_scratch_budget():
                                                  # the top of the next step (loop depth 1, none of it inside the emission loops: profiles/r5_notes.md)
                                                  ('19fairnav_span_kernelILi192ELi0', 168, 64, 3),
                                                  # the four-wave form (fewer than 160 or more than 192 agent lanes per workgroup: small geometries; only up
-                                                 # to five agents -- beyond, fmarl_step_span launches per step): no carry, the state through global memory
+                                                 # to three agents -- beyond, fmarl_step_span launches per step): no carry, the state through global memory
                                                  # between the steps at four waves per SIMD (round 5: the carry at 128 registers, 236 bytes of scratch;
                                                  # the carry at 168 registers = three waves per SIMD measured 20 % slower, profiles/r6_fnav_spans_by_n.txt)
                                                  ('19fairnav_span_kernelILi256ELi0', 128, 112, 4)):
