@@ -248,7 +248,38 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
     bool any_skip = false;
     for (uint32_t e = lane; e < w1 - w0; e += 64) any_skip |= *(const int *)(tb0 + (size_t)e * k_env + k_flag) != 0;
     any_skip = __ballot(any_skip) != 0;   // (uniform: rare -- only reset emissions leave some envs' matrices alone)
-    for (uint32_t idx = lane; idx < total; idx += 64) {
+    uint32_t idx = lane;
+    auto advance = [&](uint32_t &el_, uint32_t &a_, uint32_t &b_) {   // 64 entries on, two carries
+        b_ += qb; a_ += qa; el_ += qe;
+        const bool cb = b_ >= E;
+        b_ -= cb ? E : 0u; a_ += cb ? 1u : 0u;
+        const bool ca = a_ >= E;
+        a_ -= ca ? E : 0u; el_ += ca ? 1u : 0u;
+    };
+    if (!any_skip && !(MODE == 1 || (MODE == 2 && count)) && total >= 1024u) {
+        // four entries per trip (round 6): the eight LDS reads leave together, then the four stores -- one entry per trip waited ~300
+        // cycles for its two reads (10 agents: adj 16 000 of a wave-step's 64 700 cycles, profiles/r6_ticks_n10_span.txt; spans 0.1798 ->
+        // 0.1733 ms per step).  Not for a wave's share of a few hundred entries (small batches: the lanes would split between this
+        // loop and the one below, 6.1 -> 6.3 us per step at 4 096 x 3)
+        for (; idx + 192 < total; idx += 256) {
+            uint32_t e1 = elq, a1 = a, b1 = b;
+            advance(e1, a1, b1);
+            uint32_t e2 = e1, a2 = a1, b2 = b1;
+            advance(e2, a2, b2);
+            uint32_t e3 = e2, a3 = a2, b3 = b2;
+            advance(e3, a3, b3);
+            const float2 *t0 = (const float2 *)(tb0 + (size_t)elq * k_env + k_posf), *t1 = (const float2 *)(tb0 + (size_t)e1 * k_env + k_posf);
+            const float2 *t2 = (const float2 *)(tb0 + (size_t)e2 * k_env + k_posf), *t3 = (const float2 *)(tb0 + (size_t)e3 * k_env + k_posf);
+            const float2 pa0 = t0[a], pb0 = t0[b], pa1 = t1[a1], pb1 = t1[b1], pa2 = t2[a2], pb2 = t2[b2], pa3 = t3[a3], pb3 = t3[b3];
+            dst[idx] = dist_f32(pa0.x - pb0.x, pa0.y - pb0.y);
+            dst[idx + 64] = dist_f32(pa1.x - pb1.x, pa1.y - pb1.y);
+            dst[idx + 128] = dist_f32(pa2.x - pb2.x, pa2.y - pb2.y);
+            dst[idx + 192] = dist_f32(pa3.x - pb3.x, pa3.y - pb3.y);
+            elq = e3; a = a3; b = b3;
+            advance(elq, a, b);
+        }
+    }
+    for (; idx < total; idx += 64) {
         const char *tb = tb0 + (size_t)elq * k_env;
         const float2 pa = ((const float2 *)(tb + k_posf))[a], pb = ((const float2 *)(tb + k_posf))[b];   // the f32 position table (what a learner-side rebuild has)
         const float d = dist_f32(pa.x - pb.x, pa.y - pb.y);
@@ -257,11 +288,7 @@ __device__ __forceinline__ void emit_adj_generic(const Params &p, const FmarlOut
             dst[idx] = d;
             if (MODE == 1 || (MODE == 2 && count)) ec.add(el_begin + (int)(w0 + elq), d);
         }
-        b += qb; a += qa; elq += qe;
-        const bool cb = b >= E;
-        b -= cb ? E : 0u; a += cb ? 1u : 0u;
-        const bool ca = a >= E;
-        a -= ca ? E : 0u; elq += ca ? 1u : 0u;
+        advance(elq, a, b);
     }
 }
 
