@@ -1974,7 +1974,7 @@ def test_time_slots_with_interleaved_physical_memory():
     with pytest.raises(MemoryError):
         alloc_time_slots(lib, torch.device(DEV), (2, (total1 // 4 // (1 << 20) * (1 << 20)) * 3 // 4), spread=True)   # 2 x 0.75 x the device
     # nothing leaked (the free figure may GROW: handing the never-mapped range back lets the runtime return a cached 64 MiB block of its own;
-    # four failed attempts in a row in a fresh process leave it unchanged: tools/jobs/r6_oom_probe.py)
+    # four failed attempts in a row in a fresh process leave it unchanged: tools/oom_probe.py)
     assert free1 - torch.cuda.mem_get_info()[0] < 64 * (1 << 20)
     assert float(torch.ones(4, device=DEV).sum()) == 4.0
     t2, inter2 = alloc_time_slots(lib, torch.device(DEV), (4, 1000, 3), spread=None)       # small slots: plain
