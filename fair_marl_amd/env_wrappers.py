@@ -14,6 +14,7 @@ There are no worker processes: every env lives in one ``RolloutEngine`` on one G
 throughput work use the engine directly (``venv.engine``): these wrappers copy every output to
 the host each step, which only makes sense for small ``n_rollout_threads``.
 """
+import os
 import warnings
 from abc import ABC, abstractmethod
 
@@ -130,11 +131,13 @@ class _EngineVecEnv(ShareVecEnv):
 
     def _fetch(self, *tensors):
         """Device tensors -> fresh float64 NumPy arrays of the same shapes (what the reference's workers pipe back).
-        The widening and the materialisation of stride-0 views (the per-agent adj) happen on the device; everything
-        crosses PCIe in ONE copy into a pinned staging buffer, from which the caller-owned arrays are cut."""
-        flat = torch.cat([t.detach().to(torch.float64).reshape(-1) for t in tensors])
-        if self._staging is None or self._staging.numel() < flat.numel():
-            self._staging = torch.empty(flat.numel(), dtype=torch.float64, pin_memory=True)
+        Everything crosses PCIe in ONE copy into a pinned staging buffer, as float32 -- what the device holds: half the bytes of the
+        float64 the caller gets -- and is widened (exactly) by the copy that cuts the caller-owned arrays out of the staging buffer,
+        a pass the host makes anyway (round 6; before, the widening happened on the device and twice the bytes crossed)."""
+        dt = torch.float32 if os.environ.get('FMARL_FETCH_F64') != '1' else torch.float64   # (=1: the device-side widening of rounds 1-5, for A/B)
+        flat = torch.cat([t.detach().to(dt).reshape(-1) for t in tensors])
+        if self._staging is None or self._staging.numel() < flat.numel() or self._staging.dtype != dt:
+            self._staging = torch.empty(flat.numel(), dtype=dt, pin_memory=True)
         host = self._staging[:flat.numel()]
         host.copy_(flat, non_blocking=True)
         torch.cuda.current_stream(self.engine.device).synchronize()
