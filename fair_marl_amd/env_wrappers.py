@@ -141,13 +141,35 @@ class _EngineVecEnv(ShareVecEnv):
         host = self._staging[:flat.numel()]
         host.copy_(flat, non_blocking=True)
         torch.cuda.current_stream(self.engine.device).synchronize()
-        arr, out, o = host.numpy(), [], 0
+        arr, out, o, jobs = host.numpy(), [], 0, []
         for slot, t in enumerate(tensors):
             dst = self._fresh(tuple(t.shape), slot)
-            np.copyto(dst.reshape(-1), arr[o:o + t.numel()])
+            flat_dst, m = dst.reshape(-1), t.numel()
+            if m >= self.PARALLEL_COPY_ELEMS and self._copy_pool() is not None:
+                # large outputs (node_obs at 512 envs x 32 agents: 104 MB of float64): the widening copy in slices on a few host threads
+                # (NumPy releases the GIL inside copyto) -- one thread fills them at 8 GB/s, 13 ms of a 16 ms step
+                k = self._copy_threads
+                cuts = [o + m * j // k for j in range(k + 1)]
+                jobs += [self._pool.submit(np.copyto, flat_dst[a - o:b - o], arr[a:b]) for a, b in zip(cuts, cuts[1:])]
+            else:
+                np.copyto(flat_dst, arr[o:o + m])
             out.append(dst)
-            o += t.numel()
+            o += m
+        for j in jobs:
+            j.result()
         return out
+
+    PARALLEL_COPY_ELEMS = 4 << 20   # outputs of four million elements and more are widened by several host threads (below, starting them costs more: 4 096 x 3 went 0.71 -> 0.9 ms)
+    _pool, _copy_threads = None, 0
+
+    def _copy_pool(self):
+        if self._pool is None and self._copy_threads == 0:
+            k = min(8, (os.cpu_count() or 1) // 2)
+            self._copy_threads = k if k >= 2 else -1
+            if k >= 2:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=k, thread_name_prefix='fmarl-copy')
+        return self._pool
 
     def _fresh(self, shape, slot=0):
         """A float64 array for output number ``slot`` of this call: new (the caller's for good) unless ``reuse_outputs = k``
@@ -188,6 +210,9 @@ class _EngineVecEnv(ShareVecEnv):
         return np.broadcast_to(np.arange(N, dtype=np.int64).reshape(1, N, 1), (n, N, 1)).copy()
 
     def close_extras(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         self.engine.close()
 
     def reset_task(self):
