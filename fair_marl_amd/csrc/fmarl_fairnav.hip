@@ -456,6 +456,8 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
         if (STEP && N > 3) t.match()[i] = p.goal_match[g];   // the previous step's assignment: where this step's solve starts (lexifair_group `warm`)
     }
     if (STEP && active && o.info) mtime = p.min_time[g];   // (constant over an episode: a cached load, issued here so that nothing waits for it)
+    // the agent's action index: a load from the tape in HBM that the contact forces would otherwise wait for at the head of the physics
+    const int a_pre = (STEP && active && action_idx) ? action_idx[g] : -1;
     if (active) {
         t.pos()[i] = x;
         t.occ()[i] = occ_i; t.hist()[i] = (int8_t)hist_i;
@@ -467,7 +469,7 @@ __device__ __forceinline__ void fairnav_pass(const Params &p, const FmarlOutputs
     if (!arrives) load_statics_range(p, lds, env0, 0, nenv, tid, THREADS);
     __syncthreads();
     FMARL_TICK(0);   // state loads, entity tables, barrier
-    if (STEP && active) world_step_agent<NL, NL ? 3 : 0, 0>(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0);
+    if (STEP && active) world_step_agent<NL, NL ? 3 : 0, 0>(p, t.base, i, g, action_idx, action_vec, x, v, pd, status == 0.0, a_pre);
     __syncthreads();   // every lane has finished reading the old positions
     FMARL_TICK(1);   // physics
     if (active) t.pos()[i] = x;
