@@ -308,7 +308,9 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     torch.cuda.synchronize(device)
     # one launch per step: an event pair around every launch sits BETWEEN the launches (6-7 us per step at 65 536 x 3: a tenth of the
     # step) -- the wall time comes from a pass without them, the kernel times from a second pass of the same steps
-    eng.profile_enable(steps if rmode != 'eager' else 0)
+    # (the same for the spans of a launch-bound batch: four event records per episode of 150 us)
+    two_pass = rmode == 'eager' or (rmode == 'span' and n * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS)
+    eng.profile_enable(0 if two_pass else steps)
     c0 = eng.launch_counts()
     if rmode == 'graph':
         for _ in range(2):
@@ -323,7 +325,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
         episode(rmode)
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    if rmode == 'eager':
+    if two_pass:
         eng.profile_enable(steps)
         c0 = eng.launch_counts()
         for _ in range(steps // ep):
@@ -371,7 +373,7 @@ def secondary_line(name, mode, device, steps=300, warmup=50, slots='ring', arena
     if n * cfg.N < fm.RolloutEngine.GRAPH_BELOW_AGENTS:
         out['bound'] = ('launch / latency: the batch cannot fill the chip (%d waves on 256 CUs), a step is one wave\'s dependent float64 chain; '
                         'an HBM roofline does not apply -- `frac` is reported for completeness' % ((n * cfg.N + 63) // 64))
-    if rmode == 'eager':
+    if two_pass:
         out['timing'] = ('ms_per_step: a pass without per-launch events; kernel_avg_ms: a second pass of the same steps with a hipEvent pair '
                          'around every launch (the pairs sit between the launches and delay their dispatch: kernel_avg_ms can exceed ms_per_step)')
     if mode.startswith('steady'):

@@ -251,6 +251,15 @@ static inline int nav_shape(const FmarlConfig *c) {
         if (nav_shape(&(h)->cfg) == 2) { constexpr int SH = 2; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); } \
         else { constexpr int SH = 0; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }                    \
     } while (0)
+// (the launch that ends an episode, step_end_kernel: also for shape 1 -- a small batch's spans end in it once per episode, and at 4 096 x 3
+// it is a fifth of the episode's kernel time)
+#define FMARL_NAV_END(h, kernel, grid, threads, lds, st, ...)                                                           \
+    do {                                                                                                                \
+        const int sh_ = nav_shape(&(h)->cfg);                                                                           \
+        if (sh_ == 1) { constexpr int SH = 1; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }           \
+        else if (sh_ == 2) { constexpr int SH = 2; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }      \
+        else { constexpr int SH = 0; hipLaunchKernelGGL(kernel, grid, threads, lds, st, __VA_ARGS__); }                    \
+    } while (0)
 // fair_graph_formation in BASELINE config 4's shape (fmarl_formation.hip formation_shape_const)
 static inline bool form_shape1(const FmarlConfig *c) { return !generic_shapes() && c->num_agents == 10 && c->num_landmarks == 1 && c->num_obstacles == 3 && c->num_walls == 2; }
 #define FMARL_FORM(h, kernel, grid, threads, lds, st, ...)                                                              \
@@ -580,7 +589,7 @@ int fmarl_create(const FmarlConfig *cfg, void **handle) {
     }
     if (h->lds_bytes > 64 * 1024) {
         hipError_t e1 = hipSuccess;
-        for (const void *f : {(const void *)step_kernel<0>, (const void *)step_kernel<2>, (const void *)step_end_kernel<0>,
+        for (const void *f : {(const void *)step_kernel<0>, (const void *)step_kernel<2>, (const void *)step_end_kernel<0>, (const void *)step_end_kernel<1>,
                               (const void *)step_end_kernel<2>, (const void *)step_span_kernel<0>, (const void *)step_span_kernel<2>,
                               (const void *)step_small_kernel<0>, (const void *)step_small_kernel<1>,
                               (const void *)step_span_small_kernel<0>, (const void *)step_span_small_kernel<1>})
@@ -730,7 +739,7 @@ int fmarl_init_state(void *handle, void *state, void *stream) {
         Params q = bind(h, state);
         q.n_envs = 0;
         FmarlOutputs none = {};
-        FMARL_NAV_FULL(h, step_end_kernel<SH>, dim3(1), dim3(kThreads), h->lds_bytes, st, q, none, (const int32_t *)nullptr,
+        FMARL_NAV_END(h, step_end_kernel<SH>, dim3(1), dim3(kThreads), h->lds_bytes, st, q, none, (const int32_t *)nullptr,
                        (const float *)nullptr, 0);
         HIP_OK(hipGetLastError());
     }
@@ -807,7 +816,7 @@ int fmarl_step(void *handle, void *state, const int32_t *action_idx, const float
         FMARL_FORM(h, (formation_kernel<true, SH>), dim3(h->grid), dim3(h->threads), h->lds_bytes, st, p, *outs, action_idx,
                    action_vec, auto_reset ? 1 : 0);
     else if (fold)
-        FMARL_NAV_FULL(h, step_end_kernel<SH>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec, 1);
+        FMARL_NAV_END(h, step_end_kernel<SH>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec, 1);
     else if (h->small_ok && !outs->edge_nnz)
         FMARL_NAV_SMALL(h, step_small_kernel<SH>, dim3(h->grid), dim3(kThreads), h->lds_bytes, st, p, *outs, action_idx, action_vec,
                         auto_reset ? 1 : 0);
