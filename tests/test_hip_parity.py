@@ -439,6 +439,36 @@ def test_bench_launch_mode_does_not_depend_on_the_number_of_gpus(tmp_path):
     assert two['multi_gpu']['span_tuning']['chosen'] == two['config']['span_steps'] and two['multi_gpu']['ideal_vs_n1_headline'] > 0
 
 
+def test_bench_drivers_command_prints_one_compact_line(tmp_path):
+    """The driver's own command, whole: `python3 bench.py --gpus 1 --steps 20 --warmup 5` -- cpu baseline, headline, every `secondary` entry
+    in its child process -- prints exactly one stdout line, at most bench.COMPACT_LIMIT bytes of strict JSON (round 5's 21 KB line came
+    back from the driver unparsed: no driver-held headline for the round), with the contract's keys, `roofline` and `cpu_baseline` as
+    scalars, one four-field row per `secondary` entry, and the full record beside it."""
+    import json
+    import subprocess
+    import sys
+    import gc
+    import bench
+    root = os.path.dirname(HERE)
+    gc.collect()
+    torch.cuda.empty_cache()   # (what earlier tests of this process left in torch's cache: the bench's ring of time slots takes 205 of the 288 GB)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--detail', str(tmp_path / 'd.json')],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and len(out[0].encode()) <= bench.COMPACT_LIMIT, (len(out), [len(l) for l in out])
+    c = json.loads(out[0], parse_constant=lambda k: pytest.fail('non-strict JSON constant %s' % k))
+    d = json.load(open(str(tmp_path / 'd.json')))
+    assert c['n_gpus'] == 1 and c['steps'] == 20 and c['warmup'] == 5 and c['higher_is_better'] is True and c['vs_baseline'] is None
+    assert c['value'] == pytest.approx(65536 * 32 * 20 / (c['ms_per_step'] * 20e-3), rel=1e-4) and c['value'] > 1e7      # BASELINE's floor
+    r = c['roofline']
+    assert r['bound'] == 'hbm' and r['kernel'] == 'step_span_kernel' and 0.4 < r['frac'] < 1.0 and r['frac'] == pytest.approx(r['achieved'] / r['peak'], rel=1e-4)
+    assert r['kernel_avg_ms'] / r['kernel_steps_per_launch'] <= c['ms_per_step'] * 1.02 and r['traffic'] > 0
+    assert c['cpu_baseline']['kind'] == 'port' and c['cpu_baseline']['value'] > 0 and c['cpu_baseline']['cores'] >= 1
+    assert [row[:2] for row in c['secondary']] == [list(nm) for nm in bench.SECONDARY] and all(row[2] > 0 and 0 < row[3] < 1 for row in c['secondary'])
+    assert 'child_errors' not in c and len(d['secondary']) == len(bench.SECONDARY) and d['value'] == pytest.approx(c['value'], rel=1e-5)
+
+
 def test_bench_exchange_through_rccl_with_one_rank(tmp_path):
     """The nccl (= RCCL) branch of sharding.py / bench.py on the one GPU of this box: a process group of ONE rank, every
     step's record and every episode record gathered through RCCL inside the timed loop, all_reduce for the timing."""
